@@ -1,0 +1,354 @@
+/*
+ * kpal_oracle.c -- CPU restatement of kPAL's k-mer counting / profile-distance hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: it restates, operation for
+ * operation, the reference's pure-Python/NumPy algorithm so the HIP product path can be
+ * checked bit-for-bit (integers) or to 1e-9 relative (fp64 sums).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * package (kpal_amd/) never imports, links or calls anything in oracle/.
+ *
+ * Parity pinning: every function here is checked against golden vectors produced by
+ * importing the unmodified reference (tools/gen_golden.py -> tests/golden/), see
+ * tests/test_oracle_golden.py.
+ *
+ * Citations are file:line into /root/reference (kPAL 2.1.2.dev).
+ *
+ * Build: gcc -O2 -fPIC -shared -o libkpal_oracle.so kpal_oracle.c -lm   (see Makefile)
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------ *
+ * a1: nucleotide -> 2-bit code.  kpal/klib.py:43-48  (A/a=0, C/c=1, G/g=2, T/t=3);
+ * every other byte is outside the alphabet regex '[^AaCcGgTt]' (klib.py:152).
+ * ------------------------------------------------------------------------------------ */
+static inline int nucleotide_to_binary(uint8_t c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a2: Profile.from_sequences inner loops for ONE sequence.  kpal/klib.py:154-168.
+ *   for part in alphabet.split(sequence):           (155)  maximal runs of AaCcGgTt
+ *     if len(part) >= length:                        (156)
+ *        fold the first k characters                 (157-161), counts[binary] += 1 (162)
+ *        for every further char: roll + mask, += 1   (165-168)
+ * counts is accumulated into (+=), so calling it once per sequence reproduces the outer
+ * loop (154).  counts must hold 4^k int64.
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API int kpal_oracle_count_sequence(const uint8_t *seq, size_t n, int k, int64_t *counts)
+{
+    if (k < 1 || k > 31) return -1;
+    const uint64_t bitmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    size_t i = 0;
+    while (i < n) {
+        /* skip separators */
+        while (i < n && nucleotide_to_binary(seq[i]) < 0) i++;
+        size_t start = i;
+        while (i < n && nucleotide_to_binary(seq[i]) >= 0) i++;
+        size_t len = i - start;               /* one `part` of alphabet.split */
+        if (len >= (size_t)k) {
+            uint64_t binary = 0;
+            size_t j;
+            for (j = 0; j < (size_t)k; j++)
+                binary = (binary << 2) | (uint64_t)nucleotide_to_binary(seq[start + j]);
+            counts[binary] += 1;
+            for (; j < len; j++) {
+                binary = ((binary << 2) | (uint64_t)nucleotide_to_binary(seq[start + j])) & bitmask;
+                counts[binary] += 1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a5: Profile.reverse_complement.  kpal/klib.py:394-412: number = ~number; then k times
+ * result = (result << 2) | (number & 3); number >>= 2.
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API uint64_t kpal_oracle_reverse_complement(uint64_t number, int k)
+{
+    number = ~number;
+    uint64_t result = 0;
+    for (int i = 0; i < k; i++) {
+        result = (result << 2) | (number & 3ULL);
+        number >>= 2;
+    }
+    return result;
+}
+
+/* a6: Profile.balance, in place.  kpal/klib.py:285-298.  int64 adds wrap like NumPy. */
+ORACLE_API void kpal_oracle_balance(int64_t *counts, int k)
+{
+    const uint64_t number = 1ULL << (2 * k);
+    uint64_t *c = (uint64_t *)counts;
+    for (uint64_t i = 0; i < number; i++) {
+        uint64_t i_rc = kpal_oracle_reverse_complement(i, k);
+        if (i < i_rc) {
+            uint64_t temp = c[i];
+            c[i] += c[i_rc];
+            c[i_rc] += temp;
+        } else if (i == i_rc) {
+            c[i] += c[i];
+        }
+    }
+}
+
+/* a7: Profile.split.  kpal/klib.py:300-327.  Returns the output length
+ * ((4^k + #palindromes)/2); forward/reverse must have room for 4^k entries. */
+ORACLE_API size_t kpal_oracle_split(const int64_t *counts, int k, int64_t *forward, int64_t *reverse)
+{
+    const uint64_t number = 1ULL << (2 * k);
+    const uint64_t *c = (const uint64_t *)counts;
+    size_t m = 0;
+    for (uint64_t i = 0; i < number; i++) {
+        uint64_t i_rc = kpal_oracle_reverse_complement(i, k);
+        if (i < i_rc) {
+            forward[m] = (int64_t)(c[i] * 2ULL);
+            reverse[m] = (int64_t)(c[i_rc] * 2ULL);
+            m++;
+        } else if (i == i_rc) {
+            forward[m] = counts[i];
+            reverse[m] = counts[i];
+            m++;
+        }
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a8: pairwise functions on int64.  kpal/metrics.py:159-162.
+ *   prod: abs(x - y) / ((x + 1) * (y + 1))      sum: abs(x - y) / (x + y + 1)
+ * NumPy evaluates numerator and denominator in int64 (silent wrap-around), then
+ * true_divide converts both to float64 and divides (metrics.py:12 imports division).
+ * ------------------------------------------------------------------------------------ */
+static inline int64_t wrap_abs(int64_t v) { return v < 0 ? (int64_t)(0ULL - (uint64_t)v) : v; }
+
+static inline double pairwise_prod_i64(int64_t x, int64_t y)
+{
+    int64_t num = wrap_abs((int64_t)((uint64_t)x - (uint64_t)y));
+    int64_t den = (int64_t)(((uint64_t)x + 1ULL) * ((uint64_t)y + 1ULL));
+    return (double)num / (double)den;
+}
+
+static inline double pairwise_sum_i64(int64_t x, int64_t y)
+{
+    int64_t num = wrap_abs((int64_t)((uint64_t)x - (uint64_t)y));
+    int64_t den = (int64_t)((uint64_t)x + (uint64_t)y + 1ULL);
+    return (double)num / (double)den;
+}
+
+static inline double pairwise_prod_f64(double x, double y) { return fabs(x - y) / ((x + 1.0) * (y + 1.0)); }
+static inline double pairwise_sum_f64(double x, double y) { return fabs(x - y) / (x + y + 1.0); }
+
+/* NumPy's float64 add.reduce on a contiguous array is pairwise summation
+ * (numpy/core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum, block size 128, 8-way
+ * unrolled).  Third-party arithmetic: NumPy is not under /root/reference (setup.py:9,
+ * unpinned; goldens were generated with 1.26.4).  Restated from its published algorithm so
+ * the oracle's sums track `distances.sum()` (metrics.py:123) as closely as possible. */
+static double np_pairwise_sum(const double *a, size_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (size_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8) {
+            r[0] += a[i + 0]; r[1] += a[i + 1]; r[2] += a[i + 2]; r[3] += a[i + 3];
+            r[4] += a[i + 4]; r[5] += a[i + 5]; r[6] += a[i + 6]; r[7] += a[i + 7];
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a9: metrics.multiset.  kpal/metrics.py:101-123.
+ *   nonzero   = np.where(np.logical_or(left, right))        (121)
+ *   distances = pairwise(left[nonzero], right[nonzero])     (122)
+ *   return distances.sum() / (len(distances) + 1)           (123)
+ * pairwise: 0 = prod, 1 = sum.  *m_out (optional) receives len(distances).
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API double kpal_oracle_multiset_i64(const int64_t *left, const int64_t *right, size_t n,
+                                           int pairwise, int64_t *m_out)
+{
+    double *distances = (double *)malloc((n ? n : 1) * sizeof(double));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (left[i] != 0 || right[i] != 0)
+            distances[m++] = pairwise == 0 ? pairwise_prod_i64(left[i], right[i])
+                                           : pairwise_sum_i64(left[i], right[i]);
+    }
+    double s = np_pairwise_sum(distances, m);
+    free(distances);
+    if (m_out) *m_out = (int64_t)m;
+    return s / (double)(m + 1);
+}
+
+/* float64 inputs (profiles after do_scale, kdistlib.py:149-157) */
+ORACLE_API double kpal_oracle_multiset_f64(const double *left, const double *right, size_t n,
+                                           int pairwise, int64_t *m_out)
+{
+    double *distances = (double *)malloc((n ? n : 1) * sizeof(double));
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (left[i] != 0.0 || right[i] != 0.0)
+            distances[m++] = pairwise == 0 ? pairwise_prod_f64(left[i], right[i])
+                                           : pairwise_sum_f64(left[i], right[i]);
+    }
+    double s = np_pairwise_sum(distances, m);
+    free(distances);
+    if (m_out) *m_out = (int64_t)m;
+    return s / (double)(m + 1);
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a10: metrics.euclidean = vector_length(np.subtract(left, right))  metrics.py:126-135,
+ * vector_length = np.sqrt(np.dot(v, v))                             metrics.py:36-46.
+ * For int64 inputs the dot is an exact int64 (wrap-around); sqrt is IEEE.
+ * *dot_out (optional) receives the int64 dot product.
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API double kpal_oracle_euclidean_i64(const int64_t *left, const int64_t *right, size_t n,
+                                            int64_t *dot_out)
+{
+    uint64_t acc = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t d = (uint64_t)left[i] - (uint64_t)right[i];
+        acc += d * d;
+    }
+    if (dot_out) *dot_out = (int64_t)acc;
+    return sqrt((double)(int64_t)acc);
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * a11: ProfileDistance.distance, default + do_balance paths.  kpal/kdistlib.py:126-161.
+ *   copies (136-137); if do_balance: balance both (139-141); then multiset(pairwise) or
+ *   distance_function (159-161).  metric: 0 = multiset/prod, 1 = multiset/sum, 2 = euclidean.
+ * Inputs are never modified (tests/test_kdistlib.py:124-135).
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API double kpal_oracle_distance(const int64_t *left, const int64_t *right, int k,
+                                       int do_balance, int metric)
+{
+    const size_t n = (size_t)1 << (2 * k);
+    int64_t *l = (int64_t *)malloc(n * sizeof(int64_t));
+    int64_t *r = (int64_t *)malloc(n * sizeof(int64_t));
+    memcpy(l, left, n * sizeof(int64_t));
+    memcpy(r, right, n * sizeof(int64_t));
+    if (do_balance) {
+        kpal_oracle_balance(l, k);
+        kpal_oracle_balance(r, k);
+    }
+    double d = metric == 2 ? kpal_oracle_euclidean_i64(l, r, n, NULL)
+                           : kpal_oracle_multiset_i64(l, r, n, metric, NULL);
+    free(l);
+    free(r);
+    return d;
+}
+
+/* a12: kdistlib.distance_matrix values.  kpal/kdistlib.py:179-186: rows i = 1..P-1,
+ * columns j < i, value = dist.distance(profiles[i], profiles[j]).  out holds P(P-1)/2
+ * doubles, row-major in that order.  profiles: P contiguous vectors of 4^k int64. */
+ORACLE_API void kpal_oracle_distance_matrix(const int64_t *profiles, int P, int k, int do_balance,
+                                            int metric, double *out)
+{
+    const size_t n = (size_t)1 << (2 * k);
+    size_t o = 0;
+    for (int i = 1; i < P; i++)
+        for (int j = 0; j < i; j++)
+            out[o++] = kpal_oracle_distance(profiles + (size_t)i * n, profiles + (size_t)j * n, k,
+                                            do_balance, metric);
+}
+
+/* a13: strand-balance score of `kpal showbalance`.  kpal/kmer.py:243-245:
+ *   forward, reverse = profile.split(); metrics.multiset(forward, reverse, pairwise['prod']) */
+ORACLE_API double kpal_oracle_strand_balance(const int64_t *counts, int k, int pairwise)
+{
+    const size_t n = (size_t)1 << (2 * k);
+    int64_t *f = (int64_t *)malloc(n * sizeof(int64_t));
+    int64_t *r = (int64_t *)malloc(n * sizeof(int64_t));
+    size_t m = kpal_oracle_split(counts, k, f, r);
+    double d = kpal_oracle_multiset_i64(f, r, m, pairwise, NULL);
+    free(f);
+    free(r);
+    return d;
+}
+
+/* ------------------------------------------------------------------------------------ *
+ * Synthetic read generator (OURS, not the reference's: SURVEY.md section 8d).  Shared spec
+ * for bench/test inputs; the HIP generator kernel must reproduce these bytes exactly.
+ *   mix = splitmix64 finaliser; g = read*read_len + pos;
+ *   base = "ACGT"[(mix(seed*0xD1342543DE82EF95 + (g>>5)) >> (2*(g&31))) & 3]
+ *   layout: read r at bytes [r*(read_len+1), +read_len), then '\n'.
+ * noisy != 0 (robustness variant): N iff mix(~seed + g) % 1000 == 0, lower-case iff % 100 == 1.
+ * ------------------------------------------------------------------------------------ */
+static inline uint64_t mix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+ORACLE_API void kpal_oracle_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                        int read_len, int noisy, uint8_t *out)
+{
+    static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    const uint64_t stride = (uint64_t)read_len + 1;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        uint8_t *dst = out + r * stride;
+        for (int pos = 0; pos < read_len; pos++) {
+            uint64_t g = (first_read + r) * (uint64_t)read_len + (uint64_t)pos;
+            uint64_t w = mix64(seed * 0xD1342543DE82EF95ULL + (g >> 5));
+            uint8_t c = (uint8_t)acgt[(w >> (2 * (g & 31))) & 3];
+            if (noisy) {
+                uint64_t h = mix64(~seed + g);
+                if (h % 1000 == 0) c = 'N';
+                else if (h % 100 == 1) c = (uint8_t)(c | 0x20);
+            }
+            dst[pos] = c;
+        }
+        dst[read_len] = '\n';
+    }
+}
+
+/* Multi-threaded counting for the at-scale bit-exactness check and the all-cores CPU
+ * baseline: the byte stream is cut at arbitrary positions; each piece is extended to the
+ * left by (k-1) bytes of halo and only k-mers ENDING inside the piece are counted, which is
+ * the same set of windows as one sequential scan.  This
+ * function counts one piece [begin, end) of buf (halo handled here). */
+ORACLE_API int kpal_oracle_count_piece(const uint8_t *buf, size_t begin, size_t end, int k,
+                                       int64_t *counts)
+{
+    if (k < 1 || k > 31) return -1;
+    const uint64_t bitmask = (1ULL << (2 * k)) - 1ULL;
+    size_t i = begin >= (size_t)(k - 1) ? begin - (size_t)(k - 1) : 0;
+    uint64_t binary = 0;
+    size_t run = 0;
+    for (; i < end; i++) {
+        int code = nucleotide_to_binary(buf[i]);
+        if (code < 0) { run = 0; binary = 0; continue; }
+        binary = ((binary << 2) | (uint64_t)code) & bitmask;
+        run++;
+        if (run >= (size_t)k && i >= begin) counts[binary] += 1;
+    }
+    return 0;
+}

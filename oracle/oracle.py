@@ -1,0 +1,209 @@
+"""ctypes binding of oracle/libkpal_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Parity pinned: checked against reference-generated goldens in tests/test_oracle_golden.py.
+Function names mirror the reference symbols they restate (kpal/klib.py, kpal/metrics.py,
+kpal/kdistlib.py); citations live in kpal_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_f64p = ctypes.POINTER(ctypes.c_double)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    """Compile libkpal_oracle.so with gcc (building the checker is not using it)."""
+    so = os.path.join(_HERE, 'libkpal_oracle.so')
+    src = os.path.join(_HERE, 'kpal_oracle.c')
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-s', '-C', _HERE, 'libkpal_oracle.so'])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.kpal_oracle_count_sequence.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_count_sequence.restype = ctypes.c_int
+        L.kpal_oracle_count_piece.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                              ctypes.c_int, _c_i64p]
+        L.kpal_oracle_count_piece.restype = ctypes.c_int
+        L.kpal_oracle_reverse_complement.argtypes = [ctypes.c_uint64, ctypes.c_int]
+        L.kpal_oracle_reverse_complement.restype = ctypes.c_uint64
+        L.kpal_oracle_balance.argtypes = [_c_i64p, ctypes.c_int]
+        L.kpal_oracle_balance.restype = None
+        L.kpal_oracle_split.argtypes = [_c_i64p, ctypes.c_int, _c_i64p, _c_i64p]
+        L.kpal_oracle_split.restype = ctypes.c_size_t
+        L.kpal_oracle_multiset_i64.argtypes = [_c_i64p, _c_i64p, ctypes.c_size_t, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_multiset_i64.restype = ctypes.c_double
+        L.kpal_oracle_multiset_f64.argtypes = [_c_f64p, _c_f64p, ctypes.c_size_t, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_multiset_f64.restype = ctypes.c_double
+        L.kpal_oracle_euclidean_i64.argtypes = [_c_i64p, _c_i64p, ctypes.c_size_t, _c_i64p]
+        L.kpal_oracle_euclidean_i64.restype = ctypes.c_double
+        L.kpal_oracle_distance.argtypes = [_c_i64p, _c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.kpal_oracle_distance.restype = ctypes.c_double
+        L.kpal_oracle_distance_matrix.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, _c_f64p]
+        L.kpal_oracle_distance_matrix.restype = None
+        L.kpal_oracle_strand_balance.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int]
+        L.kpal_oracle_strand_balance.restype = ctypes.c_double
+        L.kpal_oracle_synth_reads.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.kpal_oracle_synth_reads.restype = None
+        _LIB = L
+    return _LIB
+
+
+PAIRWISE = {'prod': 0, 'sum': 1}
+METRIC = {'prod': 0, 'sum': 1, 'euclidean': 2}
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_c_i64p)
+
+
+def _bytes_view(seq):
+    if isinstance(seq, str):
+        seq = seq.encode('latin-1', 'replace')
+    if isinstance(seq, (bytes, bytearray, memoryview)):
+        return np.frombuffer(seq, dtype=np.uint8)
+    return np.ascontiguousarray(seq, dtype=np.uint8)
+
+
+def from_sequences(sequences, length):
+    """Restates Profile.from_sequences (klib.py:135-170) -> int64[4**length]."""
+    counts = np.zeros(4 ** length, dtype=np.int64)
+    cp = counts.ctypes.data_as(_c_i64p)
+    L = lib()
+    for s in sequences:
+        b = _bytes_view(s)
+        if b.size:
+            rc = L.kpal_oracle_count_sequence(b.ctypes.data, b.size, length, cp)
+            if rc:
+                raise ValueError('bad k')
+    return counts
+
+
+def count_flat(buf, length, threads=1):
+    """Count a flat byte stream (any non-AaCcGgTt byte separates); optionally N threads
+    with private histograms + integer merge (the all-cores baseline / at-scale oracle)."""
+    b = _bytes_view(buf)
+    L = lib()
+    n = b.size
+    if threads <= 1 or n < (1 << 16):
+        counts = np.zeros(4 ** length, dtype=np.int64)
+        if n:
+            L.kpal_oracle_count_piece(b.ctypes.data, 0, n, length, counts.ctypes.data_as(_c_i64p))
+        return counts
+    parts = [np.zeros(4 ** length, dtype=np.int64) for _ in range(threads)]
+    edges = [n * t // threads for t in range(threads + 1)]
+
+    def work(t):
+        L.kpal_oracle_count_piece(b.ctypes.data, edges[t], edges[t + 1], length,
+                                  parts[t].ctypes.data_as(_c_i64p))
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    out = parts[0]
+    for p in parts[1:]:
+        out += p
+    return out
+
+
+def reverse_complement(number, length):
+    return int(lib().kpal_oracle_reverse_complement(number, length))
+
+
+def balance(counts, length):
+    """Restates Profile.balance (klib.py:285-298); returns a balanced COPY."""
+    c = np.array(counts, dtype=np.int64, copy=True)
+    lib().kpal_oracle_balance(c.ctypes.data_as(_c_i64p), length)
+    return c
+
+
+def split(counts, length):
+    """Restates Profile.split (klib.py:300-327)."""
+    c, cp = _i64(counts)
+    f = np.empty(c.size, dtype=np.int64)
+    r = np.empty(c.size, dtype=np.int64)
+    m = lib().kpal_oracle_split(cp, length, f.ctypes.data_as(_c_i64p), r.ctypes.data_as(_c_i64p))
+    return f[:m].copy(), r[:m].copy()
+
+
+def multiset(left, right, pairwise='prod', return_m=False):
+    """Restates metrics.multiset (metrics.py:101-123) with the built-in pairwise functions."""
+    left = np.asanyarray(left)
+    right = np.asanyarray(right)
+    m = ctypes.c_int64(0)
+    if left.dtype.kind == 'f' or right.dtype.kind == 'f':
+        l = np.ascontiguousarray(left, dtype=np.float64)
+        r = np.ascontiguousarray(right, dtype=np.float64)
+        d = lib().kpal_oracle_multiset_f64(l.ctypes.data_as(_c_f64p), r.ctypes.data_as(_c_f64p),
+                                           l.size, PAIRWISE[pairwise], ctypes.byref(m))
+    else:
+        l, lp = _i64(left)
+        r, rp = _i64(right)
+        d = lib().kpal_oracle_multiset_i64(lp, rp, l.size, PAIRWISE[pairwise], ctypes.byref(m))
+    return (d, m.value) if return_m else d
+
+
+def euclidean(left, right, return_dot=False):
+    """Restates metrics.euclidean (metrics.py:126-135) for int64 vectors."""
+    l, lp = _i64(left)
+    r, rp = _i64(right)
+    dot = ctypes.c_int64(0)
+    d = lib().kpal_oracle_euclidean_i64(lp, rp, l.size, ctypes.byref(dot))
+    return (d, dot.value) if return_dot else d
+
+
+def distance(left, right, length, do_balance=False, metric='prod'):
+    """Restates ProfileDistance.distance default/do_balance paths (kdistlib.py:126-161)."""
+    l, lp = _i64(left)
+    r, rp = _i64(right)
+    return lib().kpal_oracle_distance(lp, rp, length, int(do_balance), METRIC[metric])
+
+
+def distance_matrix_values(profiles, length, do_balance=False, metric='prod'):
+    """Lower-triangle values in kdistlib.distance_matrix order (kdistlib.py:179-186)."""
+    p = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.int64) for x in profiles]))
+    P = p.shape[0]
+    out = np.empty(P * (P - 1) // 2, dtype=np.float64)
+    lib().kpal_oracle_distance_matrix(p.ctypes.data_as(_c_i64p), P, length, int(do_balance),
+                                      METRIC[metric], out.ctypes.data_as(_c_f64p))
+    return out
+
+
+def distance_matrix_text(names, values, precision):
+    """Text layout of kdistlib.distance_matrix (kdistlib.py:176-186)."""
+    n = len(names)
+    lines = [str(n)] + list(names)
+    o = 0
+    for i in range(1, n):
+        lines.append(' '.join('{{0:.{0}f}}'.format(precision).format(values[o + j]) for j in range(i)))
+        o += i
+    return '\n'.join(lines) + '\n'
+
+
+def strand_balance(counts, length, pairwise='prod'):
+    """Restates kmer.get_balance's score (kmer.py:243-245)."""
+    c, cp = _i64(counts)
+    return lib().kpal_oracle_strand_balance(cp, length, PAIRWISE[pairwise])
+
+
+def synth_reads(seed, first_read, n_reads, read_len=150, noisy=False):
+    """SURVEY.md 8d generator -> uint8[n_reads*(read_len+1)] ('\\n'-terminated reads)."""
+    out = np.empty(n_reads * (read_len + 1), dtype=np.uint8)
+    lib().kpal_oracle_synth_reads(seed, first_read, n_reads, read_len, int(noisy), out.ctypes.data)
+    return out

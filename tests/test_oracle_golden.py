@@ -1,0 +1,157 @@
+"""Pins oracle/ (the CPU restatement) to golden vectors generated from the unmodified
+reference (tools/gen_golden.py).  CPU only."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import dense
+
+
+def sha(v):
+    return hashlib.sha256(np.ascontiguousarray(v, dtype='<i8').tobytes()).hexdigest()
+
+
+def test_g1_fixture_counts(golden_counts):
+    for case in golden_counts['G1']:
+        got = oracle.from_sequences(case['sequences'], case['k'])
+        np.testing.assert_array_equal(got, dense(case['counts']))
+        assert got.sum() == case['total'] and np.count_nonzero(got) == case['non_zero']
+
+
+def test_g2_randomized_counts_and_flat_identity(golden_counts):
+    assert len(golden_counts['G2']) >= 300
+    for case in golden_counts['G2']:
+        want = dense(case['counts'])
+        np.testing.assert_array_equal(oracle.from_sequences(case['sequences'], case['k']), want)
+        # joining with one separator byte gives the same windows
+        flat = '\n'.join(case['sequences'])
+        np.testing.assert_array_equal(oracle.count_flat(flat, case['k']), want)
+
+
+def test_g3_config1_and_generator(golden_synth):
+    g = golden_synth['config1']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], g['read_len'])
+    assert buf[:150].tobytes().decode() == g['read0']
+    assert buf[151 * 9999:151 * 9999 + 150].tobytes().decode() == g['read9999']
+    c = oracle.count_flat(buf, g['k'])
+    assert c.sum() == g['total'] == 1420000
+    assert np.count_nonzero(c) == g['non_zero']
+    assert list(c[:64]) == g['first64'] and list(c[-64:]) == g['last64']
+    assert sha(c) == g['sha256']
+    # threaded variant (private histograms + merge) is the at-scale oracle
+    assert sha(oracle.count_flat(buf, g['k'], threads=4)) == g['sha256']
+
+
+def test_g3_noisy_and_long(golden_synth):
+    g = golden_synth['noisy']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], 150, noisy=True)
+    assert buf[:150].tobytes().decode() == g['read0']
+    for case in g['cases']:
+        c = oracle.count_flat(buf, case['k'])
+        assert (int(c.sum()), int(np.count_nonzero(c)), sha(c)) == (case['total'], case['non_zero'], case['sha256'])
+        assert sha(oracle.count_flat(buf, case['k'], threads=3)) == case['sha256']
+    g = golden_synth['long']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], 150, noisy=True)
+    seq = buf.reshape(-1, 151)[:, :150].reshape(-1)   # one long record, newlines deleted
+    for case in g['cases']:
+        c = oracle.from_sequences([seq], case['k'])
+        assert (int(c.sum()), sha(c)) == (case['total'], case['sha256'])
+        assert sha(oracle.count_flat(seq, case['k'], threads=5)) == case['sha256']
+
+
+def test_g5_rc_balance_split(golden_scalars, golden_vectors):
+    g = golden_scalars['G5']
+    for rec in g['rc']:
+        assert [oracle.reverse_complement(x, rec['k']) for x in rec['x']] == rec['rc']
+    for rec in g['balance_split']:
+        name, k = rec['name'], rec['k']
+        v = golden_vectors['g5_%s_in' % name]
+        np.testing.assert_array_equal(oracle.balance(v, k), golden_vectors['g5_%s_bal' % name])
+        f, r = oracle.split(v, k)
+        np.testing.assert_array_equal(f, golden_vectors['g5_%s_fwd' % name])
+        np.testing.assert_array_equal(r, golden_vectors['g5_%s_rev' % name])
+
+
+def _counts(seqs, k):
+    return oracle.from_sequences(seqs, k)
+
+
+def test_g6_known_answers(golden_scalars, golden_counts):
+    g = golden_scalars['G6']
+    a = _counts(g['toy_k2']['a'], 2)
+    b = _counts(g['toy_k2']['b'], 2)
+    assert oracle.distance(a, b, 2) == g['toy_k2']['distance'] == 0.0625
+    fx = {c['fixture']: c['sequences'] for c in golden_counts['G1']}
+    left = _counts(fx['LENGTH_60'], 8)
+    right = _counts(fx['LENGTH_60_MORE'], 8)
+    o = g['left_right_k8']
+    assert oracle.distance(left, right, 8) == pytest.approx(o['prod'], rel=1e-14)
+    assert o['prod'] == pytest.approx(0.4626209322, abs=1e-10)   # tests/test_kdistlib.py:114-122
+    assert oracle.distance(left, right, 8, metric='sum') == pytest.approx(o['sum'], rel=1e-14)
+    assert oracle.distance(left, right, 8, do_balance=True) == pytest.approx(o['balance_prod'], rel=1e-14)
+    assert oracle.distance(left, right, 8, do_balance=True, metric='sum') == pytest.approx(o['balance_sum'], rel=1e-14)
+    assert oracle.distance(left, right, 8, metric='euclidean') == o['euclidean']
+    assert oracle.distance(left, right, 8, do_balance=True, metric='euclidean') == o['balance_euclidean']
+    assert oracle.strand_balance(left, 8) == pytest.approx(o['showbalance_left'], rel=1e-14)
+    assert oracle.strand_balance(left, 8, 'sum') == pytest.approx(o['showbalance_left_sum'], rel=1e-14)
+
+
+def test_g7_metrics(golden_scalars, golden_vectors):
+    bitexact = 0
+    for rec in golden_scalars['G7']:
+        l = golden_vectors['g7_%s_l' % rec['name']]
+        r = golden_vectors['g7_%s_r' % rec['name']]
+        for pw in ('prod', 'sum'):
+            d, m = oracle.multiset(l, r, pw, return_m=True)
+            assert m == rec['m']
+            if np.isfinite(rec[pw]):
+                assert d == pytest.approx(rec[pw], rel=1e-13, abs=1e-300)
+                bitexact += d == rec[pw]
+            else:
+                assert not np.isfinite(d) or np.isnan(d)
+        if 'euclidean' in rec:
+            d, dot = oracle.euclidean(l, r, return_dot=True)
+            assert dot == rec['dot']
+            assert d == rec['euclidean'] or (np.isnan(d) and np.isnan(rec['euclidean']))
+    assert bitexact >= 10   # the restated NumPy pairwise summation is normally bit-identical
+
+
+def test_g8_matrix_text(golden_scalars):
+    g = golden_scalars['G8']
+    profs = [_counts(s, g['k']) for s in g['sets']]
+    for case in g['cases']:
+        n = case['count']
+        vals = oracle.distance_matrix_values(profs[:n], g['k'], case['do_balance'], case['pairwise']) if n > 1 else []
+        assert oracle.distance_matrix_text(g['names'][:n], vals, case['precision']) == case['text']
+
+
+def test_g4_tutorial(golden_scalars, tutorial_dir):
+    g = golden_scalars['G4']
+    prof = {}
+    for fname, rec in g['files'].items():
+        if not fname.endswith('.fa'):
+            continue
+        # FASTA flattening for the shapes the reference pins: header lines dropped,
+        # record lines joined, records separated (doc/tutorial.rst:44-82)
+        seqs, cur = [], None
+        with open(os.path.join(tutorial_dir, fname)) as fh:
+            for line in fh:
+                if line.startswith('>'):
+                    cur = []
+                    seqs.append(cur)
+                elif cur is not None:
+                    cur.append(line.strip())
+        c = oracle.from_sequences([''.join(s) for s in seqs], 8)
+        assert (int(c.sum()), int(np.count_nonzero(c)), sha(c)) == (rec['total'], rec['non_zero'], rec['sha256'])
+        prof[fname[:-3]] = c
+    assert g['files']['a_1.fa']['total'] == 18600 and g['files']['a_1.fa']['non_zero'] == 16141
+    assert oracle.distance(prof['c_1'], prof['c_2'], 8) == pytest.approx(g['distance_c1_c2'], rel=1e-14)
+    merged = [prof[s + '_1'] + prof[s + '_2'] for s in 'abcd']
+    vals = oracle.distance_matrix_values(merged, 8)
+    assert oracle.distance_matrix_text(list('abcd'), vals, 3) == g['matrix_abcd_p3']
+    assert oracle.distance(merged[0], merged[1], 8, do_balance=True) == pytest.approx(g['distance_balanced_a_b'], rel=1e-14)
+    assert oracle.strand_balance(merged[0], 8) == pytest.approx(g['showbalance_a'], rel=1e-14)

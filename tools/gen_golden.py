@@ -1,0 +1,352 @@
+#!/opt/conda/bin/python3.9
+"""Generate tests/golden/* by importing the UNMODIFIED reference (kPAL at /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONPATH=tools/oracle_stubs:/root/reference /opt/conda/bin/python3.9 tools/gen_golden.py
+
+tools/oracle_stubs holds import shims for two third-party packages the image lacks
+(Bio.SeqIO, semantic_version); everything that computes an expected value below is the
+reference's own code: kpal.klib.Profile, kpal.metrics, kpal.kdistlib, kpal.kmer.
+
+Fixture groups follow SURVEY.md section 8c (G1..G8).  Only DATA is written: inputs and the
+reference's outputs.
+"""
+from __future__ import print_function
+
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import zipfile
+
+import numpy as np
+
+from kpal import kdistlib, klib, kmer, metrics
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+
+# Fixture sequences of the reference's own tests (tests/utils.py:24-59) -- data.
+LENGTH_8 = ['GTACATGA', 'TAAACTAA', 'TATCTTTA', 'TACTATGT']
+LENGTH_8_WITH_N = ['GNACATGA', 'TAAACTNA', 'TATNTTTA', 'TACTATGN']
+LENGTH_60 = ['GTACATGATAGGTCCACAGCTCTGAGCAAGGCAGACGTCCATACTTAAAACCCAGACTGC',
+             'TAAACTAAAAGAAAGAATTTTTTTAATGGTAGACTACCTAAAATTATGTCTCTTAGTCCT',
+             'TATCTTTACCTATATATTTGACTAAGATTTAGTATTACTACTACCTAAAATTATGTCTCT',
+             'TACTATGTCTTGAAGGACAGCACCTGACCTCCCCCTGCAAGGTGTCATCCCCAAGCTGGT']
+LENGTH_60_WITH_N = ['GTANATGATAGGTCCACAGCTCTGAGCAAGGCAGACGTCCATACTTAAAACCCAGACTGC',
+                    'TAAACTAAAAGAAAGAATTTTTTTAATGGTAGACTACCTAAAATTATGTCTCTTAGNCCT',
+                    'TATCTTTACCTATATATTTGACTAAGATTTAGTNTTACTACTACCTAAAATTATGTCTCT',
+                    'TACTATGTCTTGAAGGACAGCCCTGACCTCCCCCTGCAAGGTGTCATCCCCAAGCTGGTN']
+LENGTH_60_MORE = ['TTACAATGATTAGGTCCACAGCTCTGAGCAACGCGCAGACGTCACATACTTCAAAACCCA',
+                  'TAAAAACTATATAAGAAATCGAATTTTCTCTTAATGGTAGCAGCTACCGTAAAATCTATG',
+                  'TACGCCTATATATCTTTGACTAAGCATTTATGTATTACATACTAACCAAAATTACTGTCT',
+                  'TACTAAGTTTTGAAGGACAGCACATCACCTGCGCAATATCGGTGTCACCCCATAGCTCCT']
+FIXTURES = {'LENGTH_8': LENGTH_8, 'LENGTH_8_WITH_N': LENGTH_8_WITH_N, 'LENGTH_60': LENGTH_60,
+            'LENGTH_60_WITH_N': LENGTH_60_WITH_N, 'LENGTH_60_MORE': LENGTH_60_MORE}
+
+
+def sparse(v):
+    v = np.asarray(v)
+    idx = np.nonzero(v)[0]
+    return {'n': int(v.size), 'idx': [int(i) for i in idx], 'val': [int(x) for x in v[idx]]}
+
+
+def fasta_text(seqs, width=None):
+    out = []
+    for i, s in enumerate(seqs):
+        out.append('>r%d' % (i + 1))
+        if width:
+            out.extend(s[j:j + width] for j in range(0, len(s), width))
+        else:
+            out.append(s)
+    return '\n'.join(out) + '\n'
+
+
+# ---- SURVEY 8d synthetic generator, pure-Python ints (third independent statement) ----
+M64 = (1 << 64) - 1
+
+
+def mix64(x):
+    z = (x + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def synth_read(seed, r, read_len=150, noisy=False):
+    out = []
+    for pos in range(read_len):
+        g = r * read_len + pos
+        w = mix64((seed * 0xD1342543DE82EF95 + (g >> 5)) & M64)
+        c = 'ACGT'[(w >> (2 * (g & 31))) & 3]
+        if noisy:
+            h = mix64(((~seed) + g) & M64)
+            if h % 1000 == 0:
+                c = 'N'
+            elif h % 100 == 1:
+                c = c.lower()
+        out.append(c)
+    return ''.join(out)
+
+
+def g1():
+    cases = []
+    for name, seqs in sorted(FIXTURES.items()):
+        for k in (1, 4, 7, 8):
+            p = klib.Profile.from_sequences(seqs, k)
+            pf = klib.Profile.from_fasta(io.StringIO(fasta_text(seqs)), k)
+            assert (p.counts == pf.counts).all()
+            cases.append({'fixture': name, 'sequences': seqs, 'k': k, 'counts': sparse(p.counts),
+                          'total': int(p.total), 'non_zero': int(p.non_zero)})
+    # k == len and k == len-1 (tests/test_klib.py:72-81)
+    for k in (60, 59):
+        pass  # 4**60 bins is not representable; the reference tests use LENGTH_8 with k=8/7 (above)
+    return cases
+
+
+def g2():
+    rnd = random.Random(20261002)
+    alphabet = 'ACGT' * 4 + 'acgt' + 'NnRY- '
+    cases = []
+    for _ in range(320):
+        k = rnd.randint(1, 8)
+        nseq = rnd.randint(0, 6)
+        seqs = [''.join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 40))) for _ in range(nseq)]
+        p = klib.Profile.from_sequences(seqs, k)
+        cases.append({'k': k, 'sequences': seqs, 'counts': sparse(p.counts)})
+    # Appendix B quirks
+    for seqs, k in ((['RYACGU'], 2), ([], 3), ([''], 3), (['AC', 'G'], 3), (['ACGT' * 10], 4),
+                    (['A' * 50], 5), (['ACGTUacgtu'], 2)):
+        p = klib.Profile.from_sequences(seqs, k)
+        cases.append({'k': k, 'sequences': seqs, 'counts': sparse(p.counts)})
+    return cases
+
+
+def g3():
+    out = {}
+    reads = [synth_read(1, r) for r in range(10000)]
+    p = klib.Profile.from_sequences(reads, 9)
+    c = p.counts.astype('<i8')
+    out['config1'] = {'seed': 1, 'n_reads': 10000, 'read_len': 150, 'k': 9,
+                      'sha256': hashlib.sha256(c.tobytes()).hexdigest(),
+                      'total': int(p.total), 'non_zero': int(p.non_zero),
+                      'first64': [int(x) for x in c[:64]], 'last64': [int(x) for x in c[-64:]],
+                      'read0': reads[0], 'read9999': reads[9999]}
+    # robustness variant (N + lower-case), smaller, several k
+    reads = [synth_read(7, r, noisy=True) for r in range(1500)]
+    out['noisy'] = {'seed': 7, 'n_reads': 1500, 'read_len': 150, 'read0': reads[0], 'cases': []}
+    for k in (3, 6, 9, 11, 12):
+        p = klib.Profile.from_sequences(reads, k)
+        c = p.counts.astype('<i8')
+        out['noisy']['cases'].append({'k': k, 'sha256': hashlib.sha256(c.tobytes()).hexdigest(),
+                                      'total': int(p.total), 'non_zero': int(p.non_zero)})
+    # one long mixed record (chunk seams / halo): a single 200 kb sequence
+    long_seq = ''.join(synth_read(11, r, noisy=True) for r in range(1400))
+    out['long'] = {'seed': 11, 'n_reads': 1400, 'cases': []}
+    for k in (5, 10, 12):
+        p = klib.Profile.from_sequences([long_seq], k)
+        c = p.counts.astype('<i8')
+        out['long']['cases'].append({'k': k, 'sha256': hashlib.sha256(c.tobytes()).hexdigest(),
+                                     'total': int(p.total), 'non_zero': int(p.non_zero)})
+    return out
+
+
+def g4():
+    """Tutorial data (doc/downloads/tutorial.zip; doc/tutorial.rst:44-144)."""
+    zpath = '/root/reference/doc/downloads/tutorial.zip'
+    tdir = os.path.join(OUT, 'tutorial')
+    os.makedirs(tdir, exist_ok=True)
+    z = zipfile.ZipFile(zpath)
+    profiles = {}
+    out = {'k': 8, 'files': {}}
+    for info in sorted(z.infolist(), key=lambda i: i.filename):
+        if not info.filename.endswith('.fa'):
+            continue
+        base = os.path.basename(info.filename)
+        data = z.read(info).decode('ascii')
+        with open(os.path.join(tdir, base), 'w') as fh:
+            fh.write(data)
+        p = klib.Profile.from_fasta(io.StringIO(data), 8, name=base[:-3])
+        profiles[base[:-3]] = p
+        c = p.counts.astype('<i8')
+        out['files'][base] = {'total': int(p.total), 'non_zero': int(p.non_zero),
+                              'sha256': hashlib.sha256(c.tobytes()).hexdigest()}
+    # merged a = a_1 + a_2 etc. (doc/tutorial.rst:84-102), distances (104-144)
+    merged = {}
+    for s in 'abcd':
+        m = profiles[s + '_1'].copy()
+        m.merge(profiles[s + '_2'])
+        m.name = s
+        merged[s] = m
+        out['files'][s + '_merged'] = {'total': int(m.total), 'non_zero': int(m.non_zero)}
+    d = kdistlib.ProfileDistance()
+    out['distance_c1_c2'] = d.distance(profiles['c_1'], profiles['c_2'])
+    buf = io.StringIO()
+    kdistlib.distance_matrix([merged[s] for s in 'abcd'], buf, 3, d)
+    out['matrix_abcd_p3'] = buf.getvalue()
+    db = kdistlib.ProfileDistance(do_balance=True)
+    out['distance_balanced_a_b'] = db.distance(merged['a'], merged['b'])
+    f, r = merged['a'].split()
+    out['showbalance_a'] = metrics.multiset(f, r, metrics.pairwise['prod'])
+    return out
+
+
+def g5(arrays):
+    out = {'rc': [], 'balance_split': []}
+    for k in (1, 2, 3, 4, 5, 8, 12, 15):
+        p = klib.Profile(np.zeros(4 ** min(k, 8), dtype='int64'))
+        p.length = k
+        rnd = random.Random(k)
+        xs = [0, 1, 4 ** k - 1] + [rnd.randrange(4 ** k) for _ in range(20)]
+        out['rc'].append({'k': k, 'x': xs, 'rc': [int(p.reverse_complement(x)) for x in xs]})
+    rs = np.random.RandomState(5)
+    cases = [('AATT', ['AATT'], 4), ('ACCTAGGT', LENGTH_60 + ['ACCTAGGT'], 8), ('SEQ2', LENGTH_60, 2),
+             ('SEQ8', LENGTH_60, 8)]
+    for name, seqs, k in cases:
+        p = klib.Profile.from_sequences(seqs, k)
+        arrays['g5_%s_in' % name] = p.counts.copy()
+        b = p.copy()
+        b.balance()
+        f, r = p.split()
+        arrays['g5_%s_bal' % name] = b.counts
+        arrays['g5_%s_fwd' % name] = np.asarray(f, dtype='int64')
+        arrays['g5_%s_rev' % name] = np.asarray(r, dtype='int64')
+        out['balance_split'].append({'name': name, 'k': k})
+    for k in range(1, 7):
+        v = rs.randint(0, 1 << 62, size=4 ** k).astype('int64')
+        v[rs.rand(4 ** k) < 0.3] = 0
+        name = 'rand%d' % k
+        p = klib.Profile(v.copy())
+        b = p.copy()
+        b.balance()
+        f, r = p.split()
+        arrays['g5_%s_in' % name] = v
+        arrays['g5_%s_bal' % name] = b.counts
+        arrays['g5_%s_fwd' % name] = np.asarray(f, dtype='int64')
+        arrays['g5_%s_rev' % name] = np.asarray(r, dtype='int64')
+        out['balance_split'].append({'name': name, 'k': k})
+    return out
+
+
+def as_array(seqs, k):
+    return klib.Profile.from_sequences(seqs, k).counts
+
+
+def g6():
+    out = {}
+    a = ['AC', 'AG', 'AT', 'CA', 'CC', 'CG', 'CT', 'GA', 'GC', 'GG', 'GT', 'TA', 'TG', 'TT']
+    b = ['AC', 'AT', 'CA', 'CC', 'CG', 'CT', 'GA', 'GC', 'GG', 'GT', 'TA', 'TC', 'TG', 'TT']
+    pa = klib.Profile(as_array(a, 2))
+    pb = klib.Profile(as_array(b, 2))
+    out['toy_k2'] = {'a': a, 'b': b, 'distance': kdistlib.ProfileDistance().distance(pa, pb)}
+    left = klib.Profile(as_array(LENGTH_60, 8), 'left')
+    right = klib.Profile(as_array(LENGTH_60_MORE, 8), 'right')
+    P = metrics.pairwise
+    o = {}
+    o['prod'] = kdistlib.ProfileDistance().distance(left, right)
+    o['sum'] = kdistlib.ProfileDistance(pairwise=P['sum']).distance(left, right)
+    o['balance_prod'] = kdistlib.ProfileDistance(do_balance=True).distance(left, right)
+    o['balance_sum'] = kdistlib.ProfileDistance(do_balance=True, pairwise=P['sum']).distance(left, right)
+    o['euclidean'] = kdistlib.ProfileDistance(distance_function=metrics.euclidean).distance(left, right)
+    o['balance_euclidean'] = kdistlib.ProfileDistance(
+        do_balance=True, distance_function=metrics.euclidean).distance(left, right)
+    o['cosine'] = kdistlib.ProfileDistance(distance_function=metrics.cosine_similarity).distance(left, right)
+    f, r = left.split()
+    o['showbalance_left'] = metrics.multiset(f, r, P['prod'])
+    o['showbalance_left_sum'] = metrics.multiset(f, r, P['sum'])
+    o['smooth_min'] = kdistlib.ProfileDistance(do_smooth=True).distance(left, right)
+    o['smooth_avg'] = kdistlib.ProfileDistance(do_smooth=True, summary=np.mean).distance(left, right)
+    o['positive'] = kdistlib.ProfileDistance(do_positive=True).distance(left, right)
+    o['scale'] = kdistlib.ProfileDistance(do_scale=True).distance(left, right)
+    o['scale_down'] = kdistlib.ProfileDistance(do_scale=True, down=True).distance(left, right)
+    out['left_right_k8'] = {k: float(v) for k, v in o.items()}
+    return out
+
+
+def g7(arrays):
+    rs = np.random.RandomState(7)
+    out = []
+
+    def add(name, l, r):
+        arrays['g7_%s_l' % name] = l
+        arrays['g7_%s_r' % name] = r
+        rec = {'name': name, 'n': int(l.size), 'dtype': str(l.dtype)}
+        with np.errstate(all='ignore'):
+            rec['prod'] = float(metrics.multiset(l, r, metrics.pairwise['prod']))
+            rec['sum'] = float(metrics.multiset(l, r, metrics.pairwise['sum']))
+            rec['m'] = int(np.count_nonzero(np.logical_or(l, r)))
+            if l.dtype.kind == 'i':
+                rec['euclidean'] = float(metrics.euclidean(l, r))
+                d = np.subtract(l, r)
+                rec['dot'] = int(np.dot(d, d))
+        out.append(rec)
+
+    for k in (6, 7, 8):
+        n = 4 ** k
+        add('dense%d' % k, rs.poisson(830, n).astype('int64'), rs.poisson(830, n).astype('int64'))
+        add('sparse%d' % k, rs.poisson(0.8, n).astype('int64'), rs.poisson(0.8, n).astype('int64'))
+    n = 4 ** 6
+    l = rs.poisson(5, n).astype('int64')
+    r = rs.poisson(5, n).astype('int64')
+    l[rs.rand(n) < 0.5] = 0
+    add('onesided', l, r)
+    add('allzero', np.zeros(64, 'int64'), np.zeros(64, 'int64'))
+    add('leftzero', np.zeros(256, 'int64'), rs.poisson(3, 256).astype('int64'))
+    # values where (x+1)*(y+1) wraps int64 (metrics.py:160 evaluates in int64)
+    big = rs.randint(3 * 10 ** 9, 4 * 10 ** 9, size=256).astype('int64')
+    big2 = rs.randint(3 * 10 ** 9, 4 * 10 ** 9, size=256).astype('int64')
+    add('wrap', big, big2)
+    huge = rs.randint(1 << 40, 1 << 61, size=1024).astype('int64')
+    huge2 = rs.randint(1 << 40, 1 << 61, size=1024).astype('int64')
+    add('huge', huge, huge2)
+    # float64 (scaled) inputs, kdistlib.py:149-157
+    lf = rs.poisson(20, 1024).astype('int64') * 1.37
+    rf = rs.poisson(20, 1024).astype('float64')
+    lf[rs.rand(1024) < 0.2] = 0.0
+    add('float', lf, rf)
+    return out
+
+
+def g8():
+    out = []
+    sets = [LENGTH_60, LENGTH_60_MORE, LENGTH_60, LENGTH_60_WITH_N, LENGTH_8 * 3]
+    names = ['a', 'b', 'c', 'd', 'e']
+    profs = [klib.Profile(as_array(s, 8), n) for s, n in zip(sets, names)]
+    for count in (1, 2, 3, 5):
+        for precision in (2, 3, 10):
+            for do_balance in (False, True):
+                for pw in ('prod', 'sum'):
+                    d = kdistlib.ProfileDistance(do_balance=do_balance, pairwise=metrics.pairwise[pw])
+                    buf = io.StringIO()
+                    kdistlib.distance_matrix(profs[:count], buf, precision, d)
+                    out.append({'count': count, 'precision': precision, 'do_balance': do_balance,
+                                'pairwise': pw, 'text': buf.getvalue()})
+    d = kdistlib.ProfileDistance(distance_function=metrics.euclidean)
+    buf = io.StringIO()
+    kdistlib.distance_matrix(profs, buf, 6, d)
+    out.append({'count': 5, 'precision': 6, 'do_balance': False, 'pairwise': 'euclidean',
+                'text': buf.getvalue()})
+    return {'sets': sets, 'names': names, 'k': 8, 'cases': out}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    arrays = {}
+    meta = {'generator': 'tools/gen_golden.py', 'reference': 'kPAL 2.1.2.dev (/root/reference)',
+            'python': sys.version.split()[0], 'numpy': np.__version__}
+    with open(os.path.join(OUT, 'counts.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G1': g1(), 'G2': g2()}, fh)
+    with open(os.path.join(OUT, 'synth.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G3': g3()}, fh, indent=1)
+    scal = {'meta': meta, 'G4': g4(), 'G5': g5(arrays), 'G6': g6(), 'G7': g7(arrays), 'G8': g8()}
+    with open(os.path.join(OUT, 'scalars.json'), 'w') as fh:
+        json.dump(scal, fh, indent=1)
+    np.savez_compressed(os.path.join(OUT, 'vectors.npz'), **arrays)
+    print('wrote', sorted(os.listdir(OUT)))
+
+
+if __name__ == '__main__':
+    main()

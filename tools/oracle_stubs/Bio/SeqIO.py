@@ -1,0 +1,33 @@
+"""Import shim standing in for Biopython's Bio.SeqIO (absent from this image, no network).
+
+Used ONLY by tools/gen_golden.py so that `import kpal.klib` succeeds when the unmodified
+reference is imported to generate golden vectors.  It is not reference code and is never
+shipped or imported by kpal_amd.  FASTA corner cases beyond `>title` + sequence lines are
+"parity unpinned" (DESIGN.md); goldens that go through this shim are limited to the shapes
+the reference's own tests and tutorial pin (single-line records, 60-column wrapped records).
+"""
+
+
+class _Record(object):
+    def __init__(self, title, seq):
+        token = title.split(None, 1)[0] if title.split() else ''
+        self.id = token
+        self.name = token
+        self.description = title
+        self.seq = seq
+
+
+def parse(handle, fmt):
+    assert fmt == 'fasta'
+    title = None
+    chunks = []
+    for line in handle:
+        if line.startswith('>'):
+            if title is not None:
+                yield _Record(title, ''.join(chunks))
+            title = line[1:].rstrip('\r\n')
+            chunks = []
+        elif title is not None:
+            chunks.append(line.strip().replace(' ', '').replace('\r', ''))
+    if title is not None:
+        yield _Record(title, ''.join(chunks))
