@@ -1,0 +1,126 @@
+/*
+ * kpal_hip.h -- C-ABI of libkpal_hip.so: the MI355X (gfx950) k-mer counting and
+ * profile-distance hot path of kPAL.
+ *
+ * The reference (kPAL 2.1.2.dev, pure Python) has no FFI for this path; its boundary is
+ * the Python API of kpal/klib.py, kpal/metrics.py and kpal/kdistlib.py.  Each entry point
+ * below names the reference interface it replaces (file:line into the reference tree).
+ * kpal_amd/_native.py is the ctypes binding; INTEGRATION.md shows the stub a kPAL
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every function returns an int status: 0 = ok, <0 = error (KPAL_E_*);
+ *    kpal_last_error() returns a thread-local, NUL-terminated description.
+ *  - the caller owns every host pointer; the library owns device memory behind kpal_ctx
+ *    (or borrows caller-provided device pointers in the *_device variants).
+ *  - calls are blocking unless stated otherwise; a ctx is bound to one GPU and one HIP
+ *    stream and must not be used from two threads at once.
+ *  - count vectors are int64, length 4^k, index = big-endian 2-bit packing of the k-mer
+ *    with A/a=0 C/c=1 G/g=2 T/t=3 (klib.py:43-48, doc/method.rst:23-45).
+ *  - 1 <= k <= KPAL_MAX_K.
+ */
+#ifndef KPAL_HIP_H
+#define KPAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPAL_MAX_K 16
+
+#define KPAL_OK 0
+#define KPAL_E_INVALID (-1) /* bad argument (-> ValueError) */
+#define KPAL_E_NOMEM (-2)   /* host or device allocation failed (-> MemoryError) */
+#define KPAL_E_HIP (-3)     /* HIP runtime error (-> RuntimeError) */
+#define KPAL_E_STATE (-4)   /* call sequence error, e.g. feed before begin (-> RuntimeError) */
+
+/* metric selectors */
+#define KPAL_PAIRWISE_PROD 0 /* metrics.pairwise['prod'], metrics.py:160 */
+#define KPAL_PAIRWISE_SUM 1  /* metrics.pairwise['sum'],  metrics.py:161 */
+#define KPAL_EUCLIDEAN 2     /* metrics.euclidean,        metrics.py:126-135 */
+
+/* counting strategies (kpal_count_set_strategy) */
+#define KPAL_STRATEGY_AUTO 0
+#define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k */
+#define KPAL_STRATEGY_LDS_DIRECT 2    /* whole 4^k table privatised in LDS; k <= 7 */
+#define KPAL_STRATEGY_PARTITION 3     /* radix-partition keys, histogram buckets in LDS; 8 <= k <= 12 */
+
+typedef struct kpal_ctx kpal_ctx;
+
+const char *kpal_last_error(void);
+const char *kpal_version(void);
+
+int kpal_device_count(int *n);
+int kpal_ctx_create(int device, kpal_ctx **out);
+void kpal_ctx_destroy(kpal_ctx *ctx);
+int kpal_sync(kpal_ctx *ctx);
+
+/* ---- device memory helpers (bench / tests keep inputs resident in HBM without torch) ---- */
+int kpal_dev_alloc(kpal_ctx *ctx, size_t nbytes, void **dev_out);
+int kpal_dev_free(kpal_ctx *ctx, void *dev);
+int kpal_memcpy_h2d(kpal_ctx *ctx, void *dev_dst, const void *host_src, size_t nbytes);
+int kpal_memcpy_d2h(kpal_ctx *ctx, void *host_dst, const void *dev_src, size_t nbytes);
+
+/* ---- counting: replaces Profile.from_sequences / from_fasta inner loops, klib.py:149-170 ----
+ * Input is a flat byte stream; every byte outside AaCcGgTt separates sequences (klib.py:152,
+ * the regex '[^AaCcGgTt]'); windows never span a separator or two feeds.  The host side joins
+ * the sequences of one from_sequences() call with a single '\n'. */
+int kpal_count_begin(kpal_ctx *ctx, int k);            /* klib.py:149-151: zeroed 4^k table */
+int kpal_count_set_strategy(kpal_ctx *ctx, int strategy);
+int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);        /* klib.py:154-168 */
+int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous */
+int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
+int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
+
+/* Deterministic synthetic reads (same bytes as oracle/kpal_oracle.c
+ * kpal_oracle_synth_reads): n_reads*(read_len+1) bytes, each read followed by '\n'. */
+int kpal_synth_reads_device(kpal_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                            int read_len, int noisy, void *dev_out);
+
+/* ---- vector operations on 4^k int64 count vectors ---- */
+/* Profile.balance, klib.py:285-298: c[i] += c[rc(i)] (palindromes doubled), in place. */
+int kpal_balance(kpal_ctx *ctx, int k, int64_t *host_inout);
+int kpal_balance_device(kpal_ctx *ctx, int k, int64_t *dev_inout);
+/* Profile.reverse_complement, klib.py:394-412 (host helper, no GPU). */
+uint64_t kpal_reverse_complement(uint64_t number, int k);
+/* Profile.split, klib.py:300-327: forward/reverse each need (4^k + 4^(k/2))/2 entries when k is
+ * even, 4^k/2 when odd; *n_out receives that length. */
+int kpal_split(kpal_ctx *ctx, int k, const int64_t *host_counts, int64_t *host_forward,
+               int64_t *host_reverse, uint64_t *n_out);
+/* kmer.get_balance score, kmer.py:243-245: multiset(*split(), pairwise) fused in one pass. */
+int kpal_strand_balance(kpal_ctx *ctx, int k, const int64_t *host_counts, int pairwise, double *out);
+
+/* metrics.multiset (metrics.py:101-123) with pairwise prod/sum, and metrics.euclidean
+ * (metrics.py:126-135), on two int64 vectors of n entries.  If do_balance != 0 both vectors are
+ * balanced copies first (kdistlib.py:136-141; n must equal 4^k); inputs are never modified.
+ * aux_out (optional): multiset -> number of bins with l!=0 or r!=0 (len(distances));
+ * euclidean -> the exact int64 dot product (np.dot wraps like int64). */
+int kpal_pair_distance(kpal_ctx *ctx, size_t n, const int64_t *host_left, const int64_t *host_right,
+                       int metric, int do_balance, int k, double *out, int64_t *aux_out);
+int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *dev_left, const int64_t *dev_right,
+                              int metric, int do_balance, int k, double *out, int64_t *aux_out);
+/* float64 inputs (profiles after do_scale, kdistlib.py:149-157); multiset only. */
+int kpal_pair_distance_f64(kpal_ctx *ctx, size_t n, const double *host_left, const double *host_right,
+                           int pairwise, double *out, int64_t *aux_out);
+
+/* kdistlib.distance_matrix values, kdistlib.py:179-186: out_lower[i*(i-1)/2 + j] =
+ * distance(profiles[i], profiles[j]) for 0 <= j < i < P (row = left, column = right). */
+int kpal_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host_profiles, int metric,
+                         int do_balance, double *out_lower);
+int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles /* P x 4^k */,
+                                int metric, int do_balance, double *out_lower);
+
+/* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) ---- */
+int kpal_prof_enable(kpal_ctx *ctx, int on);
+int kpal_prof_reset(kpal_ctx *ctx);
+int kpal_prof_count(kpal_ctx *ctx, int *n_kernels);
+int kpal_prof_get(kpal_ctx *ctx, int index, char *name_out, size_t name_cap, double *total_ms,
+                  uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPAL_HIP_H */

@@ -1,0 +1,323 @@
+"""ctypes binding of libkpal_hip.so (C-ABI: include/kpal_hip.h).
+
+This is the only gateway from the Python host code to the HIP kernels.  There is NO CPU
+fallback: if the shared library has not been built, or no GPU is visible, every hot-path call
+raises -- loudly -- instead of computing something on the host.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libkpal_hip.so')
+
+KPAL_MAX_K = 16
+PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN = 0, 1, 2
+STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3}
+
+_E_INVALID, _E_NOMEM, _E_HIP, _E_STATE = -1, -2, -3, -4
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_vp = ctypes.c_void_p
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); one entry per symbol declared in include/kpal_hip.h
+SIGNATURES = {
+    'kpal_last_error': (ctypes.c_char_p, []),
+    'kpal_version': (ctypes.c_char_p, []),
+    'kpal_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'kpal_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    'kpal_ctx_destroy': (None, [_vp]),
+    'kpal_sync': (ctypes.c_int, [_vp]),
+    'kpal_dev_alloc': (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    'kpal_dev_free': (ctypes.c_int, [_vp, _vp]),
+    'kpal_memcpy_h2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    'kpal_memcpy_d2h': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    'kpal_count_begin': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'kpal_count_set_strategy': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'kpal_count_feed': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_count_feed_device': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
+    'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_int, ctypes.c_int, _vp]),
+    'kpal_balance': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    'kpal_balance_device': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    'kpal_reverse_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'kpal_split': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_strand_balance': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _f64p]),
+    'kpal_pair_distance': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, _f64p, _i64p]),
+    'kpal_pair_distance_device': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, _f64p, _i64p]),
+    'kpal_pair_distance_f64': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, ctypes.c_int, _f64p, _i64p]),
+    'kpal_distance_matrix': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp), ctypes.c_int,
+                                            ctypes.c_int, _f64p]),
+    'kpal_distance_matrix_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int,
+                                                   ctypes.c_int, _f64p]),
+    'kpal_prof_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'kpal_prof_reset': (ctypes.c_int, [_vp]),
+    'kpal_prof_count': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
+    'kpal_prof_get': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, _f64p,
+                                     ctypes.POINTER(ctypes.c_uint64)]),
+}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libkpal_hip.so (once).  Raises NativeLibraryMissing if it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeLibraryMissing(
+                    '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                    '(hipcc --offload-arch=gfx950).  kpal_amd has no CPU fallback.' % LIB_PATH)
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = load().kpal_last_error().decode('utf-8', 'replace')
+    if rc == _E_INVALID:
+        raise ValueError(msg)
+    if rc == _E_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError('kpal_hip error %d: %s' % (rc, msg))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().kpal_device_count(ctypes.byref(n))
+    if rc != 0:
+        return 0
+    return n.value
+
+
+def reverse_complement(number, length):
+    return int(load().kpal_reverse_complement(int(number) & 0xFFFFFFFFFFFFFFFF, int(length)))
+
+
+def _as_i64(a, what='counts'):
+    a = np.asanyarray(a)
+    if a.dtype.kind not in 'iub':
+        raise TypeError('%s must be an integer array (got %s)' % (what, a.dtype))
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class DeviceTable(object):
+    """Zero-copy view of a device buffer through __cuda_array_interface__ (consumed by
+    torch.as_tensor(..., device='cuda') for the RCCL reduce)."""
+
+    def __init__(self, ptr, n, owner, typestr='<i8'):
+        self.ptr, self.n, self._owner = ptr, n, owner
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': typestr, 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+class Context(object):
+    """One GPU, one HIP stream.  Not thread-safe (mirrors the single-threaded reference)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = _vp()
+        _check(self._L.kpal_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.kpal_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ------------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        p = _vp()
+        _check(self._L.kpal_dev_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        _check(self._L.kpal_dev_free(self._h, _vp(ptr)))
+
+    def h2d(self, dev_ptr, host_array):
+        a = np.ascontiguousarray(host_array)
+        _check(self._L.kpal_memcpy_h2d(self._h, _vp(dev_ptr), a.ctypes.data, a.nbytes))
+
+    def d2h(self, host_array, dev_ptr):
+        assert host_array.flags['C_CONTIGUOUS']
+        _check(self._L.kpal_memcpy_d2h(self._h, host_array.ctypes.data, _vp(dev_ptr), host_array.nbytes))
+
+    def sync(self):
+        _check(self._L.kpal_sync(self._h))
+
+    # -- counting ----------------------------------------------------------------------------
+    def count_begin(self, k, strategy='auto'):
+        _check(self._L.kpal_count_set_strategy(self._h, STRATEGY[strategy]))
+        _check(self._L.kpal_count_begin(self._h, int(k)))
+
+    def count_feed(self, buf):
+        """buf: bytes-like or uint8 array in host memory."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if a.size:
+            _check(self._L.kpal_count_feed(self._h, a.ctypes.data, a.size))
+
+    def count_feed_device(self, dev_ptr, nbytes):
+        _check(self._L.kpal_count_feed_device(self._h, _vp(dev_ptr), int(nbytes)))
+
+    def count_finish(self, k=None, to_host=True):
+        if not to_host:
+            _check(self._L.kpal_count_finish(self._h, None))
+            return None
+        ptr, n = self.count_table()
+        out = np.empty(n, dtype=np.int64)
+        _check(self._L.kpal_count_finish(self._h, out.ctypes.data))
+        return out
+
+    def count_table(self):
+        p = _vp()
+        n = ctypes.c_uint64(0)
+        _check(self._L.kpal_count_table(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def count_table_view(self):
+        ptr, n = self.count_table()
+        return DeviceTable(ptr, n, self)
+
+    def synth_reads_device(self, seed, first_read, n_reads, read_len, dev_ptr, noisy=False):
+        _check(self._L.kpal_synth_reads_device(self._h, int(seed), int(first_read), int(n_reads), int(read_len),
+                                               int(bool(noisy)), _vp(dev_ptr)))
+
+    def count_bytes(self, k, buf, strategy='auto'):
+        """Count one flat host byte stream -> int64[4**k]."""
+        self.count_begin(k, strategy)
+        self.count_feed(buf)
+        return self.count_finish()
+
+    # -- vector operations -----------------------------------------------------------------------
+    def balance_inplace(self, counts, k):
+        assert counts.dtype == np.int64 and counts.flags['C_CONTIGUOUS'] and counts.flags['WRITEABLE']
+        _check(self._L.kpal_balance(self._h, int(k), counts.ctypes.data))
+
+    def balance_device(self, k, dev_ptr):
+        _check(self._L.kpal_balance_device(self._h, int(k), _vp(dev_ptr)))
+
+    def split(self, counts, k):
+        c = _as_i64(counts)
+        f = np.empty(c.size, dtype=np.int64)
+        r = np.empty(c.size, dtype=np.int64)
+        m = ctypes.c_uint64(0)
+        _check(self._L.kpal_split(self._h, int(k), c.ctypes.data, f.ctypes.data, r.ctypes.data, ctypes.byref(m)))
+        return f[:m.value].copy(), r[:m.value].copy()
+
+    def strand_balance(self, counts, k, pairwise=PAIRWISE_PROD):
+        c = _as_i64(counts)
+        out = ctypes.c_double(0.0)
+        _check(self._L.kpal_strand_balance(self._h, int(k), c.ctypes.data, int(pairwise), ctypes.byref(out)))
+        return out.value
+
+    def pair_distance(self, left, right, metric, do_balance=False, k=0, return_aux=False):
+        l = _as_i64(left, 'left')
+        r = _as_i64(right, 'right')
+        if l.shape != r.shape or l.ndim != 1:
+            raise ValueError('left and right must be 1-d vectors of equal length')
+        out = ctypes.c_double(0.0)
+        aux = ctypes.c_int64(0)
+        _check(self._L.kpal_pair_distance(self._h, l.size, l.ctypes.data, r.ctypes.data, int(metric),
+                                          int(bool(do_balance)), int(k), ctypes.byref(out), ctypes.byref(aux)))
+        return (out.value, aux.value) if return_aux else out.value
+
+    def pair_distance_f64(self, left, right, pairwise, return_aux=False):
+        l = np.ascontiguousarray(left, dtype=np.float64)
+        r = np.ascontiguousarray(right, dtype=np.float64)
+        if l.shape != r.shape or l.ndim != 1:
+            raise ValueError('left and right must be 1-d vectors of equal length')
+        out = ctypes.c_double(0.0)
+        aux = ctypes.c_int64(0)
+        _check(self._L.kpal_pair_distance_f64(self._h, l.size, l.ctypes.data, r.ctypes.data, int(pairwise),
+                                              ctypes.byref(out), ctypes.byref(aux)))
+        return (out.value, aux.value) if return_aux else out.value
+
+    def pair_distance_device(self, n, dev_left, dev_right, metric, do_balance=False, k=0):
+        out = ctypes.c_double(0.0)
+        aux = ctypes.c_int64(0)
+        _check(self._L.kpal_pair_distance_device(self._h, int(n), _vp(dev_left), _vp(dev_right), int(metric),
+                                                 int(bool(do_balance)), int(k), ctypes.byref(out), ctypes.byref(aux)))
+        return out.value
+
+    def distance_matrix(self, profiles, k, metric, do_balance=False):
+        """profiles: list of int64[4**k] host vectors -> float64[P(P-1)/2] (kdistlib.py:179-186 order)."""
+        arrs = [_as_i64(p) for p in profiles]
+        P = len(arrs)
+        for a in arrs:
+            if a.size != 4 ** k:
+                raise ValueError('profile length %d != 4**%d' % (a.size, k))
+        out = np.zeros(P * (P - 1) // 2, dtype=np.float64)
+        ptrs = (_vp * P)(*[a.ctypes.data for a in arrs])
+        _check(self._L.kpal_distance_matrix(self._h, P, int(k), ptrs, int(metric), int(bool(do_balance)),
+                                            out.ctypes.data_as(_f64p)))
+        return out
+
+    def distance_matrix_device(self, P, k, dev_profiles, metric, do_balance=False):
+        out = np.zeros(P * (P - 1) // 2, dtype=np.float64)
+        _check(self._L.kpal_distance_matrix_device(self._h, int(P), int(k), _vp(dev_profiles), int(metric),
+                                                   int(bool(do_balance)), out.ctypes.data_as(_f64p)))
+        return out
+
+    # -- profiling ---------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        _check(self._L.kpal_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        _check(self._L.kpal_prof_reset(self._h))
+
+    def prof_get(self):
+        """-> {kernel name: (total_ms, launches)}"""
+        n = ctypes.c_int(0)
+        _check(self._L.kpal_prof_count(self._h, ctypes.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = ctypes.create_string_buffer(64)
+            ms = ctypes.c_double(0.0)
+            cnt = ctypes.c_uint64(0)
+            _check(self._L.kpal_prof_get(self._h, i, name, 64, ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+
+_default_ctx = None
+
+
+def default_device():
+    """LOCAL_RANK when launched one-process-per-GPU by torch.distributed.run, else KPAL_DEVICE or 0."""
+    return int(os.environ.get('KPAL_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+
+
+def context():
+    """Process-wide default Context (created on first use; raises if no library / no GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        if device_count() < 1:
+            raise RuntimeError('kpal_amd: no HIP device visible; the k-mer hot path has no CPU fallback')
+        _default_ctx = Context(default_device())
+    return _default_ctx

@@ -1,0 +1,834 @@
+// kpal_hip.hip -- C-ABI (include/kpal_hip.h) over the gfx950 kernels.  Host side: context,
+// workspace management, launch planning, H2D staging and per-kernel HIP-event timing.
+#include "../../include/kpal_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "count_kernels.hpp"
+#include "vec_kernels.hpp"
+
+#define KPAL_API extern "C" __attribute__((visibility("default")))
+
+using namespace kpal;
+
+// ----------------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(e_ == hipErrorOutOfMemory ? KPAL_E_NOMEM : KPAL_E_HIP, "%s failed: %s (%s:%d)", \
+                           #expr, hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define CHK(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != KPAL_OK) return rc_; \
+    } while (0)
+
+KPAL_API const char *kpal_last_error(void) { return g_err; }
+KPAL_API const char *kpal_version(void) { return "kpal_amd 0.1 (gfx950)"; }
+
+// ----------------------------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int name;
+    hipEvent_t a, b;
+};
+
+struct kpal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+    int num_cu = 256;
+    // counting state
+    int k = 0;
+    int strategy = KPAL_STRATEGY_AUTO;
+    bool counting = false;
+    DevBuf table;  // int64[4^k]
+    uint64_t bins = 0;
+    size_t batch_bytes = (size_t)1 << 30;
+    // partition workspace
+    DevBuf keys, cntmat, offs, bucket_start;
+    // host-feed staging
+    static constexpr size_t kStage = (size_t)64 << 20;
+    void *pinned[2] = {nullptr, nullptr};
+    DevBuf dstage[2];
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    // scratch for vector ops
+    DevBuf scratch[4];
+    DevBuf partials, result;
+    // profiling
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<uint64_t> prof_launches;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int ensure(kpal_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes && b.p) return KPAL_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_err(KPAL_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    b.cap = bytes;
+    return KPAL_OK;
+}
+
+static int prof_name_id(kpal_ctx *ctx, const char *name)
+{
+    for (size_t i = 0; i < ctx->prof_names.size(); ++i)
+        if (ctx->prof_names[i] == name) return (int)i;
+    ctx->prof_names.push_back(name);
+    ctx->prof_ms.push_back(0.0);
+    ctx->prof_launches.push_back(0);
+    return (int)ctx->prof_names.size() - 1;
+}
+
+static hipEvent_t prof_event(kpal_ctx *ctx)
+{
+    if (!ctx->ev_pool.empty()) {
+        hipEvent_t e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    kpal_ctx *ctx;
+    ProfRec rec;
+    bool on;
+    ProfScope(kpal_ctx *c, const char *name) : ctx(c), on(c->prof)
+    {
+        if (on) {
+            rec.name = prof_name_id(c, name);
+            rec.a = prof_event(c);
+            rec.b = prof_event(c);
+            (void)hipEventRecord(rec.a, c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(rec.b, ctx->stream);
+            ctx->prof_pending.push_back(rec);
+        }
+    }
+};
+
+static int prof_collect(kpal_ctx *ctx)
+{
+    if (ctx->prof_pending.empty()) return KPAL_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof_pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        ctx->prof_ms[r.name] += ms;
+        ctx->prof_launches[r.name] += 1;
+        ctx->ev_pool.push_back(r.a);
+        ctx->ev_pool.push_back(r.b);
+    }
+    ctx->prof_pending.clear();
+    return KPAL_OK;
+}
+
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                       \
+    do {                                                                                  \
+        {                                                                                 \
+            ProfScope ps_(ctx, name);                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);       \
+        }                                                                                 \
+        HIPCHK(hipGetLastError());                                                        \
+    } while (0)
+
+#define CASE_K(N, ...)           \
+    case N: {                    \
+        constexpr int K = N;     \
+        __VA_ARGS__;             \
+    } break;
+
+#define DISPATCH_K_1_16(k, ...)                                                                            \
+    switch (k) {                                                                                            \
+        CASE_K(1, __VA_ARGS__) CASE_K(2, __VA_ARGS__) CASE_K(3, __VA_ARGS__) CASE_K(4, __VA_ARGS__) CASE_K(5, __VA_ARGS__) CASE_K(6, __VA_ARGS__)     \
+        CASE_K(7, __VA_ARGS__) CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__) \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__)                                 \
+    default:                                                                                                \
+        return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);                           \
+    }
+
+#define DISPATCH_K_1_7(k, ...)                                                                         \
+    switch (k) {                                                                                        \
+        CASE_K(1, __VA_ARGS__) CASE_K(2, __VA_ARGS__) CASE_K(3, __VA_ARGS__) CASE_K(4, __VA_ARGS__) CASE_K(5, __VA_ARGS__) CASE_K(6, __VA_ARGS__) \
+        CASE_K(7, __VA_ARGS__)                                                                                 \
+    default:                                                                                            \
+        return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);                   \
+    }
+
+#define DISPATCH_K_8_12(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);         \
+    }
+
+KPAL_API int kpal_device_count(int *n)
+{
+    if (!n) return set_err(KPAL_E_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return set_err(KPAL_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
+{
+    if (!out) return set_err(KPAL_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return set_err(KPAL_E_INVALID, "device %d not in 0..%d", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    kpal_ctx *ctx = new (std::nothrow) kpal_ctx();
+    if (!ctx) return set_err(KPAL_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+    }
+    if (const char *e = getenv("KPAL_BATCH_BYTES")) {
+        unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= (1ULL << 20)) ctx->batch_bytes = (size_t)v;
+    }
+    *out = ctx;
+    return KPAL_OK;
+}
+
+KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->dstage[0],
+                      &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
+                      &ctx->partials, &ctx->result};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
+        if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);
+        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    }
+    for (auto &r : ctx->prof_pending) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+}
+
+#define CTX_ENTER(ctx)                                            \
+    if (!(ctx)) return set_err(KPAL_E_INVALID, "ctx is NULL");    \
+    HIPCHK(hipSetDevice((ctx)->device))
+
+KPAL_API int kpal_sync(kpal_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_dev_alloc(kpal_ctx *ctx, size_t nbytes, void **dev_out)
+{
+    CTX_ENTER(ctx);
+    if (!dev_out) return set_err(KPAL_E_INVALID, "dev_out is NULL");
+    *dev_out = nullptr;
+    hipError_t e = hipMalloc(dev_out, nbytes ? nbytes : 16);
+    if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_dev_free(kpal_ctx *ctx, void *dev)
+{
+    CTX_ENTER(ctx);
+    if (!dev) return KPAL_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(dev));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_memcpy_h2d(kpal_ctx *ctx, void *dev_dst, const void *host_src, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (nbytes == 0) return KPAL_OK;
+    HIPCHK(hipMemcpyAsync(dev_dst, host_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_memcpy_d2h(kpal_ctx *ctx, void *host_dst, const void *dev_src, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (nbytes == 0) return KPAL_OK;
+    HIPCHK(hipMemcpyAsync(host_dst, dev_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// counting
+// ----------------------------------------------------------------------------------------------
+KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    ctx->k = k;
+    ctx->bins = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
+    HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+    ctx->counting = true;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION)
+        return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
+    ctx->strategy = strategy;
+    return KPAL_OK;
+}
+
+static int resolve_strategy(kpal_ctx *ctx, int *out)
+{
+    int s = ctx->strategy;
+    const int k = ctx->k;
+    if (s == KPAL_STRATEGY_AUTO) s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : KPAL_STRATEGY_GLOBAL_ATOMIC);
+    if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
+    if (s == KPAL_STRATEGY_PARTITION && (k < 8 || k > 12))
+        return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
+    *out = s;
+    return KPAL_OK;
+}
+
+// Span for emitting the k-mers that end in [addr, addr+n), with `halo` readable bytes of the
+// same feed to the left of addr.
+static Span make_span(const uint8_t *addr, size_t n, size_t halo)
+{
+    const uintptr_t first = (uintptr_t)addr - halo;
+    const uintptr_t base = first & ~(uintptr_t)15;
+    Span s;
+    s.base = reinterpret_cast<const uint4 *>(base);
+    s.lo = first - base;
+    s.emit_from = s.lo + halo;
+    s.hi = s.emit_from + n;
+    s.nchunks = (s.hi + 15) / 16;
+    return s;
+}
+
+static int launch_global_atomic(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t steps = (s.nchunks + 63) / 64;
+    const uint64_t max_waves = (uint64_t)ctx->num_cu * 8 * 4;  // 8 blocks of 4 waves per CU
+    const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+    const uint64_t waves = (steps + spw - 1) / spw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_1_16(ctx->k, LAUNCH(ctx, "count_global_atomic", (count_global_atomic_kernel<K>), dim3(grid), dim3(256), s, spw, table));
+    return KPAL_OK;
+}
+
+static int launch_lds_direct(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t steps = (s.nchunks + 63) / 64;
+    const uint64_t max_waves = (uint64_t)ctx->num_cu * 2 * 8;  // 2 blocks of 8 waves per CU
+    const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+    const uint64_t waves = (steps + spw - 1) / spw;
+    const unsigned grid = (unsigned)((waves + 7) / 8);
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_1_7(ctx->k, LAUNCH(ctx, "count_lds_direct", (count_lds_direct_kernel<K>), dim3(grid), dim3(512), s, spw, table));
+    return KPAL_OK;
+}
+
+static int launch_partition(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t ntiles = (s.nchunks + kTileChunks - 1) / kTileChunks;
+    if (ntiles == 0) return KPAL_OK;
+    const uint64_t want_blocks = std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cu * 4);
+    const uint64_t tpb = (ntiles + want_blocks - 1) / want_blocks;
+    const uint32_t G = (uint32_t)((ntiles + tpb - 1) / tpb);
+    const uint64_t max_keys = s.nchunks * 16;
+    CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
+    CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs, (size_t)kNumBuckets * G * sizeof(uint64_t)));
+    CHK(ensure(ctx, ctx->bucket_start, (size_t)(kNumBuckets + 1) * sizeof(uint64_t)));
+    uint32_t *cntmat = (uint32_t *)ctx->cntmat.p;
+    uint64_t *offs = (uint64_t *)ctx->offs.p;
+    uint64_t *bstart = (uint64_t *)ctx->bucket_start.p;
+    uint16_t *keys = (uint16_t *)ctx->keys.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    const uint32_t slices = 4;
+    DISPATCH_K_8_12(ctx->k, {
+        LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb, cntmat);
+        LAUNCH(ctx, "part_scan", part_scan_kernel, dim3(1), dim3(1024), (const uint32_t *)cntmat, G, offs, bstart);
+        LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb,
+               (const uint64_t *)offs, keys);
+        LAUNCH(ctx, "part_hist", (part_hist_kernel<K>), dim3(kNumBuckets * slices), dim3(1024),
+               (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
+    });
+    return KPAL_OK;
+}
+
+// Count all k-mers ending in [addr, addr+n) of a device buffer; `halo` bytes left of addr are
+// readable and belong to the same feed.
+static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo)
+{
+    int strat = 0;
+    CHK(resolve_strategy(ctx, &strat));
+    const size_t km1 = (size_t)ctx->k - 1;
+    size_t piece = n;
+    if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
+    else if (strat == KPAL_STRATEGY_LDS_DIRECT) piece = (size_t)1 << 31;
+    piece &= ~(size_t)15;
+    if (piece == 0) piece = 16;
+    for (size_t off = 0; off < n; off += piece) {
+        const size_t len = std::min(piece, n - off);
+        const size_t h = std::min(km1, halo + off);
+        const Span s = make_span(addr + off, len, h);
+        if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
+        else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
+        else CHK(launch_partition(ctx, s));
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_device before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!dev_buf) return set_err(KPAL_E_INVALID, "dev_buf is NULL");
+    return count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
+}
+
+KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
+    const size_t km1 = (size_t)ctx->k - 1;
+    const size_t stage = kpal_ctx::kStage;
+    const size_t pad = 64;  // room for the halo, keeps the payload 16-byte aligned
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->pinned[i]) {
+            hipError_t e = hipHostMalloc(&ctx->pinned[i], stage + pad, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+        }
+        CHK(ensure(ctx, ctx->dstage[i], stage + pad));
+    }
+    int slot = 0;
+    for (size_t off = 0; off < nbytes; off += stage, slot ^= 1) {
+        const size_t len = std::min(stage, nbytes - off);
+        const size_t h = std::min(km1, off);
+        // the pinned/device slot is free once the H2D copy (pinned) and the kernels (device) that used it are done
+        if (ctx->stage_used[slot]) {
+            HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));
+            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[slot], 0));
+        }
+        uint8_t *hp = (uint8_t *)ctx->pinned[slot] + (pad - h);
+        memcpy(hp, host_buf + off - h, len + h);
+        uint8_t *dp = (uint8_t *)ctx->dstage[slot].p + (pad - h);
+        HIPCHK(hipMemcpyAsync(dp, hp, len + h, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+        CHK(count_device_range(ctx, dp + h, len, h));
+        HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
+        ctx->stage_used[slot] = true;
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
+    if (host_out)
+        HIPCHK(hipMemcpyAsync(host_out, ctx->table.p, ctx->bins * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "no count table (call kpal_count_begin)");
+    if (dev_table) *dev_table = ctx->table.p;
+    if (n_bins) *n_bins = ctx->bins;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_synth_reads_device(kpal_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                     int read_len, int noisy, void *dev_out)
+{
+    CTX_ENTER(ctx);
+    if (read_len < 1) return set_err(KPAL_E_INVALID, "read_len must be >= 1");
+    if (n_reads == 0) return KPAL_OK;
+    if (!dev_out || ((uintptr_t)dev_out & 15)) return set_err(KPAL_E_INVALID, "dev_out must be a 16-byte aligned device pointer");
+    const uint64_t total = n_reads * (uint64_t)(read_len + 1);
+    const uint64_t nvec = (total + 15) / 16;
+    const unsigned grid = (unsigned)std::min<uint64_t>((nvec + 255) / 256, (uint64_t)ctx->num_cu * 16);
+    LAUNCH(ctx, "synth_reads", synth_reads_kernel, dim3(grid), dim3(256), seed, first_read, n_reads,
+           (uint32_t)read_len, noisy, (uint8_t *)dev_out);
+    return KPAL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// vector operations
+// ----------------------------------------------------------------------------------------------
+static unsigned stream_grid(kpal_ctx *ctx, uint64_t n_items, unsigned block = 256)
+{
+    const uint64_t want = (n_items + block - 1) / block;
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cu * 8));
+}
+
+KPAL_API uint64_t kpal_reverse_complement(uint64_t number, int k)
+{
+    if (k < 1 || k > 32) return 0;
+    return revcomp(number, k);
+}
+
+KPAL_API int kpal_balance_device(kpal_ctx *ctx, int k, int64_t *dev_inout)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!dev_inout) return set_err(KPAL_E_INVALID, "dev_inout is NULL");
+    const uint64_t n = 1ULL << (2 * k);
+    LAUNCH(ctx, "balance_inplace", balance_inplace_kernel, dim3(stream_grid(ctx, n)), dim3(256), dev_inout, k, n);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_balance(kpal_ctx *ctx, int k, int64_t *host_inout)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!host_inout) return set_err(KPAL_E_INVALID, "host_inout is NULL");
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_inout, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CHK(kpal_balance_device(ctx, k, (int64_t *)ctx->scratch[0].p));
+    HIPCHK(hipMemcpyAsync(host_inout, ctx->scratch[0].p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_split(kpal_ctx *ctx, int k, const int64_t *host_counts, int64_t *host_forward,
+                        int64_t *host_reverse, uint64_t *n_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!host_counts || !host_forward || !host_reverse) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const uint64_t n = 1ULL << (2 * k);
+    const uint64_t pal = (k % 2 == 0) ? (1ULL << k) : 0ULL;   // 4^(k/2) palindromes for even k
+    const uint64_t m = (n + pal) / 2;
+    const uint32_t nseg = (uint32_t)((n + kSplitSeg - 1) / kSplitSeg);
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], m * 8));
+    CHK(ensure(ctx, ctx->scratch[2], m * 8));
+    CHK(ensure(ctx, ctx->scratch[3], (size_t)nseg * 16));
+    int64_t *dc = (int64_t *)ctx->scratch[0].p;
+    uint32_t *dcount = (uint32_t *)ctx->scratch[3].p;
+    uint64_t *doffs = (uint64_t *)((uint8_t *)ctx->scratch[3].p + (size_t)nseg * 4 + ((size_t)nseg * 4) % 8);
+    HIPCHK(hipMemcpyAsync(dc, host_counts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, "split_count", split_count_kernel, dim3(nseg), dim3(256), k, n, dcount);
+    std::vector<uint32_t> hc(nseg);
+    HIPCHK(hipMemcpyAsync(hc.data(), dcount, (size_t)nseg * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> ho(nseg);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < nseg; ++i) {
+        ho[i] = run;
+        run += hc[i];
+    }
+    if (run != m) return set_err(KPAL_E_HIP, "split: canonical count %llu != expected %llu", (unsigned long long)run, (unsigned long long)m);
+    HIPCHK(hipMemcpyAsync(doffs, ho.data(), (size_t)nseg * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, "split_write", split_write_kernel, dim3(nseg), dim3(256), (const int64_t *)dc, k, n,
+           (const uint64_t *)doffs, (int64_t *)ctx->scratch[1].p, (int64_t *)ctx->scratch[2].p);
+    HIPCHK(hipMemcpyAsync(host_forward, ctx->scratch[1].p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(host_reverse, ctx->scratch[2].p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n_out) *n_out = m;
+    return KPAL_OK;
+}
+
+// Reduce `nq` groups of `nblocks` partials and fetch them.
+static int finish_partials(kpal_ctx *ctx, uint32_t nq, uint32_t nblocks, std::vector<Partial> &out)
+{
+    CHK(ensure(ctx, ctx->result, (size_t)nq * sizeof(Partial)));
+    LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(nq), dim3(256), (const Partial *)ctx->partials.p,
+           nblocks, (Partial *)ctx->result.p);
+    out.resize(nq);
+    HIPCHK(hipMemcpyAsync(out.data(), ctx->result.p, (size_t)nq * sizeof(Partial), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+static double finish_value(int metric, const Partial &p, int64_t *aux)
+{
+    if (metric == KPAL_EUCLIDEAN) {
+        if (aux) *aux = (int64_t)p.m;
+        return std::sqrt((double)(int64_t)p.m);  // metrics.py:46: np.sqrt(np.dot(v, v))
+    }
+    if (aux) *aux = (int64_t)p.m;
+    return p.s / (double)(p.m + 1ULL);  // metrics.py:123
+}
+
+KPAL_API int kpal_strand_balance(kpal_ctx *ctx, int k, const int64_t *host_counts, int pairwise, double *out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!host_counts || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (pairwise != KPAL_PAIRWISE_PROD && pairwise != KPAL_PAIRWISE_SUM) return set_err(KPAL_E_INVALID, "pairwise must be prod or sum");
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_counts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = stream_grid(ctx, n);
+    CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
+    if (pairwise == KPAL_PAIRWISE_PROD)
+        LAUNCH(ctx, "strand_balance", (strand_balance_kernel<0>), dim3(grid), dim3(256), (const int64_t *)ctx->scratch[0].p, k, n, (Partial *)ctx->partials.p);
+    else
+        LAUNCH(ctx, "strand_balance", (strand_balance_kernel<1>), dim3(grid), dim3(256), (const int64_t *)ctx->scratch[0].p, k, n, (Partial *)ctx->partials.p);
+    std::vector<Partial> res;
+    CHK(finish_partials(ctx, 1, grid, res));
+    *out = finish_value(pairwise, res[0], nullptr);
+    return KPAL_OK;
+}
+
+template <typename T>
+static int pair_distance_launch(kpal_ctx *ctx, size_t n, const T *dl, const T *dr, int metric, double *out, int64_t *aux)
+{
+    const unsigned grid = stream_grid(ctx, (n + 1) / 2);
+    CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
+    Partial *pp = (Partial *)ctx->partials.p;
+    if (metric == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "pair_distance", (pair_distance_kernel<0, T>), dim3(grid), dim3(256), dl, dr, (uint64_t)n, pp);
+    else if (metric == KPAL_PAIRWISE_SUM) LAUNCH(ctx, "pair_distance", (pair_distance_kernel<1, T>), dim3(grid), dim3(256), dl, dr, (uint64_t)n, pp);
+    else {
+        if constexpr (std::is_same<T, int64_t>::value)
+            LAUNCH(ctx, "pair_distance", (pair_distance_kernel<2, T>), dim3(grid), dim3(256), dl, dr, (uint64_t)n, pp);
+        else
+            return set_err(KPAL_E_INVALID, "euclidean is int64 only");
+    }
+    std::vector<Partial> res;
+    CHK(finish_partials(ctx, 1, grid, res));
+    *out = finish_value(metric, res[0], aux);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *dev_left, const int64_t *dev_right,
+                                       int metric, int do_balance, int k, double *out, int64_t *aux_out)
+{
+    CTX_ENTER(ctx);
+    if (!dev_left || !dev_right || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (metric < 0 || metric > 2) return set_err(KPAL_E_INVALID, "unknown metric %d", metric);
+    if (((uintptr_t)dev_left & 15) || ((uintptr_t)dev_right & 15)) return set_err(KPAL_E_INVALID, "device vectors must be 16-byte aligned");
+    const int64_t *l = dev_left, *r = dev_right;
+    if (do_balance) {
+        if (k < 1 || k > KPAL_MAX_K || n != (1ULL << (2 * k))) return set_err(KPAL_E_INVALID, "do_balance needs n == 4^k");
+        CHK(ensure(ctx, ctx->scratch[2], n * 8));
+        CHK(ensure(ctx, ctx->scratch[3], n * 8));
+        LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256), l, (int64_t *)ctx->scratch[2].p, k, (uint64_t)n);
+        LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256), r, (int64_t *)ctx->scratch[3].p, k, (uint64_t)n);
+        l = (const int64_t *)ctx->scratch[2].p;
+        r = (const int64_t *)ctx->scratch[3].p;
+    }
+    return pair_distance_launch<int64_t>(ctx, n, l, r, metric, out, aux_out);
+}
+
+KPAL_API int kpal_pair_distance(kpal_ctx *ctx, size_t n, const int64_t *host_left, const int64_t *host_right,
+                                int metric, int do_balance, int k, double *out, int64_t *aux_out)
+{
+    CTX_ENTER(ctx);
+    if (!host_left || !host_right || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_left, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, host_right, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    return kpal_pair_distance_device(ctx, n, (const int64_t *)ctx->scratch[0].p, (const int64_t *)ctx->scratch[1].p,
+                                     metric, do_balance, k, out, aux_out);
+}
+
+KPAL_API int kpal_pair_distance_f64(kpal_ctx *ctx, size_t n, const double *host_left, const double *host_right,
+                                    int pairwise, double *out, int64_t *aux_out)
+{
+    CTX_ENTER(ctx);
+    if (!host_left || !host_right || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (pairwise != KPAL_PAIRWISE_PROD && pairwise != KPAL_PAIRWISE_SUM) return set_err(KPAL_E_INVALID, "pairwise must be prod or sum");
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_left, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, host_right, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    return pair_distance_launch<double>(ctx, n, (const double *)ctx->scratch[0].p, (const double *)ctx->scratch[1].p,
+                                        pairwise, out, aux_out);
+}
+
+KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles, int metric,
+                                         int do_balance, double *out_lower)
+{
+    CTX_ENTER(ctx);
+    if (P < 1) return set_err(KPAL_E_INVALID, "P must be >= 1");
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (metric < 0 || metric > 2) return set_err(KPAL_E_INVALID, "unknown metric %d", metric);
+    if (P == 1) return KPAL_OK;
+    if (!dev_profiles || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const uint64_t n = 1ULL << (2 * k);
+    const int64_t *prof = dev_profiles;
+    if (do_balance) {
+        // balance once per profile: identical to the reference balancing copies per pair (kdistlib.py:136-141)
+        CHK(ensure(ctx, ctx->scratch[2], (size_t)P * n * 8));
+        for (int p = 0; p < P; ++p)
+            LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256),
+                   dev_profiles + (uint64_t)p * n, (int64_t *)ctx->scratch[2].p + (uint64_t)p * n, k, n);
+        prof = (const int64_t *)ctx->scratch[2].p;
+    }
+    constexpr int TILE = 4;
+    const int side = (P + TILE - 1) / TILE;
+    std::vector<int2> tiles;
+    for (int ti = 0; ti < side; ++ti)
+        for (int tj = 0; tj <= ti; ++tj) tiles.push_back(make_int2(ti, tj));
+    const uint32_t ntiles = (uint32_t)tiles.size();
+    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 16 / ntiles)));
+    CHK(ensure(ctx, ctx->scratch[3], (size_t)ntiles * sizeof(int2)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, tiles.data(), (size_t)ntiles * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
+    Partial *pp = (Partial *)ctx->partials.p;
+    const int2 *dt = (const int2 *)ctx->scratch[3].p;
+    if (metric == 0) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<0, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+    else if (metric == 1) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<1, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+    else LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<2, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+    std::vector<Partial> res;
+    CHK(finish_partials(ctx, ntiles * TILE * TILE, gx, res));
+    for (int i = 1; i < P; ++i)
+        for (int j = 0; j < i; ++j) {
+            const int ti = i / TILE, tj = j / TILE;
+            const uint32_t t = (uint32_t)(ti * (ti + 1) / 2 + tj);
+            const Partial &p = res[(size_t)t * TILE * TILE + (i % TILE) * TILE + (j % TILE)];
+            out_lower[(size_t)i * (i - 1) / 2 + j] = finish_value(metric, p, nullptr);
+        }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host_profiles, int metric,
+                                  int do_balance, double *out_lower)
+{
+    CTX_ENTER(ctx);
+    if (P < 1) return set_err(KPAL_E_INVALID, "P must be >= 1");
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (P == 1) return KPAL_OK;
+    if (!host_profiles || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->scratch[0], (size_t)P * n * 8));
+    for (int p = 0; p < P; ++p) {
+        if (!host_profiles[p]) return set_err(KPAL_E_INVALID, "profile %d is NULL", p);
+        HIPCHK(hipMemcpyAsync((int64_t *)ctx->scratch[0].p + (uint64_t)p * n, host_profiles[p], n * 8,
+                              hipMemcpyHostToDevice, ctx->stream));
+    }
+    return kpal_distance_matrix_device(ctx, P, k, (const int64_t *)ctx->scratch[0].p, metric, do_balance, out_lower);
+}
+
+// ----------------------------------------------------------------------------------------------
+// profiling
+// ----------------------------------------------------------------------------------------------
+KPAL_API int kpal_prof_enable(kpal_ctx *ctx, int on)
+{
+    CTX_ENTER(ctx);
+    CHK(prof_collect(ctx));
+    ctx->prof = on != 0;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_prof_reset(kpal_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    CHK(prof_collect(ctx));
+    std::fill(ctx->prof_ms.begin(), ctx->prof_ms.end(), 0.0);
+    std::fill(ctx->prof_launches.begin(), ctx->prof_launches.end(), 0);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_prof_count(kpal_ctx *ctx, int *n_kernels)
+{
+    CTX_ENTER(ctx);
+    CHK(prof_collect(ctx));
+    if (n_kernels) *n_kernels = (int)ctx->prof_names.size();
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_prof_get(kpal_ctx *ctx, int index, char *name_out, size_t name_cap, double *total_ms,
+                           uint64_t *launches)
+{
+    CTX_ENTER(ctx);
+    CHK(prof_collect(ctx));
+    if (index < 0 || index >= (int)ctx->prof_names.size()) return set_err(KPAL_E_INVALID, "index out of range");
+    if (name_out && name_cap) {
+        strncpy(name_out, ctx->prof_names[index].c_str(), name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = ctx->prof_ms[index];
+    if (launches) *launches = ctx->prof_launches[index];
+    return KPAL_OK;
+}

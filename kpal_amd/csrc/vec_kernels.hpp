@@ -1,0 +1,285 @@
+// vec_kernels.hpp -- streaming kernels over 4^k int64 count vectors (gfx950).
+//   balance            Profile.balance            kpal/klib.py:285-298
+//   split              Profile.split              kpal/klib.py:300-327
+//   strand balance     kmer.get_balance score     kpal/kmer.py:243-245
+//   pair distance      metrics.multiset/euclidean kpal/metrics.py:101-135
+//   distance matrix    kdistlib.distance_matrix   kpal/kdistlib.py:179-186
+// All are HBM-bandwidth kernels except the matrix, which is fp64-divide bound.
+// fp64 sums are reduced in a FIXED order (per-thread serial, wave shuffle tree, block tree,
+// then a single-workgroup pass over the per-block partials) so results are run-to-run
+// reproducible; they agree with NumPy's pairwise summation to ~1e-15 relative.
+#pragma once
+#include "kpal_device.hpp"
+
+namespace kpal {
+
+// ---- pairwise functions, kpal/metrics.py:159-162, int64 wrap-around like NumPy -------------
+__device__ __forceinline__ int64_t wrap_abs_diff(int64_t x, int64_t y)
+{
+    const uint64_t d = (uint64_t)x - (uint64_t)y;
+    return (int64_t)d < 0 ? (int64_t)(0ULL - d) : (int64_t)d;
+}
+__device__ __forceinline__ double pw_prod(int64_t x, int64_t y)
+{
+    const int64_t den = (int64_t)(((uint64_t)x + 1ULL) * ((uint64_t)y + 1ULL));
+    return (double)wrap_abs_diff(x, y) / (double)den;
+}
+__device__ __forceinline__ double pw_sum(int64_t x, int64_t y)
+{
+    const int64_t den = (int64_t)((uint64_t)x + (uint64_t)y + 1ULL);
+    return (double)wrap_abs_diff(x, y) / (double)den;
+}
+__device__ __forceinline__ double pw_prod(double x, double y) { return fabs(x - y) / ((x + 1.0) * (y + 1.0)); }
+__device__ __forceinline__ double pw_sum(double x, double y) { return fabs(x - y) / (x + y + 1.0); }
+
+struct Partial {
+    double s;            // sum of pairwise terms
+    unsigned long long m;  // multiset: bins with l!=0 or r!=0; euclidean: wrapping int64 dot
+};
+
+__device__ __forceinline__ Partial block_reduce(Partial p)
+{
+    __shared__ double sh_s[16];
+    __shared__ unsigned long long sh_m[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        p.s += __shfl_down(p.s, d);
+        p.m += __shfl_down(p.m, d);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sh_s[wave] = p.s;
+        sh_m[wave] = p.m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) {
+            p.s += sh_s[w];
+            p.m += sh_m[w];
+        }
+    }
+    return p;  // valid in thread 0
+}
+
+// ---- balance ------------------------------------------------------------------------------
+// out[i] = in[i] + in[rc(i)] (i == rc(i) gives 2*in[i], klib.py:297-298).  Out of place.
+__global__ __launch_bounds__(256) void balance_oop_kernel(const int64_t *__restrict__ in, int64_t *__restrict__ out,
+                                                          int k, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (int64_t)((uint64_t)in[i] + (uint64_t)in[revcomp(i, k)]);
+}
+
+// In place: the thread owning i < rc(i) updates both ends of the pair (klib.py:290-296).
+__global__ __launch_bounds__(256) void balance_inplace_kernel(int64_t *__restrict__ c, int k, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = revcomp(i, k);
+        if (i < r) {
+            const uint64_t v = (uint64_t)c[i] + (uint64_t)c[r];
+            c[i] = (int64_t)v;
+            c[r] = (int64_t)v;
+        } else if (i == r) {
+            c[i] = (int64_t)((uint64_t)c[i] * 2ULL);
+        }
+    }
+}
+
+// ---- split --------------------------------------------------------------------------------
+// Order-preserving compaction of i <= rc(i).  Pass 1 counts canonical indices per block-sized
+// segment; the host scans the (small) count array; pass 2 writes.
+constexpr int kSplitSeg = 4096;  // indices per block
+
+__global__ __launch_bounds__(256) void split_count_kernel(int k, uint64_t n, uint32_t *__restrict__ seg_count)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * kSplitSeg;
+    uint32_t c = 0;
+    for (int t = threadIdx.x; t < kSplitSeg; t += blockDim.x) {
+        const uint64_t i = base + t;
+        if (i < n && i <= revcomp(i, k)) ++c;
+    }
+    __shared__ uint32_t sh[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_count[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void split_write_kernel(const int64_t *__restrict__ c, int k, uint64_t n,
+                                                          const uint64_t *__restrict__ seg_offset,
+                                                          int64_t *__restrict__ fwd, int64_t *__restrict__ rev)
+{
+    __shared__ uint32_t wave_tot[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kSplitSeg;
+    uint64_t out = seg_offset[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t0 = 0; t0 < kSplitSeg; t0 += 256) {
+        const uint64_t i = base + t0 + threadIdx.x;
+        uint64_t r = 0;
+        bool keep = false;
+        if (i < n) {
+            r = revcomp(i, k);
+            keep = i <= r;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const uint32_t before = __popcll(bal & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wbase += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        if (keep) {
+            const uint64_t o = out + wbase + before;
+            if (i < r) {
+                fwd[o] = (int64_t)((uint64_t)c[i] * 2ULL);   // klib.py:319-320
+                rev[o] = (int64_t)((uint64_t)c[r] * 2ULL);
+            } else {
+                fwd[o] = c[i];                               // klib.py:322-323
+                rev[o] = c[i];
+            }
+        }
+        out += tot;
+        __syncthreads();
+    }
+}
+
+// ---- strand balance: multiset(*split()) fused ------------------------------------------------
+template <int PW>
+__global__ __launch_bounds__(256) void strand_balance_kernel(const int64_t *__restrict__ c, int k, uint64_t n,
+                                                             Partial *__restrict__ partials)
+{
+    Partial p = {0.0, 0ULL};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = revcomp(i, k);
+        if (i > r) continue;
+        int64_t f, v;
+        if (i < r) {
+            f = (int64_t)((uint64_t)c[i] * 2ULL);
+            v = (int64_t)((uint64_t)c[r] * 2ULL);
+        } else {
+            f = v = c[i];
+        }
+        if (f != 0 || v != 0) {
+            p.s += PW == 0 ? pw_prod(f, v) : pw_sum(f, v);
+            p.m += 1;
+        }
+    }
+    p = block_reduce(p);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+// ---- pair distance --------------------------------------------------------------------------
+// METRIC 0/1: multiset prod/sum (metrics.py:121-123); 2: euclidean (int64 dot, metrics.py:135,46).
+template <int METRIC, typename T>
+__global__ __launch_bounds__(256) void pair_distance_kernel(const T *__restrict__ l, const T *__restrict__ r,
+                                                            uint64_t n, Partial *__restrict__ partials)
+{
+    Partial p = {0.0, 0ULL};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // two elements per 16-byte load
+    const uint64_t n2 = n >> 1;
+    using V2 = typename std::conditional<std::is_same<T, double>::value, double2, longlong2>::type;
+    const V2 *l2 = reinterpret_cast<const V2 *>(l);
+    const V2 *r2 = reinterpret_cast<const V2 *>(r);
+    auto term = [&](T x, T y) {
+        if constexpr (METRIC == 2) {
+            const uint64_t d = (uint64_t)x - (uint64_t)y;
+            p.m += d * d;
+        } else {
+            if (x != 0 || y != 0) {
+                p.s += METRIC == 0 ? pw_prod(x, y) : pw_sum(x, y);
+                p.m += 1;
+            }
+        }
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const V2 a = l2[i], b = r2[i];
+        term((T)a.x, (T)b.x);
+        term((T)a.y, (T)b.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) term(l[n - 1], r[n - 1]);
+    p = block_reduce(p);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+// Final fixed-order reduction of per-block partials: out[q] = sum over blocks of partials[q*nblocks + b].
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const Partial *__restrict__ partials, uint32_t nblocks,
+                                                              Partial *__restrict__ out)
+{
+    const Partial *src = partials + (uint64_t)blockIdx.x * nblocks;
+    Partial p = {0.0, 0ULL};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        p.s += src[b].s;
+        p.m += src[b].m;
+    }
+    p = block_reduce(p);
+    if (threadIdx.x == 0) out[blockIdx.x] = p;
+}
+
+// ---- distance matrix --------------------------------------------------------------------------
+// Lower triangle of P x P in TILE x TILE register tiles.  blockIdx.y = tile (ti >= tj),
+// blockIdx.x strides over bins.  Each thread streams one bin at a time for the TILE row
+// profiles and TILE column profiles (coalesced 512-B wave loads per profile), accumulating
+// TILE^2 (sum, m) pairs in registers.  partial layout: [tile][entry a*TILE+b][blockIdx.x].
+template <int METRIC, int TILE>
+__global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                          const int2 *__restrict__ tiles,
+                                                          Partial *__restrict__ partials)
+{
+    const int ti = tiles[blockIdx.y].x, tj = tiles[blockIdx.y].y;
+    double s[TILE][TILE];
+    unsigned long long m[TILE][TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            s[a][b] = 0.0;
+            m[a][b] = 0ULL;
+        }
+    const int64_t *rowp[TILE];
+    const int64_t *colp[TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a) {
+        rowp[a] = prof + (uint64_t)min(ti * TILE + a, P - 1) * n;
+        colp[a] = prof + (uint64_t)min(tj * TILE + a, P - 1) * n;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        int64_t x[TILE], y[TILE];
+#pragma unroll
+        for (int a = 0; a < TILE; ++a) {
+            x[a] = rowp[a][i];
+            y[a] = colp[a][i];
+        }
+#pragma unroll
+        for (int a = 0; a < TILE; ++a)
+#pragma unroll
+            for (int b = 0; b < TILE; ++b) {
+                if constexpr (METRIC == 2) {
+                    const uint64_t d = (uint64_t)x[a] - (uint64_t)y[b];
+                    m[a][b] += d * d;
+                } else {
+                    if (x[a] != 0 || y[b] != 0) {
+                        s[a][b] += METRIC == 0 ? pw_prod(x[a], y[b]) : pw_sum(x[a], y[b]);
+                        m[a][b] += 1;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            Partial p = {s[a][b], m[a][b]};
+            p = block_reduce(p);
+            if (threadIdx.x == 0)
+                partials[((uint64_t)blockIdx.y * TILE * TILE + a * TILE + b) * gridDim.x + blockIdx.x] = p;
+        }
+}
+
+}  // namespace kpal

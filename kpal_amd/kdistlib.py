@@ -1,0 +1,125 @@
+"""Drop-in for ``kpal.kdistlib``: :class:`ProfileDistance` and :func:`distance_matrix`.
+
+The default pipeline of ``ProfileDistance.distance`` -- copy, optional balance, multiset or
+euclidean (kpal/kdistlib.py:126-161) -- runs as fused HIP kernels (``kpal_pair_distance``), and
+``distance_matrix`` over P profiles is ONE tiled kernel launch (``kpal_distance_matrix``) instead
+of P(P-1)/2 Python-level distances; profiles are balanced once each, which is identical to the
+reference balancing copies inside every pair.  The optional positive / dynamic-smooth / scale
+steps (kpal/kdistlib.py:143-157) keep the reference's NumPy formulation and hand the resulting
+vectors to the same HIP reductions.
+"""
+import numpy as np
+
+from . import _native, metrics
+
+
+class ProfileDistance(object):
+    """Configurable distance between two profiles (kpal/kdistlib.py:21-51)."""
+
+    def __init__(self, do_balance=False, do_positive=False, do_smooth=False,
+                 summary=metrics.summary['min'], threshold=0, do_scale=False,
+                 down=False, distance_function=None,
+                 pairwise=metrics.pairwise['prod']):
+        self._do_balance = do_balance
+        self._do_positive = do_positive
+        self._do_smooth = do_smooth
+        self._threshold = threshold
+        self._do_scale = do_scale
+        self._down = down
+        self._distance_function = distance_function
+        self._pairwise = pairwise
+        self._function = summary
+
+    # ---- dynamic smoothing (kpal/kdistlib.py:53-124); NumPy, "next" for the GPU ---------------
+    def _collapse(self, vector, start, length):
+        """Sums of the four quarters of ``vector[start:start+length]``."""
+        return np.reshape(vector[start:start + length], (4, length // 4)).sum(axis=1)
+
+    def _dynamic_smooth(self, left, right, start, length):
+        if length == 1:
+            return
+        left_c = self._collapse(left.counts, start, length)
+        right_c = self._collapse(right.counts, start, length)
+        if min(self._function(left_c), self._function(right_c)) <= self._threshold:
+            left.counts[start] = left_c.sum()
+            right.counts[start] = right_c.sum()
+            left.counts[start + 1:start + length] = 0
+            right.counts[start + 1:start + length] = 0
+            return
+        quarter = length // 4
+        for i in range(4):
+            self._dynamic_smooth(left, right, start + i * quarter, quarter)
+
+    def dynamic_smooth(self, left, right):
+        """Collapse sub-profiles that fail the summary/threshold test, in place."""
+        self._dynamic_smooth(left, right, 0, left.number)
+
+    # ---- routing -------------------------------------------------------------------------------
+    def _native_metric(self):
+        """Metric code when the final reduction can run on the GPU, else None."""
+        if self._distance_function is None:
+            return metrics.pairwise_code(self._pairwise)
+        if self._distance_function is metrics.euclidean:
+            return _native.EUCLIDEAN
+        return None
+
+    def _is_plain(self):
+        return not (self._do_positive or self._do_smooth or self._do_scale)
+
+    def distance(self, left, right):
+        """Distance between two profiles; the inputs are left unmodified
+        (kpal/kdistlib.py:126-161, tests/test_kdistlib.py:124-135)."""
+        metric = self._native_metric()
+        if (self._is_plain() and metric is not None and np.asanyarray(left.counts).dtype.kind in 'iub'
+                and np.asanyarray(right.counts).dtype.kind in 'iub'):
+            # fused: balanced copies are made on the device, nothing is written back
+            return _native.context().pair_distance(left.counts, right.counts, metric,
+                                                   do_balance=self._do_balance, k=left.length)
+
+        left = left.copy()
+        right = right.copy()
+        if self._do_balance:
+            left.balance()
+            right.balance()
+        if self._do_positive:
+            left.counts = metrics.positive(left.counts, right.counts)
+            right.counts = metrics.positive(right.counts, left.counts)
+        if self._do_smooth:
+            self.dynamic_smooth(left, right)
+        if self._do_scale:
+            left_scale, right_scale = metrics.get_scale(left.counts, right.counts)
+            if self._down:
+                left_scale, right_scale = metrics.scale_down(left_scale, right_scale)
+            left.counts = left.counts * left_scale
+            right.counts = right.counts * right_scale
+        if not self._distance_function:
+            return metrics.multiset(left.counts, right.counts, self._pairwise)
+        return self._distance_function(left.counts, right.counts)
+
+
+def distance_matrix(profiles, output, precision, dist):
+    """Write the lower-triangular distance matrix of ``profiles`` to ``output``
+    (kpal/kdistlib.py:164-186): the count, the names, then row i = distances to profiles
+    0..i-1, ``precision`` decimals, space separated."""
+    count = len(profiles)
+    print(str(count), file=output)
+    for profile in profiles:
+        print(profile.name, file=output)
+    if count < 2:
+        return
+
+    metric = dist._native_metric()
+    same_k = len(set(p.length for p in profiles)) == 1
+    integer = all(np.asanyarray(p.counts).dtype.kind in 'iub' for p in profiles)
+    if dist._is_plain() and metric is not None and same_k and integer:
+        values = _native.context().distance_matrix([p.counts for p in profiles], profiles[0].length, metric,
+                                                   do_balance=dist._do_balance)
+    else:
+        values = [dist.distance(profiles[i], profiles[j]) for i in range(1, count) for j in range(i)]
+
+    fmt = '{{0:.{0}f}}'.format(precision)
+    at = 0
+    for i in range(1, count):
+        output.write(' '.join(fmt.format(values[at + j]) for j in range(i)))
+        output.write('\n')
+        at += i

@@ -1,0 +1,273 @@
+"""Drop-in for ``kpal.klib``: the :class:`Profile` container with k-mer counting, balance and
+split running as HIP kernels on an MI355X.
+
+Same constructor, classmethods, methods, properties and error behaviour as the reference class
+(kpal/klib.py:26-487).  Differences are internal only:
+
+* ``from_sequences`` / ``from_fasta`` do not loop over characters in Python: sequences are joined
+  into a flat byte stream (one ``\\n`` between sequences -- any byte outside ``AaCcGgTt`` splits
+  windows exactly like the reference's ``re.split``, kpal/klib.py:152-156) and fed to
+  ``kpal_count_feed``.
+* FASTA is tokenised here (the reference delegates to ``Bio.SeqIO.parse``, kpal/klib.py:111,131):
+  lines starting with ``>`` open a record whose name is the first whitespace-delimited token;
+  the record's remaining lines are concatenated with surrounding whitespace removed; text before
+  the first ``>`` is ignored.
+* ``balance`` / ``split`` call ``kpal_balance`` / ``kpal_split``.
+
+There is no CPU fallback for those paths: without libkpal_hip.so or without a GPU they raise.
+Container-only helpers (``merge``, ``shrink``, ``shuffle``, statistics, printers, HDF5 I/O) are
+not part of the hot path and use NumPy like the reference.
+"""
+import itertools
+import math
+
+import numpy as np
+
+from . import _native, metrics
+
+_FEED_BYTES = 32 << 20  # host-side join buffer per feed
+
+
+def _fasta_records(handle):
+    """Yield ``(name, sequence)`` per FASTA record."""
+    name = None
+    parts = []
+    for line in handle:
+        if isinstance(line, bytes):
+            line = line.decode('ascii', 'replace')
+        if line.startswith('>'):
+            if name is not None:
+                yield name, ''.join(parts)
+            title = line[1:].strip()
+            name = title.split(None, 1)[0] if title else ''
+            parts = []
+        elif name is not None:
+            parts.append(''.join(line.split()))
+    if name is not None:
+        yield name, ''.join(parts)
+
+
+def _encode(sequence):
+    if isinstance(sequence, (bytes, bytearray, memoryview)):
+        return bytes(sequence)
+    # non-latin-1 characters can never be nucleotides: they become '?' (a separator)
+    return str(sequence).encode('latin-1', 'replace')
+
+
+class Profile(object):
+    """A k-mer profile: ``counts[i]`` is the count of the k-mer whose 2-bit big-endian encoding
+    (A=0, C=1, G=2, T=3) is ``i`` (kpal/klib.py:26-61).
+
+    :arg counts: ``numpy.ndarray`` of length ``4**k`` (kept by reference, like the original).
+    :arg str name: optional profile name (no ``/`` or ``.``).
+    """
+
+    _nucleotide_to_binary = {'A': 0, 'a': 0, 'C': 1, 'c': 1, 'G': 2, 'g': 2, 'T': 3, 't': 3}
+    _binary_to_nucleotide = {0: 'A', 1: 'C', 2: 'G', 3: 'T'}
+
+    def __init__(self, counts, name=None):
+        self.length = int(math.log(len(counts), 4))
+        self.counts = counts
+        self.name = name
+
+    # ---- constructors --------------------------------------------------------------------
+    @classmethod
+    def from_file(cls, handle, name=None):
+        """Load from an open HDF5 k-mer file (kpal/klib.py:63-76)."""
+        name = name or sorted(handle['profiles'].keys())[0]
+        return cls(handle['profiles/' + name][:], name=name)
+
+    @classmethod
+    def from_file_old_format(cls, handle, name=None):
+        """Load the pre-1.0 plaintext format: three header lines, then one count per line
+        (kpal/klib.py:78-95)."""
+        for _ in range(3):
+            next(handle)
+        return cls(np.loadtxt(handle, dtype='int64'), name=name)
+
+    @classmethod
+    def from_fasta(cls, handle, length, name=None):
+        """One profile over all records of a FASTA handle (kpal/klib.py:97-112)."""
+        return cls.from_sequences((seq for _, seq in _fasta_records(handle)), length, name=name)
+
+    @classmethod
+    def from_fasta_by_record(cls, handle, length, prefix=None):
+        """One profile per FASTA record, named by record (kpal/klib.py:114-133)."""
+        prefix = prefix + '_' if prefix else ''
+        for i, (record_name, seq) in enumerate(_fasta_records(handle)):
+            yield cls.from_sequences([seq], length, name=prefix + (record_name or str(i + 1)))
+
+    @classmethod
+    def from_sequences(cls, sequences, length, name=None):
+        """Count all k-mers of every sequence (kpal/klib.py:135-170) on the GPU.
+
+        Windows never span two sequences or a character outside ``AaCcGgTt``.
+        """
+        length = int(length)
+        if length < 1 or length > _native.KPAL_MAX_K:
+            raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
+        ctx = _native.context()
+        ctx.count_begin(length)
+        pending = []
+        size = 0
+        for sequence in sequences:
+            data = _encode(sequence)
+            pending.append(data)
+            size += len(data) + 1
+            if size >= _FEED_BYTES:
+                # feeds are independent: a window never spans two feeds, nor two sequences
+                ctx.count_feed(b'\n'.join(pending))
+                pending, size = [], 0
+        if pending:
+            ctx.count_feed(b'\n'.join(pending))
+        return cls(ctx.count_finish(), name=name)
+
+    # ---- properties ------------------------------------------------------------------------
+    @property
+    def name(self):
+        return self._name
+
+    @name.setter
+    def name(self, name):
+        if name and ('/' in name or '.' in name):
+            raise ValueError('Profile name may not contain / or . characters.')
+        self._name = name
+
+    @property
+    def number(self):
+        """Number of possible k-mers of this length."""
+        return len(self.counts)
+
+    @property
+    def non_zero(self):
+        return np.count_nonzero(self.counts)
+
+    @property
+    def total(self):
+        return self.counts.sum()
+
+    @property
+    def mean(self):
+        return self.counts.mean()
+
+    @property
+    def median(self):
+        return np.median(self.counts)
+
+    @property
+    def std(self):
+        return self.counts.std()
+
+    # ---- I/O -------------------------------------------------------------------------------
+    def save(self, handle, name=None):
+        """Write to an open HDF5 k-mer file, dataset ``profiles/<name>`` with the summary
+        attributes of format 1.0.0 (kpal/klib.py:227-256, doc/fileformat.rst:23-46)."""
+        if name and ('/' in name or '.' in name):
+            raise ValueError('Profile name may not contain / or . characters.')
+        name = name or self.name or next(str(n) for n in itertools.count(1) if str(n) not in handle['profiles'])
+        dataset = handle.create_dataset('profiles/' + name, data=self.counts, dtype='int64', compression='gzip')
+        for key in ('length', 'total', 'non_zero', 'mean', 'median', 'std'):
+            dataset.attrs[key] = getattr(self, key)
+        handle.flush()
+        return name
+
+    def copy(self):
+        """Deep copy (kpal/klib.py:258-267)."""
+        return type(self)(self.counts.copy(), name=self.name)
+
+    def merge(self, profile, merger=metrics.mergers['sum']):
+        """Merge another profile into this one with a vectorised merger (kpal/klib.py:269-283)."""
+        self.counts = merger(self.counts, profile.counts)
+
+    # ---- hot path: balance / split ------------------------------------------------------------
+    def _int64_counts(self):
+        c = np.asanyarray(self.counts)
+        if c.dtype.kind not in 'iub':
+            raise TypeError('balance/split need integer counts (got %s)' % c.dtype)
+        return c
+
+    def balance(self):
+        """``counts[i] += counts[rc(i)]`` for every k-mer, palindromes doubled, in place
+        (kpal/klib.py:285-298) -- one HIP kernel."""
+        c = self._int64_counts()
+        if c.dtype == np.int64 and c.flags['C_CONTIGUOUS'] and c.flags['WRITEABLE']:
+            _native.context().balance_inplace(c, self.length)
+        else:
+            tmp = np.ascontiguousarray(c, dtype=np.int64).copy()
+            _native.context().balance_inplace(tmp, self.length)
+            self.counts[...] = tmp
+
+    def split(self):
+        """Doubled forward / reverse-complement halves in ascending k-mer order
+        (kpal/klib.py:300-327) -- ``kpal_split``."""
+        return _native.context().split(self._int64_counts(), self.length)
+
+    # ---- container helpers (NumPy; not on the hot path) ------------------------------------------
+    def shrink(self, factor=1):
+        """Reduce k by ``factor`` by summing groups of ``4**factor`` bins (kpal/klib.py:329-352)."""
+        if self.length <= factor:
+            raise ValueError('Reduction factor should be smaller than k-mer size.')
+        group = 4 ** factor
+        self.counts = np.asarray(self.counts).reshape(-1, group).sum(axis=1, dtype='int64')
+        self.length -= factor
+
+    def shuffle(self):
+        """Randomise the profile in place (kpal/klib.py:354-358)."""
+        np.random.shuffle(self.counts)
+
+    def dna_to_binary(self, sequence):
+        """DNA string -> integer; ``KeyError`` on a non-ACGT character (kpal/klib.py:360-375)."""
+        result = 0
+        for nucleotide in sequence:
+            result = (result << 2) | self._nucleotide_to_binary[nucleotide]
+        return result
+
+    def binary_to_dna(self, number):
+        """Integer -> DNA string of this profile's k (kpal/klib.py:377-392)."""
+        letters = []
+        for _ in range(self.length):
+            letters.append(self._binary_to_nucleotide[number & 3])
+            number >>= 2
+        return ''.join(reversed(letters))
+
+    def reverse_complement(self, number):
+        """Reverse complement in the binary representation (kpal/klib.py:394-412)."""
+        return _native.reverse_complement(number, self.length)
+
+    def _ratios_matrix(self):
+        """All relative frequencies count[i]/count[j]/total, -1.0 where count[j] is 0
+        (kpal/klib.py:414-437)."""
+        c = np.asarray(self.counts, dtype='float64')
+        total = float(self.total)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            m = (c[:, None] / c[None, :]) / total
+        m[:, c == 0] = -1.0
+        return m.tolist()
+
+    def _freq_diff_matrix(self):
+        """All |count[i]-count[j]|/total, 0 where count[j] is 0 (kpal/klib.py:439-456)."""
+        c = np.asarray(self.counts)
+        total = self.total
+        m = np.abs(c[:, None] - c[None, :]) / total
+        out = m.tolist()
+        for j in np.nonzero(c == 0)[0]:
+            for row in out:
+                row[j] = 0
+        return out
+
+    def print_counts(self):
+        """Print ``<k-mer> <count>`` lines (kpal/klib.py:458-463)."""
+        for i in range(self.number):
+            print(self.binary_to_dna(i), self.counts[i])
+
+    def _print_ratios(self, ratios):
+        """Print a ratios matrix (kpal/klib.py:465-487)."""
+        print((self.length + 1) * ' ', end=' ')
+        for i in range(self.number):
+            print(self.binary_to_dna(i), end='   ')
+        print()
+        for i in range(self.number):
+            print(self.binary_to_dna(i), end=' ')
+            for j in range(self.number):
+                print('{{0:.{0}f}}'.format(self.length).format(ratios[i][j]), end=' ')
+            print()

@@ -1,0 +1,143 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/kpal_hip.h
+declares, the product path fails loudly without a GPU, host logic (FASTA tokenising, names,
+sharding) and the world_size-2 gloo reduce."""
+import io
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__
+    __graft_entry__.build()
+    from kpal_amd import _native
+    return _native
+
+
+def test_header_symbols_exported(built):
+    header = open(os.path.join(ROOT, 'include', 'kpal_hip.h')).read()
+    declared = set(re.findall(r'\b(kpal_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 25
+    L = built.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), 'libkpal_hip.so does not export %s' % name
+    assert declared == set(built.SIGNATURES), declared ^ set(built.SIGNATURES)
+    assert b'gfx950' in L.kpal_version()
+
+
+def test_host_helpers_without_gpu(built):
+    import oracle
+    for k in (1, 2, 5, 12, 15, 16):
+        for x in (0, 1, 4 ** k - 1, 12345 % 4 ** k):
+            assert built.reverse_complement(x, k) == oracle.reverse_complement(x, k)
+
+
+def test_fails_loudly_without_gpu(built):
+    if built.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    from kpal_amd import klib, metrics
+    with pytest.raises(RuntimeError):
+        klib.Profile.from_sequences(['ACGT'], 2)
+    with pytest.raises(RuntimeError):
+        metrics.multiset(np.ones(4, dtype=np.int64), np.ones(4, dtype=np.int64), metrics.pairwise['prod'])
+    with pytest.raises(RuntimeError):
+        klib.Profile(np.ones(16, dtype=np.int64)).balance()
+
+
+def test_no_oracle_import_in_product():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'kpal_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'kpal_oracle' not in text, f
+
+
+def test_fasta_tokeniser_and_profile_surface():
+    from kpal_amd import klib
+    recs = list(klib._fasta_records(io.StringIO('junk\n>a first\nACG\nT G\n\n>b\n>\nNN\n')))
+    assert recs == [('a', 'ACGTG'), ('b', ''), ('', 'NN')]
+    p = klib.Profile(np.arange(16, dtype=np.int64), 'n')
+    assert (p.length, p.number, p.total, p.non_zero) == (2, 16, 120, 15)
+    assert p.binary_to_dna(p.dna_to_binary('GT')) == 'GT'
+    with pytest.raises(KeyError):
+        p.dna_to_binary('AN')
+    with pytest.raises(ValueError):
+        p.name = 'a.b'
+    p.name = None
+    q = p.copy()
+    q.counts[0] = 99
+    assert p.counts[0] == 0
+    p.merge(q)
+    assert p.counts[0] == 99 and p.counts[1] == 2
+    p.shrink()
+    assert p.length == 1 and list(p.counts) == [111, 44, 76, 108]
+    with pytest.raises(ValueError):
+        p.shrink(1)
+
+
+def test_metrics_numpy_helpers():
+    from kpal_amd import metrics
+    assert set(metrics.pairwise) == {'prod', 'sum'} and set(metrics.mergers) == {'sum', 'xor', 'int', 'nint'}
+    assert set(metrics.summary) == {'min', 'average', 'median'} and set(metrics.vector_distance) == {'default', 'euclidean', 'cosine'}
+    l, r = np.array([1, 2, 3]), np.array([2, 4, 6])
+    assert metrics.get_scale(l, r) == (2.0, 1.0) and metrics.scale_down(2.0, 1.0) == (1.0, 0.5)
+    assert list(metrics.positive(l, [0, 1, 1])) == [0, 2, 3]
+    assert metrics.distribution([1, 1, 2]) == [(1, 2), (2, 1)]
+    np.testing.assert_allclose(metrics.pairwise['prod'](l, r), abs(l - r) / ((l + 1) * (r + 1)))
+
+
+def test_shard_range():
+    from kpal_amd import dist
+    for n in (0, 1, 7, 100, 10 ** 8):
+        for w in (1, 2, 3, 8):
+            blocks = [dist.shard_range(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
+            for (f0, c0), (f1, _) in zip(blocks[:-1], blocks[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+    with pytest.raises(ValueError):
+        dist.shard_range(10, 2, 2)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as td
+import oracle
+from kpal_amd import dist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+td.init_process_group('gloo', rank=rank, world_size=world)
+k, n_reads = 6, 1001
+first, n = dist.shard_range(n_reads, rank, world)
+local = oracle.count_flat(oracle.synth_reads(3, first, n, 150), k)      # per-rank table (oracle stands in for the GPU here)
+t = torch.from_numpy(local.copy())
+dist.reduce_counts(t, dst=0)
+if rank == 0:
+    want = oracle.count_flat(oracle.synth_reads(3, 0, n_reads, 150), k)
+    assert np.array_equal(t.numpy(), want), 'sharded + reduced counts differ from the single-stream count'
+    print('GLOO_OK', int(t.sum()))
+td.barrier()
+td.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_reduce(tmp_path):
+    """N > 1 path on CPU: shard reads over 2 ranks, reduce the int64 tables with one collective
+    (gloo here, RCCL on the GPUs), compare with the single-stream count."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_GLOO_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', WORLD_SIZE='2')
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'GLOO_OK %d' % (1001 * 145) in outs[0]

@@ -1,0 +1,284 @@
+"""Parity of the HIP counting path (through the C-ABI) with the oracle and the reference
+goldens.  Bit-exact: integer work.  Run on the GPU box: pytest -m gpu."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import dense
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(v):
+    return hashlib.sha256(np.ascontiguousarray(v, dtype='<i8').tobytes()).hexdigest()
+
+
+def strategies(k):
+    s = ['auto', 'global_atomic']
+    if k <= 7:
+        s.append('lds_direct')
+    if 8 <= k <= 12:
+        s.append('partition')
+    return s
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from kpal_amd import _native
+    return _native.context()
+
+
+def test_g1_fixtures_through_profile_api(golden_counts):
+    from kpal_amd import klib
+    for case in golden_counts['G1']:
+        p = klib.Profile.from_sequences(case['sequences'], case['k'])
+        assert p.counts.dtype == np.int64 and p.length == case['k']
+        np.testing.assert_array_equal(p.counts, dense(case['counts']))
+        assert p.total == case['total'] and p.non_zero == case['non_zero']
+        fasta = ''.join('>r%d\n%s\n' % (i, s) for i, s in enumerate(case['sequences']))
+        pf = klib.Profile.from_fasta(io.StringIO(fasta), case['k'])
+        np.testing.assert_array_equal(pf.counts, p.counts)
+
+
+def test_g2_randomized_all_strategies(golden_counts, ctx):
+    for case in golden_counts['G2']:
+        want = dense(case['counts'])
+        flat = '\n'.join(case['sequences']).encode('latin-1', 'replace')
+        for strat in strategies(case['k']):
+            got = ctx.count_bytes(case['k'], flat, strat)
+            np.testing.assert_array_equal(got, want, err_msg='k=%d %s %r' % (case['k'], strat, case['sequences']))
+
+
+def test_empty_and_short_inputs(ctx):
+    from kpal_amd import klib
+    for seqs in ([], [''], ['AC', 'G'], ['N' * 40]):
+        p = klib.Profile.from_sequences(seqs, 3)
+        assert p.counts.shape == (64,) and p.total == 0
+    for k in (1, 7, 8, 12, 13):
+        for strat in strategies(k):
+            assert ctx.count_bytes(k, b'', strat).sum() == 0
+            assert ctx.count_bytes(k, b'ACGT'[:min(k - 1, 4)] or b'N', strat).sum() == 0
+
+
+def test_k_equals_length_and_every_k(ctx):
+    seq = b'GATTACAGATTACACATGCATGCAAACCCGGGTTT'
+    for k in range(1, 16):
+        want_total = max(0, len(seq) - k + 1)
+        if k <= 13:
+            want = oracle.count_flat(seq, k)
+            for strat in strategies(k):
+                np.testing.assert_array_equal(ctx.count_bytes(k, seq, strat), want, err_msg='k=%d %s' % (k, strat))
+        elif k <= 15:   # big tables: check total and the positions of the hits only
+            got = ctx.count_bytes(k, seq)
+            assert got.sum() == want_total
+            idx = np.nonzero(got)[0]
+            ref = sorted(set(_enc(seq[i:i + k]) for i in range(want_total)))
+            assert list(idx) == ref
+    # k == len(seq) and k == len(seq) - 1 (tests/test_klib.py:72-81)
+    s8 = b'GTACATGA'
+    for k in (8, 7):
+        np.testing.assert_array_equal(ctx.count_bytes(k, s8), oracle.count_flat(s8, k))
+
+
+def _enc(b):
+    v = 0
+    for c in b:
+        v = (v << 2) | 'ACGT'.index(chr(c))
+    return v
+
+
+def test_g3_config1(golden_synth, ctx):
+    g = golden_synth['config1']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], g['read_len'])
+    for strat in strategies(g['k']):
+        c = ctx.count_bytes(g['k'], buf, strat)
+        assert c.sum() == g['total'] == 1420000
+        assert sha(c) == g['sha256'], strat
+    from kpal_amd import klib
+    p = klib.Profile.from_sequences((bytes(r) for r in buf.reshape(-1, 151)[:, :150]), g['k'])
+    assert sha(p.counts) == g['sha256'] and p.non_zero == g['non_zero']
+
+
+def test_g3_noisy_and_long(golden_synth, ctx):
+    g = golden_synth['noisy']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], 150, noisy=True)
+    for case in g['cases']:
+        for strat in strategies(case['k']):
+            c = ctx.count_bytes(case['k'], buf, strat)
+            assert (int(c.sum()), int(np.count_nonzero(c)), sha(c)) == (case['total'], case['non_zero'], case['sha256']), (case['k'], strat)
+    g = golden_synth['long']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    for case in g['cases']:
+        for strat in strategies(case['k']):
+            c = ctx.count_bytes(case['k'], seq, strat)
+            assert (int(c.sum()), sha(c)) == (case['total'], case['sha256']), (case['k'], strat)
+
+
+def test_generator_matches_oracle(ctx):
+    for noisy in (False, True):
+        n = 3001
+        want = oracle.synth_reads(5, 12345, n, 150, noisy=noisy)
+        d = ctx.alloc(want.size)
+        try:
+            ctx.synth_reads_device(5, 12345, n, 150, d, noisy=noisy)
+            got = np.empty_like(want)
+            ctx.d2h(got, d)
+        finally:
+            ctx.free(d)
+        np.testing.assert_array_equal(got, want)
+    # odd read length, single read
+    want = oracle.synth_reads(9, 7, 1, 37)
+    d = ctx.alloc(64)
+    ctx.synth_reads_device(9, 7, 1, 37, d)
+    got = np.empty_like(want)
+    ctx.d2h(got, d)
+    ctx.free(d)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_unaligned_device_buffers_and_multiple_feeds(ctx):
+    buf = oracle.synth_reads(31, 0, 700, 150, noisy=True)
+    d = ctx.alloc(buf.size + 64)
+    try:
+        for off in (0, 1, 7, 15, 16, 33):
+            ctx.h2d(d + off, buf)
+            for k in (4, 10, 13):
+                for strat in strategies(k):
+                    ctx.count_begin(k, strat)
+                    ctx.count_feed_device(d + off, buf.size)
+                    got = ctx.count_finish()
+                    np.testing.assert_array_equal(got, oracle.count_flat(buf, k), err_msg='off=%d k=%d %s' % (off, k, strat))
+        # several feeds: windows never span feeds, even when a feed ends mid-read
+        ctx.h2d(d, buf)
+        cuts = [0, 1000, 1001, 5000, 77777, buf.size]
+        for k in (6, 11):
+            ctx.count_begin(k)
+            want = np.zeros(4 ** k, dtype=np.int64)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                ctx.count_feed_device(d + a, b - a)
+                want += oracle.count_flat(buf[a:b], k)
+            np.testing.assert_array_equal(ctx.count_finish(), want)
+    finally:
+        ctx.free(d)
+
+
+def test_host_feed_larger_than_staging(ctx):
+    # 160 MB of noisy reads: crosses the 64 MiB pinned staging pieces (halo handling) and
+    # several partition batches
+    n = 1060000
+    buf = oracle.synth_reads(41, 0, n, 150, noisy=True)
+    assert buf.size > 2 * (64 << 20)
+    for k in (5, 12):
+        want = oracle.count_flat(buf, k, threads=8)
+        got = ctx.count_bytes(k, buf)
+        np.testing.assert_array_equal(got, want)
+    # one long record with no separators at all across staging seams
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    np.testing.assert_array_equal(ctx.count_bytes(12, seq), oracle.count_flat(seq, 12, threads=8))
+
+
+def test_small_partition_batches():
+    """Partition path with 1 MiB batches: halo across batch seams inside one device feed."""
+    from kpal_amd import _native
+    os.environ['KPAL_BATCH_BYTES'] = str(1 << 20)
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_BATCH_BYTES']
+    buf = oracle.synth_reads(43, 0, 40000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    for k in (8, 12):
+        np.testing.assert_array_equal(c2.count_bytes(k, buf, 'partition'), oracle.count_flat(buf, k, threads=4))
+        np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition'), oracle.count_flat(seq, k, threads=4))
+    c2.close()
+
+
+def test_skewed_input_homopolymer(ctx):
+    # every k-mer identical: one bucket, one bin (worst-case contention / bucket skew)
+    buf = np.full(3_000_000, ord('A'), dtype=np.uint8)
+    for k in (3, 12, 14):
+        for strat in strategies(k):
+            c = ctx.count_bytes(k, buf, strat)
+            assert c[0] == buf.size - k + 1 and c.sum() == c[0], (k, strat)
+    buf = np.frombuffer(b'ACGT' * 500000, dtype=np.uint8)
+    for k in (9, 12):
+        c = ctx.count_bytes(k, buf)
+        np.testing.assert_array_equal(c, oracle.count_flat(buf, k))
+
+
+@pytest.mark.parametrize('k,n_reads', [(12, 100_000_000), (9, 20_000_000)])
+def test_full_size_properties_k12(ctx, k, n_reads):
+    """BASELINE config 2 at full size (100 M x 150 bp, k = 12): exact total, linearity over
+    shards, and agreement with the threaded oracle on a 2 M-read prefix."""
+    from kpal_amd import dist
+    nbytes = n_reads * 151
+    d = ctx.alloc(nbytes)
+    try:
+        ctx.synth_reads_device(2, 0, n_reads, 150, d)
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, nbytes)
+        full = ctx.count_finish()
+        assert full.sum() == n_reads * (150 - k + 1)
+        assert full.min() >= 0
+        # linearity: counting two shards separately and adding gives the same table
+        first, n0 = dist.shard_range(n_reads, 0, 2)
+        parts = []
+        for r in range(2):
+            f, n = dist.shard_range(n_reads, r, 2)
+            ctx.count_begin(k)
+            ctx.count_feed_device(d + f * 151, n * 151)
+            parts.append(ctx.count_finish())
+        np.testing.assert_array_equal(parts[0] + parts[1], full)
+        # alternative strategy agrees on a 10 M-read prefix
+        ctx.count_begin(k, 'global_atomic')
+        ctx.count_feed_device(d, 10_000_000 * 151)
+        a = ctx.count_finish()
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, 10_000_000 * 151)
+        np.testing.assert_array_equal(ctx.count_finish(), a)
+        # oracle on a 2 M-read prefix
+        pre = np.empty(2_000_000 * 151, dtype=np.uint8)
+        ctx.d2h(pre, d)
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, pre.size)
+        np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(pre, k, threads=8))
+        # balance on the device table doubles the total (klib.py:285-298)
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, nbytes)
+        ctx.count_finish(to_host=False)
+        ptr, bins = ctx.count_table()
+        ctx.balance_device(k, ptr)
+        bal = np.empty(bins, dtype=np.int64)
+        ctx.d2h(bal, ptr)
+        assert bal.sum() == 2 * full.sum()
+        np.testing.assert_array_equal(bal[:4096], oracle.balance(full, k)[:4096])
+    finally:
+        ctx.free(d)
+
+
+def test_full_size_k15(ctx):
+    """BASELINE config 4 (k = 15, 8 GiB table) on 20 M reads: exact total and linearity."""
+    k, n_reads = 15, 20_000_000
+    nbytes = n_reads * 151
+    d = ctx.alloc(nbytes)
+    try:
+        ctx.synth_reads_device(4, 0, n_reads, 150, d)
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, nbytes)
+        full = ctx.count_finish()
+        assert full.sum() == n_reads * (150 - k + 1)
+        half = 10_000_000
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, half * 151)
+        a = ctx.count_finish()
+        ctx.count_begin(k)
+        ctx.count_feed_device(d + half * 151, half * 151)
+        a += ctx.count_finish()
+        assert np.array_equal(a, full)
+    finally:
+        ctx.free(d)

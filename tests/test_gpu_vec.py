@@ -1,0 +1,248 @@
+"""Parity of the HIP balance / split / distance kernels (through the C-ABI and the
+kpal-compatible Python API) with the oracle and the reference goldens.
+Integers bit-exact; fp64 multiset sums within 1e-9 relative (north_star tolerance; observed
+~1e-15).  Run on the GPU box: pytest -m gpu."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from kpal_amd import _native
+    return _native.context()
+
+
+def close(a, b, rtol=RTOL):
+    if np.isnan(b):
+        return np.isnan(a)
+    if np.isinf(b):
+        return a == b
+    return abs(a - b) <= rtol * abs(b) + 1e-300
+
+
+def test_g5_rc_balance_split(golden_scalars, golden_vectors):
+    from kpal_amd import klib
+    g = golden_scalars['G5']
+    for rec in g['rc']:
+        p = klib.Profile(np.zeros(4, dtype=np.int64))
+        p.length = rec['k']
+        assert [p.reverse_complement(x) for x in rec['x']] == rec['rc']
+    for rec in g['balance_split']:
+        name, k = rec['name'], rec['k']
+        v = golden_vectors['g5_%s_in' % name]
+        p = klib.Profile(v.copy())
+        f, r = p.split()
+        np.testing.assert_array_equal(f, golden_vectors['g5_%s_fwd' % name])
+        np.testing.assert_array_equal(r, golden_vectors['g5_%s_rev' % name])
+        np.testing.assert_array_equal(p.counts, v)   # split does not modify
+        p.balance()
+        np.testing.assert_array_equal(p.counts, golden_vectors['g5_%s_bal' % name])
+
+
+def test_balance_split_random_vs_oracle(ctx):
+    rs = np.random.RandomState(3)
+    for k in (1, 2, 3, 5, 6, 7, 9, 10, 11):
+        v = rs.randint(0, 1 << 40, size=4 ** k).astype(np.int64)
+        v[rs.rand(4 ** k) < 0.4] = 0
+        b = v.copy()
+        ctx.balance_inplace(b, k)
+        np.testing.assert_array_equal(b, oracle.balance(v, k))
+        f, r = ctx.split(v, k)
+        fo, ro = oracle.split(v, k)
+        np.testing.assert_array_equal(f, fo)
+        np.testing.assert_array_equal(r, ro)
+        for pw in (0, 1):
+            assert close(ctx.strand_balance(v, k, pw), oracle.strand_balance(v, k, ('prod', 'sum')[pw]))
+
+
+def test_g6_known_answers(golden_scalars, golden_counts):
+    from kpal_amd import klib, kdistlib, metrics
+    g = golden_scalars['G6']
+    pa = klib.Profile.from_sequences(g['toy_k2']['a'], 2)
+    pb = klib.Profile.from_sequences(g['toy_k2']['b'], 2)
+    assert kdistlib.ProfileDistance().distance(pa, pb) == 0.0625      # tests/test_kdistlib.py:104-112
+    fx = {c['fixture']: c['sequences'] for c in golden_counts['G1']}
+    left = klib.Profile.from_sequences(fx['LENGTH_60'], 8, 'left')
+    right = klib.Profile.from_sequences(fx['LENGTH_60_MORE'], 8, 'right')
+    keep_l, keep_r = left.counts.copy(), right.counts.copy()
+    o = g['left_right_k8']
+    P = metrics.pairwise
+    PD = kdistlib.ProfileDistance
+    assert close(PD().distance(left, right), o['prod'])
+    np.testing.assert_almost_equal(PD().distance(left, right), 0.4626209322)   # tests/test_kdistlib.py:114-122
+    assert close(PD(pairwise=P['sum']).distance(left, right), o['sum'])
+    assert close(PD(do_balance=True).distance(left, right), o['balance_prod'])
+    assert close(PD(do_balance=True, pairwise=P['sum']).distance(left, right), o['balance_sum'])
+    assert PD(distance_function=metrics.euclidean).distance(left, right) == o['euclidean']
+    assert PD(do_balance=True, distance_function=metrics.euclidean).distance(left, right) == o['balance_euclidean']
+    assert close(PD(distance_function=metrics.cosine_similarity).distance(left, right), o['cosine'])
+    f, r = left.split()
+    assert close(metrics.multiset(f, r, P['prod']), o['showbalance_left'])
+    assert close(_ctx().strand_balance(left.counts, 8, 0), o['showbalance_left'])
+    assert close(_ctx().strand_balance(left.counts, 8, 1), o['showbalance_left_sum'])
+    # option branches that keep the reference's NumPy steps but end in the HIP reduction
+    assert close(PD(do_smooth=True).distance(left, right), o['smooth_min'])
+    assert close(PD(do_smooth=True, summary=np.mean).distance(left, right), o['smooth_avg'])
+    assert close(PD(do_positive=True).distance(left, right), o['positive'])
+    assert close(PD(do_scale=True).distance(left, right), o['scale'])
+    assert close(PD(do_scale=True, down=True).distance(left, right), o['scale_down'])
+    # inputs unmodified (tests/test_kdistlib.py:124-135)
+    np.testing.assert_array_equal(left.counts, keep_l)
+    np.testing.assert_array_equal(right.counts, keep_r)
+    # custom pairwise callable -> reference formulation, same value as the built-in
+    custom = lambda x, y: abs(x - y) / ((x + 1) * (y + 1))   # noqa: E731
+    assert close(PD(pairwise=custom).distance(left, right), o['prod'])
+
+
+def _ctx():
+    from kpal_amd import _native
+    return _native.context()
+
+
+def test_g7_metrics(golden_scalars, golden_vectors, ctx):
+    from kpal_amd import metrics
+    for rec in golden_scalars['G7']:
+        l = golden_vectors['g7_%s_l' % rec['name']]
+        r = golden_vectors['g7_%s_r' % rec['name']]
+        for pw in ('prod', 'sum'):
+            with np.errstate(all='ignore'):
+                d = metrics.multiset(l, r, metrics.pairwise[pw])
+            assert close(d, rec[pw]), (rec['name'], pw, d, rec[pw])
+            if l.dtype.kind == 'i':
+                _, m = ctx.pair_distance(l, r, ('prod', 'sum').index(pw), return_aux=True)
+                assert m == rec['m']
+        if 'euclidean' in rec:
+            d, dot = ctx.pair_distance(l, r, 2, return_aux=True)
+            assert dot == rec['dot']
+            assert d == rec['euclidean'] or (np.isnan(d) and np.isnan(rec['euclidean']))
+            e = metrics.euclidean(l, r)
+            assert e == rec['euclidean'] or (np.isnan(e) and np.isnan(rec['euclidean']))
+
+
+def test_pair_distance_large_vs_oracle(ctx):
+    rs = np.random.RandomState(11)
+    for k, lam in ((9, 830), (10, 0.8), (11, 16.6)):
+        n = 4 ** k
+        l = rs.poisson(lam, n).astype(np.int64)
+        r = rs.poisson(lam, n).astype(np.int64)
+        for metric in ('prod', 'sum', 'euclidean'):
+            for bal in (False, True):
+                got = ctx.pair_distance(l, r, ('prod', 'sum', 'euclidean').index(metric), do_balance=bal, k=k)
+                want = oracle.distance(l, r, k, do_balance=bal, metric=metric)
+                if metric == 'euclidean':
+                    assert got == want
+                else:
+                    assert close(got, want), (k, metric, bal, got, want)
+    # odd length vector (not a power of 4) through the raw ABI
+    l = rs.poisson(3, 1001).astype(np.int64)
+    r = rs.poisson(3, 1001).astype(np.int64)
+    assert close(ctx.pair_distance(l, r, 0), oracle.multiset(l, r, 'prod'))
+    assert ctx.pair_distance(l, r, 2) == oracle.euclidean(l, r)
+
+
+def test_g8_matrix_text(golden_scalars):
+    from kpal_amd import klib, kdistlib, metrics
+    g = golden_scalars['G8']
+    profs = [klib.Profile.from_sequences(s, g['k'], n) for s, n in zip(g['sets'], g['names'])]
+    for case in g['cases']:
+        if case['pairwise'] == 'euclidean':
+            dist = kdistlib.ProfileDistance(distance_function=metrics.euclidean)
+        else:
+            dist = kdistlib.ProfileDistance(do_balance=case['do_balance'], pairwise=metrics.pairwise[case['pairwise']])
+        out = io.StringIO()
+        kdistlib.distance_matrix(profs[:case['count']], out, case['precision'], dist)
+        assert out.getvalue() == case['text'], case
+    # reference test expectations (tests/test_kdistlib.py:38-74)
+    out = io.StringIO()
+    kdistlib.distance_matrix(profs[:1], out, 2, kdistlib.ProfileDistance())
+    assert out.getvalue().strip().split('\n') == ['1', 'a']
+    out = io.StringIO()
+    kdistlib.distance_matrix(profs[:3], out, 2, kdistlib.ProfileDistance())
+    assert out.getvalue().strip().split('\n') == ['3', 'a', 'b', 'c', '0.46', '0.00 0.46']
+
+
+def test_matrix_vs_pairs_and_oracle(ctx):
+    rs = np.random.RandomState(13)
+    for k, P in ((6, 5), (8, 7), (9, 13), (7, 64)):
+        profs = [rs.poisson(rs.choice([0.8, 16.6, 200]), 4 ** k).astype(np.int64) for _ in range(P)]
+        for metric in ('prod', 'sum', 'euclidean'):
+            for bal in (False, True):
+                got = ctx.distance_matrix(profs, k, ('prod', 'sum', 'euclidean').index(metric), do_balance=bal)
+                if P <= 13:
+                    want = oracle.distance_matrix_values(profs, k, bal, metric)
+                else:
+                    want = np.array([ctx.pair_distance(profs[i], profs[j], ('prod', 'sum', 'euclidean').index(metric),
+                                                       do_balance=bal, k=k) for i in range(1, P) for j in range(i)])
+                assert got.shape == want.shape
+                if metric == 'euclidean':
+                    np.testing.assert_array_equal(got, want)
+                else:
+                    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+
+
+def test_g4_tutorial_end_to_end(golden_scalars, tutorial_dir):
+    """doc/tutorial.rst:44-144 through the drop-in API: count 8 FASTA files (60-column wrapped
+    records), merge, distance, matrix, showbalance."""
+    from kpal_amd import klib, kdistlib, metrics
+    g = golden_scalars['G4']
+    prof = {}
+    for fname, rec in g['files'].items():
+        if not fname.endswith('.fa'):
+            continue
+        with open(os.path.join(tutorial_dir, fname)) as fh:
+            p = klib.Profile.from_fasta(fh, 8, name=fname[:-3])
+        assert (int(p.total), int(p.non_zero)) == (rec['total'], rec['non_zero'])
+        prof[p.name] = p
+    d = kdistlib.ProfileDistance()
+    assert close(d.distance(prof['c_1'], prof['c_2']), g['distance_c1_c2'])
+    merged = []
+    for s in 'abcd':
+        m = prof[s + '_1'].copy()
+        m.merge(prof[s + '_2'])
+        m.name = s
+        assert (int(m.total), int(m.non_zero)) == (g['files'][s + '_merged']['total'], g['files'][s + '_merged']['non_zero'])
+        merged.append(m)
+    out = io.StringIO()
+    kdistlib.distance_matrix(merged, out, 3, d)
+    assert out.getvalue() == g['matrix_abcd_p3']
+    assert close(kdistlib.ProfileDistance(do_balance=True).distance(merged[0], merged[1]), g['distance_balanced_a_b'])
+    f, r = merged[0].split()
+    assert close(metrics.multiset(f, r, metrics.pairwise['prod']), g['showbalance_a'])
+
+
+def test_from_fasta_by_record_and_names():
+    from kpal_amd import klib
+    fasta = '>one desc\nACGTAC\nGT\n>two\nNNNN\n>\nACGT\n'
+    ps = list(klib.Profile.from_fasta_by_record(io.StringIO(fasta), 2, prefix='x'))
+    assert [p.name for p in ps] == ['x_one', 'x_two', 'x_3']
+    np.testing.assert_array_equal(ps[0].counts, oracle.from_sequences(['ACGTACGT'], 2))
+    assert ps[1].total == 0
+    with pytest.raises(ValueError):
+        klib.Profile(np.zeros(16, dtype=np.int64), 'a/b')
+    with pytest.raises(ValueError):
+        klib.Profile.from_sequences(['ACGT'], 0)
+
+
+def test_config5_matrix_k12_subset(ctx):
+    """BASELINE config 5 shape at k = 12 on an 8-profile subset: each profile = counts of
+    100 000 synthetic reads (sparse variant) -- matrix vs per-pair oracle, 1e-9 relative."""
+    k, P = 12, 8
+    profs = []
+    for p in range(P):
+        buf = oracle.synth_reads(100 + p, 0, 100000, 150)
+        profs.append(ctx.count_bytes(k, buf))
+    got = ctx.distance_matrix(profs, k, 0)
+    want = oracle.distance_matrix_values(profs, k, False, 'prod')
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    got = ctx.distance_matrix(profs[:3], k, 0, do_balance=True)
+    want = oracle.distance_matrix_values(profs[:3], k, True, 'prod')
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
