@@ -18,11 +18,12 @@ namespace kpal {
 
 constexpr int kPartBits = 9;
 constexpr int kNumBuckets = 1 << kPartBits;  // 512
-constexpr int kScatterThreads = 512;         // 8 waves
+constexpr int kScatterThreads = 512;         // 8 waves; two workgroups per CU (LDS 70 KiB each)
 constexpr int kScatterWaves = kScatterThreads / 64;
-constexpr int kScatterSteps = 4;             // wave-steps per wave per sub-tile
-constexpr int kTileChunks = kScatterWaves * kScatterSteps * 64;  // 2048 chunks = 32 KiB per sub-tile
-constexpr int kTileKeys = kTileChunks * 16;                      // <= 32768 k-mers per sub-tile
+constexpr int kScatterSteps = 3;             // wave-steps per wave per sub-tile
+constexpr int kTileChunks = kScatterWaves * kScatterSteps * 64;  // 1536 chunks = 24 KiB per sub-tile
+constexpr int kBucketsPerWave = (kNumBuckets + kScatterWaves - 1) / kScatterWaves;  // 43: copy-out share of a wave
+constexpr int kSlotCap = 64;  // LDS staging slots per bucket per sub-tile (mean fill 44 for 150 bp reads)
 
 // ------------------------------------------------------------------------------------------
 // Strategy 1: global atomics.  Each wave walks `steps_per_wave` consecutive 1-KiB steps.
@@ -41,7 +42,8 @@ __global__ __launch_bounds__(256) void count_global_atomic_kernel(Span s, uint64
     for (uint64_t st = step0; st < step1; ++st) {
         uint64_t window;
         uint32_t mask;
-        wave_step<K>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+        if (interior_range(s, st * 64, st * 64 + 64)) wave_step<K, false>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+        else wave_step<K, true>(s, (int64_t)(st * 64 + lane), carry, window, mask);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (mask & (1u << (15 - j))) atomicAdd(&table[kmer_at<K>(window, j)], 1ULL);
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(512) void count_lds_direct_kernel(Span s, uint64_t 
         for (uint64_t st = step0; st < step1; ++st) {
             uint64_t window;
             uint32_t mask;
-            wave_step<K>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+            if (interior_range(s, st * 64, st * 64 + 64)) wave_step<K, false>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+            else wave_step<K, true>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+            // branch-free: a k-mer that must not be counted adds 0 to whatever bin its bits name
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (mask & (1u << (15 - j))) atomicAdd(&h[kmer_at<K>(window, j) * R + rep], 1u);
-            }
+            for (int j = 0; j < 16; ++j) atomicAdd(&h[kmer_at<K>(window, j) * R + rep], (mask >> (15 - j)) & 1u);
         }
     }
     __syncthreads();
@@ -98,8 +100,11 @@ __global__ __launch_bounds__(512) void count_lds_direct_kernel(Span s, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// Strategy 3: partition.  Block `blk` of G owns the chunk range [blk*chunks_per_block, ...),
-// a whole number of sub-tiles; within a sub-tile wave w owns kScatterSteps consecutive steps.
+// Strategy 3: partition.  Block `blk` of G owns 8 * steps_per_wave consecutive wave-steps; wave w
+// of the block streams the contiguous sub-range [(8 blk + w) S, (8 blk + w + 1) S) of steps, so
+// its left-neighbour chunk is carried in registers from step to step and never re-encoded.  The
+// count (A1) and scatter (A3) kernels use the same mapping, hence agree on every per-(bucket,
+// block) count.
 // ------------------------------------------------------------------------------------------
 template <int K>
 struct PartCfg {
@@ -107,165 +112,232 @@ struct PartCfg {
     static constexpr uint32_t kKeyMask = (1u << kKeyBits) - 1u;
 };
 
-// Visit every countable k-mer of one sub-tile held in registers.
-template <int K, typename F>
-__device__ __forceinline__ void for_each_kmer(const uint64_t (&window)[kScatterSteps],
-                                              const uint32_t (&mask)[kScatterSteps], F f)
-{
-#pragma unroll
-    for (int st = 0; st < kScatterSteps; ++st) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (mask[st] & (1u << (15 - j))) f(kmer_at<K>(window[st], j));
-        }
-    }
-}
-
+// One wave-step at absolute step index `step` (interior fast path chosen per wave).
 template <int K>
-__device__ __forceinline__ void load_subtile(const Span &s, uint64_t tile_chunk0,
-                                             uint64_t (&window)[kScatterSteps], uint32_t (&mask)[kScatterSteps])
+__device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &carry, uint64_t &window, uint32_t &mask)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint64_t c0 = tile_chunk0 + (uint64_t)wave * kScatterSteps * 64;
-    Chunk carry = load_chunk(s, (int64_t)c0 - 1);
-#pragma unroll
-    for (int st = 0; st < kScatterSteps; ++st)
-        wave_step<K>(s, (int64_t)(c0 + st * 64 + lane), carry, window[st], mask[st]);
+    if (interior_range(s, step * 64, step * 64 + 64)) wave_step<K, false>(s, (int64_t)(step * 64 + lane), carry, window, mask);
+    else wave_step<K, true>(s, (int64_t)(step * 64 + lane), carry, window, mask);
 }
 
 // A1: per-(bucket, block) key counts.  cntmat is bucket-major: cntmat[b * G + blk].
+// The 512 counters are kept in 32 bank-interleaved replicas (replica = lane % 32 lives in LDS
+// bank lane % 32), so a wave's 64 ds_add_u32 never conflict; a k-mer that must not be counted
+// adds 0 (branch-free).
 template <int K>
-__global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uint64_t tiles_per_block,
+__global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uint64_t steps_per_wave,
                                                                      uint32_t *__restrict__ cntmat)
 {
-    __shared__ uint32_t cnt[kNumBuckets];
-    for (int i = threadIdx.x; i < kNumBuckets; i += blockDim.x) cnt[i] = 0;
+    __shared__ uint32_t cnt[kNumBuckets * 32];  // 64 KiB
+    for (int i = threadIdx.x; i < kNumBuckets * 32; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
-    for (uint64_t t = 0; t < tiles_per_block; ++t) {
-        const uint64_t chunk0 = (tile0 + t) * kTileChunks;
-        if (chunk0 >= s.nchunks) break;
-        uint64_t window[kScatterSteps];
-        uint32_t mask[kScatterSteps];
-        load_subtile<K>(s, chunk0, window, mask);
-        for_each_kmer<K>(window, mask, [&](uint32_t kmer) { atomicAdd(&cnt[kmer >> PartCfg<K>::kKeyBits], 1u); });
+    const uint32_t rep = threadIdx.x & 31;
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint64_t step0 = ((uint64_t)blockIdx.x * kScatterWaves + (threadIdx.x >> 6)) * steps_per_wave;
+    if (step0 < total_steps) {
+        const uint64_t step1 = min(step0 + steps_per_wave, total_steps);
+        Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
+        for (uint64_t st = step0; st < step1; ++st) {
+            uint64_t window;
+            uint32_t mask;
+            part_step<K>(s, st, carry, window, mask);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                atomicAdd(&cnt[(kmer_at<K>(window, j) >> PartCfg<K>::kKeyBits) * 32 + rep], (mask >> (15 - j)) & 1u);
+        }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x)
-        cntmat[(uint64_t)b * gridDim.x + blockIdx.x] = cnt[b];
+    for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) v += cnt[b * 32 + ((r + b) & 31)];
+        cntmat[(uint64_t)b * gridDim.x + blockIdx.x] = v;
+    }
 }
 
-// A2: exclusive scan of the M = 512*G counts (flat, bucket-major) into 64-bit offsets; also
-// bucket_start[b] (b = 0..512, last = total).  Single workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void part_scan_kernel(const uint32_t *__restrict__ cntmat, uint32_t G,
-                                                         uint64_t *__restrict__ offs,
-                                                         uint64_t *__restrict__ bucket_start)
+// A2a: one workgroup per bucket: exclusive scan of that bucket's G per-block counts into
+// offs32 (position of each block's keys inside the bucket) and the bucket total.
+__global__ __launch_bounds__(256) void part_rowscan_kernel(const uint32_t *__restrict__ cntmat, uint32_t G,
+                                                           uint32_t *__restrict__ offs32,
+                                                           uint64_t *__restrict__ bucket_total)
 {
-    __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t wave_base[17];
-    const uint64_t M = (uint64_t)kNumBuckets * G;
-    const uint64_t per = (M + 1023) / 1024;
-    const uint64_t i0 = min((uint64_t)threadIdx.x * per, M);
-    const uint64_t i1 = min(i0 + per, M);
-    uint64_t sum = 0;
-    for (uint64_t i = i0; i < i1; ++i) sum += cntmat[i];
-    // inclusive scan of `sum` across the workgroup
+    __shared__ uint32_t wsum[4];
+    const uint32_t *row = cntmat + (uint64_t)blockIdx.x * G;
+    uint32_t *orow = offs32 + (uint64_t)blockIdx.x * G;
+    const uint32_t per = (G + 255) / 256;
+    const uint32_t i0 = min(threadIdx.x * per, G), i1 = min(i0 + per, G);
+    uint32_t sum = 0;
+    for (uint32_t i = i0; i < i1; ++i) sum += row[i];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t incl = sum;
+    uint32_t incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        uint64_t o = __shfl_up(incl, d);
+        const uint32_t o = __shfl_up(incl, d);
         if (lane >= d) incl += o;
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int w = 0; w < 16; ++w) {
-            wave_base[w] = run;
-            run += wave_tot[w];
-        }
-        wave_base[16] = run;
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) base += (w < wave) ? wsum[w] : 0u;
+    uint32_t run = base + incl - sum;
+    for (uint32_t i = i0; i < i1; ++i) {
+        orow[i] = run;
+        run += row[i];
     }
-    __syncthreads();
-    uint64_t run = wave_base[wave] + incl - sum;
-    for (uint64_t i = i0; i < i1; ++i) {
-        offs[i] = run;
-        if (i % G == 0) bucket_start[i / G] = run;
-        run += cntmat[i];
-    }
-    if (threadIdx.x == 0) bucket_start[kNumBuckets] = wave_base[16];
+    if (threadIdx.x == 255) bucket_total[blockIdx.x] = (uint64_t)run;  // a launch holds < 2^32 keys
 }
 
-// A3: scatter.  Per sub-tile: count buckets in LDS, scan, place 16-bit keys bucket-sorted in
-// LDS, then copy each bucket's run to its global cursor.  Output keys are bucket-major and
-// contiguous; order inside a bucket is irrelevant to the histogram.
-template <int K>
-__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t tiles_per_block,
-                                                                       const uint64_t *__restrict__ offs,
-                                                                       uint16_t *__restrict__ keys_out)
+// A2b: exclusive scan of the 512 bucket totals -> bucket_start[0..512].
+__global__ __launch_bounds__(kNumBuckets) void part_bucketscan_kernel(const uint64_t *__restrict__ bucket_total,
+                                                                      uint64_t *__restrict__ bucket_start)
 {
-    __shared__ uint16_t keys[kTileKeys];          // 64 KiB
-    __shared__ uint32_t cnt[kNumBuckets];
-    __shared__ uint32_t start[kNumBuckets];
+    __shared__ uint64_t wsum[kNumBuckets / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t v = bucket_total[threadIdx.x];
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t base = 0;
+#pragma unroll
+    for (int w = 0; w < kNumBuckets / 64; ++w) base += (w < wave) ? wsum[w] : 0ULL;
+    bucket_start[threadIdx.x] = base + incl - v;
+    if (threadIdx.x == kNumBuckets - 1) bucket_start[kNumBuckets] = base + incl;
+}
+
+// A3: scatter.  Every bucket has kSlotCap 16-bit staging slots in LDS.  A k-mer takes the next
+// slot of its bucket with one returning ds_add (an uncounted k-mer adds 0 and its store is
+// diverted to a dummy halfword): per step 16 atomics are in flight, then 16 ds_write_b16.  The
+// slot index is rotated by the bucket index so that buckets filling in lock-step hit different
+// banks.  Slots >= kSlotCap -- rare for unskewed input, the whole stream for a homopolymer -- are
+// written straight to their final global position after the step.  After the tile (3 steps per
+// wave), wave w copies the staged runs of buckets [64w, 64w+64) to the buckets' global cursors,
+// one masked 2-byte-per-lane store per bucket, and advances the cursors by the full slot
+// count.  Output keys are bucket-major and contiguous; order inside a bucket is irrelevant to
+// the histogram.
+// Diagnostic stamp (only in the STAMP build of the scatter kernel; never in the product launch).
+__device__ __forceinline__ unsigned long long phase_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int K, bool STAMP = false>
+__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_wave,
+                                                                       const uint32_t *__restrict__ offs32,
+                                                                       const uint64_t *__restrict__ bucket_start,
+                                                                       uint16_t *__restrict__ keys_out,
+                                                                       unsigned long long *__restrict__ dbg = nullptr)
+{
+    unsigned long long acc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    // byte layout: keys rows [512][64] u16 | dummy halfword (+pad) | pos[512] u32 | gcur[512] u64
+    constexpr uint32_t kKeysBytes = kNumBuckets * kSlotCap * 2;
+    constexpr uint32_t kDummyByte = kKeysBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kKeysBytes + 16];
     __shared__ uint32_t pos[kNumBuckets];
     __shared__ uint64_t gcur[kNumBuckets];
-    __shared__ uint32_t wsum[kScatterWaves];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int KB = PartCfg<K>::kKeyBits;
+    static_assert(kSlotCap == 64 && kBucketsPerWave <= 64, "copy-out: one lane per slot, one lane per owned bucket");
 
-    for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) gcur[b] = offs[(uint64_t)b * gridDim.x + blockIdx.x];
-    const uint64_t tile0 = (uint64_t)blockIdx.x * tiles_per_block;
-    for (uint64_t t = 0; t < tiles_per_block; ++t) {
-        const uint64_t chunk0 = (tile0 + t) * kTileChunks;
-        if (chunk0 >= s.nchunks) break;
-        cnt[threadIdx.x] = 0;  // blockDim.x == kNumBuckets == 512
-        __syncthreads();
+    for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) {
+        gcur[b] = bucket_start[b] + offs32[(uint64_t)b * gridDim.x + blockIdx.x];
+        pos[b] = 0;
+    }
+    __syncthreads();
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint64_t block_step0 = (uint64_t)blockIdx.x * kScatterWaves * steps_per_wave;
+    const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
+    Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
+    for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
+        if (block_step0 + t >= total_steps) break;  // block-uniform: wave 0 owns the lowest addresses
         uint64_t window[kScatterSteps];
         uint32_t mask[kScatterSteps];
-        load_subtile<K>(s, chunk0, window, mask);
-        for_each_kmer<K>(window, mask, [&](uint32_t kmer) { atomicAdd(&cnt[kmer >> KB], 1u); });
-        __syncthreads();
-        // exclusive scan of cnt[512] (one value per thread)
-        {
-            const uint32_t v = cnt[threadIdx.x];
-            uint32_t incl = v;
+        if constexpr (STAMP) t0 = phase_stamp();
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            uint32_t base = 0;
-#pragma unroll
-            for (int w = 0; w < kScatterWaves; ++w) base += (w < wave) ? wsum[w] : 0u;
-            const uint32_t ex = base + incl - v;
-            start[threadIdx.x] = ex;
-            pos[threadIdx.x] = ex;
-        }
-        __syncthreads();
-        for_each_kmer<K>(window, mask, [&](uint32_t kmer) {
-            const uint32_t slot = atomicAdd(&pos[kmer >> KB], 1u);
-            keys[slot] = (uint16_t)(kmer & PartCfg<K>::kKeyMask);
-        });
-        __syncthreads();
-        // copy-out: wave w owns buckets [64w, 64w+64); lane l holds bucket 64w+l's metadata
+        for (int st = 0; st < kScatterSteps; ++st) part_step<K>(s, step0 + t + st, carry, window[st], mask[st]);
+        if constexpr (STAMP) { asm volatile("" ::"v"(window[0]), "v"(window[kScatterSteps - 1])); t1 = phase_stamp(); acc[0] += t1 - t0; t0 = t1; }
         {
-            const int b = wave * 64 + lane;
-            const uint32_t my_n = cnt[b];
-            const uint32_t my_st = start[b];
-            const uint64_t my_g = gcur[b];
-            for (int i = 0; i < 64; ++i) {
-                const uint32_t n = __shfl(my_n, i);
-                const uint32_t st = __shfl(my_st, i);
-                const uint64_t g = __shfl(my_g, i);
-                for (uint32_t e = lane; e < n; e += 64) keys_out[g + e] = keys[st + e];
+#pragma unroll
+            for (int st = 0; st < kScatterSteps; ++st) {
+                const uint64_t w = window[st];
+                const uint32_t m = mask[st];
+                uint32_t slot[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t b4 = (kmer_at<K>(w, j) >> (KB - 2)) & 0x7FCu;  // 4 * bucket
+                    slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (m >> (15 - j)) & 1u);
+                }
+                uint32_t smax = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t kmer = kmer_at<K>(w, j);
+                    const uint32_t b4 = (kmer >> (KB - 2)) & 0x7FCu;
+                    const uint32_t x = slot[j] | (((~m >> (15 - j)) & 1u) << 6);    // >= 64: not counted, or row full
+                    const uint32_t at = ((2u * slot[j] + b4) & 126u) | (b4 << 5);      // byte offset of the rotated slot
+                    *(uint16_t *)(lds + (x < 64u ? at : kDummyByte)) = (uint16_t)(kmer & PartCfg<K>::kKeyMask);
+                    smax = max(smax, slot[j]);
+                }
+                if (smax >= (uint32_t)kSlotCap) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (((m >> (15 - j)) & 1u) && slot[j] >= (uint32_t)kSlotCap) {
+                            const uint32_t kmer = kmer_at<K>(w, j);
+                            keys_out[gcur[kmer >> KB] + slot[j]] = (uint16_t)(kmer & PartCfg<K>::kKeyMask);
+                        }
+                    }
+                }
             }
-            gcur[b] = my_g + my_n;
         }
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[1] += t1 - t0; t0 = t1; }
         __syncthreads();
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[2] += t1 - t0; t0 = t1; }
+        {
+            // wave w owns buckets [43w, 43w+43); lane l < 43 holds the slot count and cursor of bucket 43w+l
+            const int first = wave * kBucketsPerWave;
+            const int mine = first + lane;
+            const bool own = lane < kBucketsPerWave && mine < kNumBuckets;
+            const uint32_t my_n = own ? pos[mine] : 0u;
+            const uint64_t my_g = own ? gcur[mine] : 0ULL;
+            const uint32_t my_glo = (uint32_t)my_g, my_ghi = (uint32_t)(my_g >> 32);
+#pragma unroll 1
+            for (int i0 = 0; i0 < kBucketsPerWave; i0 += 8) {
+                uint16_t v[8];
+                // unconditional LDS reads first (8 in flight), predicated stores after
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t b = min((uint32_t)(first + i0 + u), (uint32_t)(kNumBuckets - 1));
+                    v[u] = *(const uint16_t *)(lds + b * 128u + ((2u * lane + 4u * b) & 126u));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t n = min((uint32_t)__builtin_amdgcn_readlane(my_n, i0 + u), (uint32_t)kSlotCap);
+                    const uint64_t g = ((uint64_t)__builtin_amdgcn_readlane(my_ghi, i0 + u) << 32) |
+                                       (uint64_t)__builtin_amdgcn_readlane(my_glo, i0 + u);
+                    if ((uint32_t)lane < n) (keys_out + g)[lane] = v[u];
+                }
+            }
+            if (own) {
+                gcur[mine] = my_g + my_n;
+                pos[mine] = 0;
+            }
+        }
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[3] += t1 - t0; t0 = t1; }
+        __syncthreads();
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[4] += t1 - t0; }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0)
+            for (int i = 0; i < 5; ++i) dbg[((uint64_t)blockIdx.x * kScatterWaves + wave) * 5 + i] = acc[i];
     }
 }
 
@@ -294,8 +366,7 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
     const uint64_t a1 = a0 + ((e1 - a0) & ~7ULL);
     const uint4 *kv = reinterpret_cast<const uint4 *>(keys + a0);
     const uint64_t nvec = (a1 - a0) >> 3;
-    for (uint64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-        const uint4 q = kv[v];
+    auto add8 = [&](const uint4 q) {
         atomicAdd(&hist[q.x & 0xFFFFu], 1u);
         atomicAdd(&hist[q.x >> 16], 1u);
         atomicAdd(&hist[q.y & 0xFFFFu], 1u);
@@ -304,7 +375,17 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
         atomicAdd(&hist[q.z >> 16], 1u);
         atomicAdd(&hist[q.w & 0xFFFFu], 1u);
         atomicAdd(&hist[q.w >> 16], 1u);
+    };
+    // four 16-byte loads in flight per lane (64 KiB per workgroup) to cover HBM latency
+    uint64_t v = threadIdx.x;
+    for (; v + 3 * (uint64_t)blockDim.x < nvec; v += 4 * (uint64_t)blockDim.x) {
+        const uint4 q0 = kv[v], q1 = kv[v + blockDim.x], q2 = kv[v + 2 * (uint64_t)blockDim.x], q3 = kv[v + 3 * (uint64_t)blockDim.x];
+        add8(q0);
+        add8(q1);
+        add8(q2);
+        add8(q3);
     }
+    for (; v < nvec; v += blockDim.x) add8(kv[v]);
     for (uint64_t e = a1 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&hist[keys[e]], 1u);
     __syncthreads();
     unsigned long long *dst = table + ((uint64_t)b << KB);

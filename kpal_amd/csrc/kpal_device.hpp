@@ -45,20 +45,20 @@ __host__ __device__ inline uint64_t revcomp(uint64_t x, int k)
 
 // 4 ASCII bytes -> 8 bits of codes (first byte most significant) + 4 bad flags (same order).
 // code = ((c >> 1) ^ (c >> 2)) & 3 maps A,C,G,T (either case) to 0,1,2,3 (kpal/klib.py:43-48);
-// a byte is in the alphabet iff re-synthesising the upper-case letter from its code gives the
-// byte back (case bit 0x20 ignored).
+// a byte is in the alphabet iff looking its code up in "ACGT" (one v_perm_b32 for the four
+// bytes) gives the byte back with the case bit 0x20 ignored.  ~17 VALU ops per dword.
 __device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
 {
     const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
-    const uint32_t b0 = t & 0x01010101u;
-    const uint32_t b1 = (t >> 1) & 0x01010101u;
-    const uint32_t an = b0 & b1;
-    const uint32_t expect = 0x40404040u | (an ^ 0x01010101u) | ((b0 ^ b1) << 1) | (b1 << 2) | (an << 4);
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t);
     const uint32_t x = (w & 0xDFDFDFDFu) ^ expect;
     const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 per non-matching byte
-    // byte 0 (lowest address) is the oldest base -> most significant digit
-    code8 = (((t << 6) | (t >> 4)) & 0xF0u) | (((t >> 14) | (t >> 24)) & 0x0Fu);
-    bad4 = ((nz >> 4) & 8u) | ((nz >> 13) & 4u) | ((nz >> 22) & 2u) | (nz >> 31);
+    // byte 0 (lowest address) is the oldest base -> most significant digit.  The 24-bit multiply
+    // gathers the codes of bytes 0..2 into bits 21:16 (fields never overlap, so no carries).
+    const uint32_t g = __umul24(t, 0x100401u);
+    code8 = ((g >> 14) & 0xFCu) | (t >> 24);
+    const uint32_t h = __umul24(nz >> 7, 0x040201u);  // flags of bytes 0..2 -> bits 18:16
+    bad4 = ((h >> 15) & 0xEu) | (nz >> 31);
 }
 
 struct Chunk {
@@ -150,25 +150,37 @@ __device__ __forceinline__ uint32_t emit_from_mask(const Span &s, int64_t c)
     return (1u << (16 - (uint32_t)(s.emit_from - p0))) - 1u;
 }
 
+// lane l <- lane l-1 across the whole wave (DPP wave_shr:1); lane 0 receives `lane0_value`.
+__device__ __forceinline__ uint32_t from_left_lane(uint32_t v, uint32_t lane0_value)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
 // One wave-step: returns this lane's 64-bit window (previous chunk's codes in the high word)
 // and the emit mask.  `carry` holds lane 63's chunk of the previous step (or the chunk left of
-// the wave's first chunk); it is updated for the next step.
-template <int K>
+// the wave's first chunk); it is updated for the next step.  EDGE = false is the interior fast
+// path: the 64 chunks and the halo chunk lie wholly inside the fed range and right of
+// emit_from, so no range logic is evaluated.
+template <int K, bool EDGE>
 __device__ __forceinline__ void wave_step(const Span &s, int64_t c, Chunk &carry, uint64_t &window,
                                           uint32_t &mask)
 {
-    const int lane = threadIdx.x & 63;
-    Chunk cur = load_chunk(s, c);
-    uint32_t pc = __shfl_up(cur.codes, 1);
-    uint32_t pb = __shfl_up(cur.bad, 1);
-    if (lane == 0) {
-        pc = carry.codes;
-        pb = carry.bad;
-    }
-    carry.codes = __shfl(cur.codes, 63);
-    carry.bad = __shfl(cur.bad, 63);
+    Chunk cur;
+    if constexpr (EDGE) cur = load_chunk(s, c);
+    else cur = encode16(s.base[c]);
+    const uint32_t pc = from_left_lane(cur.codes, carry.codes);
+    const uint32_t pb = from_left_lane(cur.bad, carry.bad);
+    carry.codes = __builtin_amdgcn_readlane(cur.codes, 63);
+    carry.bad = __builtin_amdgcn_readlane(cur.bad, 63);
     window = ((uint64_t)pc << 32) | cur.codes;
-    mask = emit_mask<K>(pb, cur.bad) & emit_from_mask(s, c);
+    mask = emit_mask<K>(pb, cur.bad);
+    if constexpr (EDGE) mask &= emit_from_mask(s, c);
+}
+
+// true iff chunks [c0 - 1, c1) are wholly inside [lo, hi) and every k-mer ending in [c0, c1) is emitted
+__device__ __forceinline__ bool interior_range(const Span &s, uint64_t c0, uint64_t c1)
+{
+    return c0 >= 1 && (c0 - 1) * 16 >= s.lo && c1 * 16 <= s.hi && s.emit_from <= c0 * 16;
 }
 
 // k-mer ending at byte j (0..15) of the lane's chunk.

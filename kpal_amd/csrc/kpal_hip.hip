@@ -407,27 +407,53 @@ static int launch_lds_direct(kpal_ctx *ctx, const Span &s)
 
 static int launch_partition(kpal_ctx *ctx, const Span &s)
 {
-    const uint64_t ntiles = (s.nchunks + kTileChunks - 1) / kTileChunks;
-    if (ntiles == 0) return KPAL_OK;
-    const uint64_t want_blocks = std::min<uint64_t>(ntiles, (uint64_t)ctx->num_cu * 4);
-    const uint64_t tpb = (ntiles + want_blocks - 1) / want_blocks;
-    const uint32_t G = (uint32_t)((ntiles + tpb - 1) / tpb);
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    // steps per wave: a multiple of the tile depth, sized for ~4 blocks per CU
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
+    uint64_t spw = (total_steps + want_blocks * kScatterWaves - 1) / (want_blocks * kScatterWaves);
+    spw = (spw + kScatterSteps - 1) / kScatterSteps * kScatterSteps;
+    const uint64_t tpb = spw;  // kernel argument: steps per wave
+    const uint32_t G = (uint32_t)((total_steps + spw * kScatterWaves - 1) / (spw * kScatterWaves));
     const uint64_t max_keys = s.nchunks * 16;
     CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
     CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
-    CHK(ensure(ctx, ctx->offs, (size_t)kNumBuckets * G * sizeof(uint64_t)));
-    CHK(ensure(ctx, ctx->bucket_start, (size_t)(kNumBuckets + 1) * sizeof(uint64_t)));
+    CHK(ensure(ctx, ctx->offs, (size_t)kNumBuckets * G * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->bucket_start, (size_t)(2 * kNumBuckets + 2) * sizeof(uint64_t)));
     uint32_t *cntmat = (uint32_t *)ctx->cntmat.p;
-    uint64_t *offs = (uint64_t *)ctx->offs.p;
+    uint32_t *offs = (uint32_t *)ctx->offs.p;
     uint64_t *bstart = (uint64_t *)ctx->bucket_start.p;
+    uint64_t *btotal = bstart + kNumBuckets + 1;
     uint16_t *keys = (uint16_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     const uint32_t slices = 4;
+    if (getenv("KPAL_OCC")) {  // diagnostic: residency of the partition kernels
+        int a = 0, b = 0, c = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)part_count_kernel<12>, kScatterThreads, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)part_scatter_kernel<12, false>, kScatterThreads, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, (const void *)part_hist_kernel<12>, 1024, 0);
+        fprintf(stderr, "[occ] blocks/CU: part_count %d, part_scatter %d, part_hist %d; G=%u spw=%llu\n", a, b, c, G, (unsigned long long)tpb);
+    }
     DISPATCH_K_8_12(ctx->k, {
         LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb, cntmat);
-        LAUNCH(ctx, "part_scan", part_scan_kernel, dim3(1), dim3(1024), (const uint32_t *)cntmat, G, offs, bstart);
+        LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
+        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal, bstart);
+        if (getenv("KPAL_STAMP")) {  // diagnostic build of the scatter kernel: per-phase s_memtime sums
+            unsigned long long *dbg = nullptr;
+            HIPCHK(hipMalloc(&dbg, (size_t)G * kScatterWaves * 5 * 8));
+            LAUNCH(ctx, "part_scatter_stamp", (part_scatter_kernel<K, true>), dim3(G), dim3(kScatterThreads), s, tpb,
+                   (const uint32_t *)offs, (const uint64_t *)bstart, keys, dbg);
+            std::vector<unsigned long long> h((size_t)G * kScatterWaves * 5);
+            HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(dbg));
+            double sum[5] = {0, 0, 0, 0, 0};
+            for (size_t i = 0; i < h.size(); ++i) sum[i % 5] += (double)h[i];
+            const double nw = (double)G * kScatterWaves;
+            fprintf(stderr, "[stamp] per-wave mean cycles: load+encode %.0f  place %.0f  barrier1 %.0f  copyout %.0f  barrier2 %.0f (steps/wave %llu)\n",
+                    sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, (unsigned long long)tpb);
+        } else
         LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb,
-               (const uint64_t *)offs, keys);
+               (const uint32_t *)offs, (const uint64_t *)bstart, keys, (unsigned long long *)nullptr);
         LAUNCH(ctx, "part_hist", (part_hist_kernel<K>), dim3(kNumBuckets * slices), dim3(1024),
                (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
     });
