@@ -16,6 +16,7 @@
  * Build: gcc -O2 -fPIC -shared -o libkpal_oracle.so kpal_oracle.c -lm   (see Makefile)
  */
 #include <math.h>
+#include <pthread.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -350,5 +351,78 @@ ORACLE_API int kpal_oracle_count_piece(const uint8_t *buf, size_t begin, size_t 
         run++;
         if (run >= (size_t)k && i >= begin) counts[binary] += 1;
     }
+    return 0;
+}
+
+/* All-cores variant of the count (baseline + at-scale oracle): T pthreads, each counts one
+ * piece of the stream into a private histogram (kpal_oracle_count_piece), then the T
+ * histograms are summed into `counts` in parallel over bin ranges.  Integer adds: the result
+ * is identical to the sequential scan. */
+typedef struct {
+    const uint8_t *buf;
+    size_t begin, end;
+    int k;
+    int64_t *hist;
+} count_job;
+
+static void *count_worker(void *arg)
+{
+    count_job *j = (count_job *)arg;
+    kpal_oracle_count_piece(j->buf, j->begin, j->end, j->k, j->hist);
+    return NULL;
+}
+
+typedef struct {
+    int64_t **hists;
+    int T;
+    size_t b0, b1;
+    int64_t *out;
+} merge_job;
+
+static void *merge_worker(void *arg)
+{
+    merge_job *m = (merge_job *)arg;
+    for (size_t i = m->b0; i < m->b1; i++) {
+        int64_t s = 0;
+        for (int t = 0; t < m->T; t++) s += m->hists[t][i];
+        m->out[i] += s;
+    }
+    return NULL;
+}
+
+ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, int threads, int64_t *counts)
+{
+    if (k < 1 || k > 31 || threads < 1) return -1;
+    const size_t bins = (size_t)1 << (2 * k);
+    int T = threads > 256 ? 256 : threads;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    count_job *jobs = (count_job *)malloc(sizeof(count_job) * T);
+    merge_job *mj = (merge_job *)malloc(sizeof(merge_job) * T);
+    int64_t **hists = (int64_t **)malloc(sizeof(int64_t *) * T);
+    for (int t = 0; t < T; t++) {
+        hists[t] = (int64_t *)calloc(bins, sizeof(int64_t));
+        if (!hists[t]) return -2;
+        jobs[t].buf = buf;
+        jobs[t].begin = n * (size_t)t / T;
+        jobs[t].end = n * (size_t)(t + 1) / T;
+        jobs[t].k = k;
+        jobs[t].hist = hists[t];
+        pthread_create(&th[t], NULL, count_worker, &jobs[t]);
+    }
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < T; t++) {
+        mj[t].hists = hists;
+        mj[t].T = T;
+        mj[t].b0 = bins * (size_t)t / T;
+        mj[t].b1 = bins * (size_t)(t + 1) / T;
+        mj[t].out = counts;
+        pthread_create(&th[t], NULL, merge_worker, &mj[t]);
+    }
+    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < T; t++) free(hists[t]);
+    free(hists);
+    free(mj);
+    free(jobs);
+    free(th);
     return 0;
 }

@@ -7,7 +7,6 @@ kpal/kdistlib.py); citations live in kpal_oracle.c.
 import ctypes
 import os
 import subprocess
-import threading
 
 import numpy as np
 
@@ -37,6 +36,8 @@ def lib():
         L.kpal_oracle_count_piece.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_int, _c_i64p]
         L.kpal_oracle_count_piece.restype = ctypes.c_int
+        L.kpal_oracle_count_flat_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_count_flat_mt.restype = ctypes.c_int
         L.kpal_oracle_reverse_complement.argtypes = [ctypes.c_uint64, ctypes.c_int]
         L.kpal_oracle_reverse_complement.restype = ctypes.c_uint64
         L.kpal_oracle_balance.argtypes = [_c_i64p, ctypes.c_int]
@@ -105,21 +106,11 @@ def count_flat(buf, length, threads=1):
         if n:
             L.kpal_oracle_count_piece(b.ctypes.data, 0, n, length, counts.ctypes.data_as(_c_i64p))
         return counts
-    parts = [np.zeros(4 ** length, dtype=np.int64) for _ in range(threads)]
-    edges = [n * t // threads for t in range(threads + 1)]
-
-    def work(t):
-        L.kpal_oracle_count_piece(b.ctypes.data, edges[t], edges[t + 1], length,
-                                  parts[t].ctypes.data_as(_c_i64p))
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    out = parts[0]
-    for p in parts[1:]:
-        out += p
-    return out
+    counts = np.zeros(4 ** length, dtype=np.int64)
+    rc = L.kpal_oracle_count_flat_mt(b.ctypes.data, n, length, int(threads), counts.ctypes.data_as(_c_i64p))
+    if rc:
+        raise MemoryError('kpal_oracle_count_flat_mt failed (%d)' % rc)
+    return counts
 
 
 def reverse_complement(number, length):
