@@ -7,7 +7,7 @@
 //   * LDS direct      : k <= 7, the whole table is privatised per workgroup in LDS as u32
 //                       (bank-replicated for tiny k), merged with one atomic per non-zero bin.
 //   * partition       : 8 <= k <= 12.  Keys are radix-partitioned on their top 9 bits into 512
-//                       buckets (count -> scan -> scatter, scatter staged and sorted in LDS so
+//                       buckets (count -> scan -> scatter, scatter staged per bucket in LDS so
 //                       global writes are runs), then each bucket's <= 2^15 bins are histogrammed
 //                       in LDS with ds_add_u32 and merged into the table.  HBM traffic per base:
 //                       1 B read (count) + 1 B read (scatter) + 2 B written + 2 B read (keys).
@@ -231,13 +231,17 @@ __device__ __forceinline__ unsigned long long phase_stamp()
     return t;
 }
 
-template <int K, bool STAMP = false>
+// MODE: 0 product; 1 per-phase stamps; 2..4 timing ablations (wrong results, diagnostics only):
+// 2 = no global stores in the copy-out, 3 = no copy-out work at all, 4 = no placement,
+// 5 = placement only (synthetic windows, no loads, no copy-out).
+template <int K, int MODE = 0>
 __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_wave,
                                                                        const uint32_t *__restrict__ offs32,
                                                                        const uint64_t *__restrict__ bucket_start,
                                                                        uint16_t *__restrict__ keys_out,
                                                                        unsigned long long *__restrict__ dbg = nullptr)
 {
+    constexpr bool STAMP = MODE == 1;
     unsigned long long acc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     // byte layout: keys rows [512][64] u16 | dummy halfword (+pad) | pos[512] u32 | gcur[512] u64
     constexpr uint32_t kKeysBytes = kNumBuckets * kSlotCap * 2;
@@ -263,10 +267,18 @@ __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, u
         uint64_t window[kScatterSteps];
         uint32_t mask[kScatterSteps];
         if constexpr (STAMP) t0 = phase_stamp();
+        if constexpr (MODE == 5) {   // placement-only timing: pseudo-random windows, no global traffic
+#pragma unroll
+            for (int st = 0; st < kScatterSteps; ++st) {
+                window[st] = mix64((step0 + t + st) * 64 + lane);
+                mask[st] = 0xFFFFu & ~(uint32_t)((window[st] >> 60) == 0 ? 0xFFF0u : 0u);
+            }
+        } else {
 #pragma unroll
         for (int st = 0; st < kScatterSteps; ++st) part_step<K>(s, step0 + t + st, carry, window[st], mask[st]);
+        }
         if constexpr (STAMP) { asm volatile("" ::"v"(window[0]), "v"(window[kScatterSteps - 1])); t1 = phase_stamp(); acc[0] += t1 - t0; t0 = t1; }
-        {
+        if constexpr (MODE != 4) {
 #pragma unroll
             for (int st = 0; st < kScatterSteps; ++st) {
                 const uint64_t w = window[st];
@@ -301,29 +313,46 @@ __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, u
         if constexpr (STAMP) { t1 = phase_stamp(); acc[1] += t1 - t0; t0 = t1; }
         __syncthreads();
         if constexpr (STAMP) { t1 = phase_stamp(); acc[2] += t1 - t0; t0 = t1; }
-        {
-            // wave w owns buckets [43w, 43w+43); lane l < 43 holds the slot count and cursor of bucket 43w+l
+        if constexpr (MODE == 5) {
+            if (threadIdx.x < kNumBuckets) pos[threadIdx.x] = 0;
+        } else if constexpr (MODE != 3) {
+            // Copy-out.  Wave w owns buckets [first, first + kBucketsPerWave); lane l holds bucket
+            // first+l's byte count and global byte address.  Per bucket: three v_readlane build a
+            // buffer descriptor {base = run start, num_records = run bytes} in SGPRs and ONE
+            // buffer_store_short writes the staged row -- lanes beyond the run are dropped by the
+            // hardware range check, so there is no exec-mask juggling and no branch.
             const int first = wave * kBucketsPerWave;
             const int mine = first + lane;
             const bool own = lane < kBucketsPerWave && mine < kNumBuckets;
             const uint32_t my_n = own ? pos[mine] : 0u;
             const uint64_t my_g = own ? gcur[mine] : 0ULL;
-            const uint32_t my_glo = (uint32_t)my_g, my_ghi = (uint32_t)(my_g >> 32);
-#pragma unroll 1
+            const uint64_t my_addr = (uint64_t)keys_out + 2ULL * my_g;
+            const uint32_t my_lo = (uint32_t)my_addr, my_hi = (uint32_t)(my_addr >> 32);
+            const uint32_t my_bytes = 2u * min(my_n, (uint32_t)kSlotCap);
+            const uint32_t r0 = 2u * lane + 4u * first;
+            const unsigned char *rows = lds + (uint32_t)first * 128u;
+#pragma unroll
             for (int i0 = 0; i0 < kBucketsPerWave; i0 += 8) {
                 uint16_t v[8];
-                // unconditional LDS reads first (8 in flight), predicated stores after
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t b = min((uint32_t)(first + i0 + u), (uint32_t)(kNumBuckets - 1));
-                    v[u] = *(const uint16_t *)(lds + b * 128u + ((2u * lane + 4u * b) & 126u));
+                for (int u = 0; u < 8; ++u) {   // unconditional LDS reads first (8 in flight)
+                    const int i = (i0 + u) < kBucketsPerWave ? (i0 + u) : (kBucketsPerWave - 1);
+                    v[u] = *(const uint16_t *)(rows + i * 128 + ((r0 + 4u * i) & 126u));
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const uint32_t n = min((uint32_t)__builtin_amdgcn_readlane(my_n, i0 + u), (uint32_t)kSlotCap);
-                    const uint64_t g = ((uint64_t)__builtin_amdgcn_readlane(my_ghi, i0 + u) << 32) |
-                                       (uint64_t)__builtin_amdgcn_readlane(my_glo, i0 + u);
-                    if ((uint32_t)lane < n) (keys_out + g)[lane] = v[u];
+                    if (i0 + u < kBucketsPerWave) {
+                        const uint32_t lo = __builtin_amdgcn_readlane(my_lo, i0 + u);
+                        const uint32_t hi = __builtin_amdgcn_readlane(my_hi, i0 + u);
+                        const uint32_t nb = __builtin_amdgcn_readlane(my_bytes, i0 + u);
+                        if constexpr (MODE != 2) {
+                            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                                (void *)(((uint64_t)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b16((short)v[u], rsrc, 2 * lane, 0, 0);
+                        } else {
+                            asm volatile("" ::"s"(lo), "s"(hi), "s"(nb), "v"(v[u]));
+                        }
+                    }
                 }
             }
             if (own) {

@@ -430,10 +430,11 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
     if (getenv("KPAL_OCC")) {  // diagnostic: residency of the partition kernels
         int a = 0, b = 0, c = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)part_count_kernel<12>, kScatterThreads, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)part_scatter_kernel<12, false>, kScatterThreads, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)part_scatter_kernel<12, 0>, kScatterThreads, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, (const void *)part_hist_kernel<12>, 1024, 0);
         fprintf(stderr, "[occ] blocks/CU: part_count %d, part_scatter %d, part_hist %d; G=%u spw=%llu\n", a, b, c, G, (unsigned long long)tpb);
     }
+#define SCATTER_ARGS s, tpb, (const uint32_t *)offs, (const uint64_t *)bstart, keys
     DISPATCH_K_8_12(ctx->k, {
         LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb, cntmat);
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
@@ -441,8 +442,7 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
         if (getenv("KPAL_STAMP")) {  // diagnostic build of the scatter kernel: per-phase s_memtime sums
             unsigned long long *dbg = nullptr;
             HIPCHK(hipMalloc(&dbg, (size_t)G * kScatterWaves * 5 * 8));
-            LAUNCH(ctx, "part_scatter_stamp", (part_scatter_kernel<K, true>), dim3(G), dim3(kScatterThreads), s, tpb,
-                   (const uint32_t *)offs, (const uint64_t *)bstart, keys, dbg);
+            LAUNCH(ctx, "part_scatter_stamp", (part_scatter_kernel<K, 1>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, dbg);
             std::vector<unsigned long long> h((size_t)G * kScatterWaves * 5);
             HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipFree(dbg));
@@ -451,12 +451,21 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
             const double nw = (double)G * kScatterWaves;
             fprintf(stderr, "[stamp] per-wave mean cycles: load+encode %.0f  place %.0f  barrier1 %.0f  copyout %.0f  barrier2 %.0f (steps/wave %llu)\n",
                     sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, (unsigned long long)tpb);
-        } else
-        LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb,
-               (const uint32_t *)offs, (const uint64_t *)bstart, keys, (unsigned long long *)nullptr);
+        } else if (getenv("KPAL_ABLATE")) {  // timing ablations of the scatter kernel (results are wrong)
+            const int mode = atoi(getenv("KPAL_ABLATE"));
+            unsigned long long *nodbg = nullptr;
+            if (mode == 2) LAUNCH(ctx, "part_scatter_nostore", (part_scatter_kernel<K, 2>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
+            else if (mode == 3) LAUNCH(ctx, "part_scatter_nocopy", (part_scatter_kernel<K, 3>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
+            else if (mode == 5) LAUNCH(ctx, "part_scatter_placeonly", (part_scatter_kernel<K, 5>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
+            else LAUNCH(ctx, "part_scatter_noplace", (part_scatter_kernel<K, 4>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
+        } else {
+            unsigned long long *nodbg = nullptr;
+            LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K, 0>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
+        }
         LAUNCH(ctx, "part_hist", (part_hist_kernel<K>), dim3(kNumBuckets * slices), dim3(1024),
                (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
     });
+#undef SCATTER_ARGS
     return KPAL_OK;
 }
 

@@ -37,9 +37,10 @@ __global__ __launch_bounds__(768) void store_kernel(unsigned char *buf, size_t s
 }
 
 template <int BYTES>
-void run(unsigned char *buf, size_t span, int lanes, int skew, int groups = 1)
+void run(unsigned char *buf, size_t span_full, int lanes, int skew, int groups = 1, size_t span = 0)
 {
     const int iters = 40;
+    if (span == 0) span = span_full;
     int lanes_log2 = 0;
     while ((1 << lanes_log2) < lanes) ++lanes_log2;
     const size_t region = span / (512 * 12);
@@ -59,7 +60,7 @@ void run(unsigned char *buf, size_t span, int lanes, int skew, int groups = 1)
     CHECK(hipEventElapsedTime(&ms, a, b));
     const double instr_per_cu = (double)iters * 64 * 12 * 2;  // 2 blocks of 12 waves per CU
     const double bytes = (double)iters * 64 * 12 * 512 * lanes * BYTES * groups;
-    printf("store %2d B/lane, %2d lanes x%d runs/instr, skew %d: %7.1f ns per store-instr per CU (%.1f clk @2.2GHz), %.2f TB/s\n", BYTES, lanes, groups, skew,
+    printf("span %5zu MiB: store %2d B/lane, %2d lanes x%d runs/instr, skew %d: %7.1f ns per store-instr per CU (%.1f clk @2.2GHz), %.2f TB/s\n", span >> 20, BYTES, lanes, groups, skew,
            ms * 1e6 / instr_per_cu, ms * 1e6 / instr_per_cu * 2.2, bytes / ms / 1e9);
 }
 
@@ -68,16 +69,12 @@ int main()
     const size_t span = (size_t)8 << 30;
     unsigned char *buf;
     CHECK(hipMalloc(&buf, span));
-    run<2>(buf, span, 32, 2);
-    run<2>(buf, span, 64, 2);
-    run<2>(buf, span, 64, 0);
-    run<16>(buf, span, 2, 0, 1);    // one aligned 32 B sector per instr
-    run<16>(buf, span, 2, 0, 32);   // 32 aligned 32 B runs per instr
-    run<16>(buf, span, 4, 0, 1);    // one aligned 64 B run
-    run<16>(buf, span, 4, 0, 16);   // 16 aligned 64 B runs per instr
-    run<16>(buf, span, 8, 0, 1);    // one aligned 128 B line
-    run<16>(buf, span, 8, 0, 8);    // 8 aligned 128 B lines per instr
-    run<16>(buf, span, 16, 0, 4);   // 4 aligned 256 B runs per instr
-    run<16>(buf, span, 64, 0, 1);   // 1 KiB contiguous
+    for (size_t sp : {(size_t)8 << 30, (size_t)2 << 30, (size_t)512 << 20, (size_t)96 << 20}) {
+        run<2>(buf, span, 32, 2, 1, sp);
+        run<2>(buf, span, 64, 0, 1, sp);
+        run<16>(buf, span, 8, 0, 1, sp);
+        run<16>(buf, span, 8, 0, 8, sp);
+        run<16>(buf, span, 64, 0, 1, sp);
+    }
     return 0;
 }
