@@ -100,11 +100,11 @@ __global__ __launch_bounds__(512) void count_lds_direct_kernel(Span s, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// Strategy 3: partition.  Block `blk` of G owns 8 * steps_per_wave consecutive wave-steps; wave w
-// of the block streams the contiguous sub-range [(8 blk + w) S, (8 blk + w + 1) S) of steps, so
-// its left-neighbour chunk is carried in registers from step to step and never re-encoded.  The
-// count (A1) and scatter (A3) kernels use the same mapping, hence agree on every per-(bucket,
-// block) count.
+// Strategy 3: partition.  Block `blk` of G owns steps_per_block (a multiple of 24) consecutive
+// wave-steps; the streaming waves of a block split that range into contiguous sub-ranges, so a
+// wave's left-neighbour chunk is carried in registers from step to step and never re-encoded.
+// The count (A1) and scatter (A3) kernels use the same block ranges, hence agree on every
+// per-(bucket, block) count even though they organise their waves differently.
 // ------------------------------------------------------------------------------------------
 template <int K>
 struct PartCfg {
@@ -126,7 +126,7 @@ __device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &c
 // bank lane % 32), so a wave's 64 ds_add_u32 never conflict; a k-mer that must not be counted
 // adds 0 (branch-free).
 template <int K>
-__global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uint64_t steps_per_wave,
+__global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uint64_t steps_per_block,
                                                                      uint32_t *__restrict__ cntmat)
 {
     __shared__ uint32_t cnt[kNumBuckets * 32];  // 64 KiB
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uin
     __syncthreads();
     const uint32_t rep = threadIdx.x & 31;
     const uint64_t total_steps = (s.nchunks + 63) / 64;
-    const uint64_t step0 = ((uint64_t)blockIdx.x * kScatterWaves + (threadIdx.x >> 6)) * steps_per_wave;
+    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
+    const uint64_t step0 = (uint64_t)blockIdx.x * steps_per_block + (uint64_t)(threadIdx.x >> 6) * steps_per_wave;
     if (step0 < total_steps) {
         const uint64_t step1 = min(step0 + steps_per_wave, total_steps);
         Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
@@ -235,7 +236,7 @@ __device__ __forceinline__ unsigned long long phase_stamp()
 // 2 = no global stores in the copy-out, 3 = no copy-out work at all, 4 = no placement,
 // 5 = placement only (synthetic windows, no loads, no copy-out).
 template <int K, int MODE = 0>
-__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_wave,
+__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_block,
                                                                        const uint32_t *__restrict__ offs32,
                                                                        const uint64_t *__restrict__ bucket_start,
                                                                        uint16_t *__restrict__ keys_out,
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, u
     }
     __syncthreads();
     const uint64_t total_steps = (s.nchunks + 63) / 64;
-    const uint64_t block_step0 = (uint64_t)blockIdx.x * kScatterWaves * steps_per_wave;
+    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
+    const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
     const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
     Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
     for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
@@ -407,8 +409,9 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
     };
     // four 16-byte loads in flight per lane (64 KiB per workgroup) to cover HBM latency
     uint64_t v = threadIdx.x;
-    for (; v + 3 * (uint64_t)blockDim.x < nvec; v += 4 * (uint64_t)blockDim.x) {
-        const uint4 q0 = kv[v], q1 = kv[v + blockDim.x], q2 = kv[v + 2 * (uint64_t)blockDim.x], q3 = kv[v + 3 * (uint64_t)blockDim.x];
+    const uint64_t B = blockDim.x;
+    for (; v + 3 * B < nvec; v += 4 * B) {
+        const uint4 q0 = kv[v], q1 = kv[v + B], q2 = kv[v + 2 * B], q3 = kv[v + 3 * B];
         add8(q0);
         add8(q1);
         add8(q2);

@@ -88,17 +88,21 @@ struct Span {
     uint64_t nchunks;    // ceil(hi / 16)
 };
 
-// Load and encode chunk c; bytes outside [lo, hi) are flagged bad; c >= nchunks or c < 0 gives
-// an all-bad chunk without touching memory.
-__device__ __forceinline__ Chunk load_chunk(const Span &s, int64_t c)
+// Raw 16 bytes of chunk c, zeros when c is outside the buffer (no memory access).
+__device__ __forceinline__ uint4 fetch_chunk(const Span &s, int64_t c)
 {
-    Chunk r;
+    if (c < 0 || (uint64_t)c >= s.nchunks) return make_uint4(0u, 0u, 0u, 0u);
+    return s.base[c];
+}
+
+// Flag the bytes of chunk c that lie outside the fed range [lo, hi) as bad.
+__device__ __forceinline__ void range_fix(const Span &s, int64_t c, Chunk &r)
+{
     if (c < 0 || (uint64_t)c >= s.nchunks) {
         r.codes = 0;
         r.bad = 0xFFFFu;
-        return r;
+        return;
     }
-    r = encode16(s.base[c]);
     const uint64_t p0 = (uint64_t)c * 16;
     if (p0 < s.lo || p0 + 16 > s.hi) {
         const uint32_t a = s.lo > p0 ? (uint32_t)(s.lo - p0) : 0u;                    // first in-range byte
@@ -106,6 +110,14 @@ __device__ __forceinline__ Chunk load_chunk(const Span &s, int64_t c)
         const uint32_t in_range = (a < b) ? (((1u << (16 - a)) - 1u) & ~((1u << (16 - b)) - 1u)) : 0u;
         r.bad |= ~in_range & 0xFFFFu;
     }
+}
+
+// Load and encode chunk c; bytes outside [lo, hi) are flagged bad; c >= nchunks or c < 0 gives
+// an all-bad chunk without touching memory.
+__device__ __forceinline__ Chunk load_chunk(const Span &s, int64_t c)
+{
+    Chunk r = encode16(fetch_chunk(s, c));
+    range_fix(s, c, r);
     return r;
 }
 
@@ -175,6 +187,25 @@ __device__ __forceinline__ void wave_step(const Span &s, int64_t c, Chunk &carry
     window = ((uint64_t)pc << 32) | cur.codes;
     mask = emit_mask<K>(pb, cur.bad);
     if constexpr (EDGE) mask &= emit_from_mask(s, c);
+}
+
+// wave_step on data that was fetched earlier (software prefetch): `raw` = fetch_chunk(s, c).
+template <int K>
+__device__ __forceinline__ void encode_step(const Span &s, uint64_t step, const uint4 raw, Chunk &carry,
+                                            uint64_t &window, uint32_t &mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)(step * 64 + lane);
+    Chunk cur = encode16(raw);
+    const bool edge = !(step * 64 >= 1 && (step * 64 - 1) * 16 >= s.lo && (step * 64 + 64) * 16 <= s.hi && s.emit_from <= step * 64 * 16);
+    if (edge) range_fix(s, c, cur);   // wave-uniform branch
+    const uint32_t pc = from_left_lane(cur.codes, carry.codes);
+    const uint32_t pb = from_left_lane(cur.bad, carry.bad);
+    carry.codes = __builtin_amdgcn_readlane(cur.codes, 63);
+    carry.bad = __builtin_amdgcn_readlane(cur.bad, 63);
+    window = ((uint64_t)pc << 32) | cur.codes;
+    mask = emit_mask<K>(pb, cur.bad);
+    if (edge) mask &= emit_from_mask(s, c);
 }
 
 // true iff chunks [c0 - 1, c1) are wholly inside [lo, hi) and every k-mer ending in [c0, c1) is emitted

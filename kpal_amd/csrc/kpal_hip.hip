@@ -409,12 +409,11 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    // steps per wave: a multiple of the tile depth, sized for ~4 blocks per CU
+    // steps per block: a multiple of 24 (= 8 waves x 3 steps = 12 waves x 2 steps), ~4 blocks per CU
     const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
-    uint64_t spw = (total_steps + want_blocks * kScatterWaves - 1) / (want_blocks * kScatterWaves);
-    spw = (spw + kScatterSteps - 1) / kScatterSteps * kScatterSteps;
-    const uint64_t tpb = spw;  // kernel argument: steps per wave
-    const uint32_t G = (uint32_t)((total_steps + spw * kScatterWaves - 1) / (spw * kScatterWaves));
+    uint64_t tpb = (total_steps + want_blocks - 1) / want_blocks;   // kernel argument: steps per block
+    tpb = (tpb + 23) / 24 * 24;
+    const uint32_t G = (uint32_t)((total_steps + tpb - 1) / tpb);
     const uint64_t max_keys = s.nchunks * 16;
     CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
     CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
@@ -588,14 +587,26 @@ KPAL_API uint64_t kpal_reverse_complement(uint64_t number, int k)
     return revcomp(number, k);
 }
 
+// out[i] = in[i] + in[rc(i)]; in == out allowed.  LDS-tiled for k >= 6, pairwise kernels below that.
+static int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out)
+{
+    const uint64_t n = 1ULL << (2 * k);
+    if (k >= 6) {
+        LAUNCH(ctx, "balance_tiled", balance_tiled_kernel, dim3((unsigned)(1u << (2 * (k - 6)))), dim3(1024), in, out, k);
+    } else if (in == out) {
+        LAUNCH(ctx, "balance_inplace", balance_inplace_kernel, dim3(stream_grid(ctx, n)), dim3(256), out, k, n);
+    } else {
+        LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256), in, out, k, n);
+    }
+    return KPAL_OK;
+}
+
 KPAL_API int kpal_balance_device(kpal_ctx *ctx, int k, int64_t *dev_inout)
 {
     CTX_ENTER(ctx);
     if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
     if (!dev_inout) return set_err(KPAL_E_INVALID, "dev_inout is NULL");
-    const uint64_t n = 1ULL << (2 * k);
-    LAUNCH(ctx, "balance_inplace", balance_inplace_kernel, dim3(stream_grid(ctx, n)), dim3(256), dev_inout, k, n);
-    return KPAL_OK;
+    return launch_balance(ctx, k, dev_inout, dev_inout);
 }
 
 KPAL_API int kpal_balance(kpal_ctx *ctx, int k, int64_t *host_inout)
@@ -726,8 +737,8 @@ KPAL_API int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *d
         if (k < 1 || k > KPAL_MAX_K || n != (1ULL << (2 * k))) return set_err(KPAL_E_INVALID, "do_balance needs n == 4^k");
         CHK(ensure(ctx, ctx->scratch[2], n * 8));
         CHK(ensure(ctx, ctx->scratch[3], n * 8));
-        LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256), l, (int64_t *)ctx->scratch[2].p, k, (uint64_t)n);
-        LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256), r, (int64_t *)ctx->scratch[3].p, k, (uint64_t)n);
+        CHK(launch_balance(ctx, k, l, (int64_t *)ctx->scratch[2].p));
+        CHK(launch_balance(ctx, k, r, (int64_t *)ctx->scratch[3].p));
         l = (const int64_t *)ctx->scratch[2].p;
         r = (const int64_t *)ctx->scratch[3].p;
     }
@@ -776,8 +787,7 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
         // balance once per profile: identical to the reference balancing copies per pair (kdistlib.py:136-141)
         CHK(ensure(ctx, ctx->scratch[2], (size_t)P * n * 8));
         for (int p = 0; p < P; ++p)
-            LAUNCH(ctx, "balance_oop", balance_oop_kernel, dim3(stream_grid(ctx, n)), dim3(256),
-                   dev_profiles + (uint64_t)p * n, (int64_t *)ctx->scratch[2].p + (uint64_t)p * n, k, n);
+            CHK(launch_balance(ctx, k, dev_profiles + (uint64_t)p * n, (int64_t *)ctx->scratch[2].p + (uint64_t)p * n));
         prof = (const int64_t *)ctx->scratch[2].p;
     }
     constexpr int TILE = 4;

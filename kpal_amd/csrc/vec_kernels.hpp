@@ -87,6 +87,41 @@ __global__ __launch_bounds__(256) void balance_inplace_kernel(int64_t *__restric
     }
 }
 
+// LDS-tiled balance for k >= 6.  Write i = (H, M, L) with H / L the top / bottom three digits
+// and M the k-6 middle digits; then rc(i) = (rc(L), rc(M), rc(H)): the 64x64 tile {(H, M, L)} maps
+// onto the tile of rc(M), transposed and with rows/columns permuted by the 3-digit reverse
+// complement.  One workgroup owns the tile pair (M, rc(M)), M <= rc(M): it reads both tiles as 64
+// runs of 512 B, keeps them in LDS (rows padded to 65 to spread banks on the transposed read),
+// and writes out[i] = in[i] + in[rc(i)] for both tiles -- 16 B of HBM traffic per bin instead of
+// scattered 8-byte partner accesses.  in == out is allowed (all reads precede the barrier).
+__global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, int64_t *out, int k)
+{
+    constexpr int T = 3, S = 64;
+    __shared__ unsigned long long A[S][S + 1];
+    __shared__ unsigned long long B[S][S + 1];
+    const int md = k - 2 * T;
+    const uint64_t M = blockIdx.x;
+    const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+    if (M > Mr) return;
+    const bool self = M == Mr;
+    const uint64_t rowstride = 1ULL << (2 * (k - T));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long *uin = reinterpret_cast<const unsigned long long *>(in);
+    unsigned long long *uout = reinterpret_cast<unsigned long long *>(out);
+    for (int h = w; h < S; h += 16) {
+        A[h][lane] = uin[(uint64_t)h * rowstride + M * S + lane];
+        if (!self) B[h][lane] = uin[(uint64_t)h * rowstride + Mr * S + lane];
+    }
+    __syncthreads();
+    const int rl = (int)revcomp((uint64_t)lane, T);
+    for (int h = w; h < S; h += 16) {
+        const int rh = (int)revcomp((uint64_t)h, T);
+        const unsigned long long partner = self ? A[rl][rh] : B[rl][rh];
+        uout[(uint64_t)h * rowstride + M * S + lane] = A[h][lane] + partner;
+        if (!self) uout[(uint64_t)h * rowstride + Mr * S + lane] = B[h][lane] + A[rl][rh];
+    }
+}
+
 // ---- split --------------------------------------------------------------------------------
 // Order-preserving compaction of i <= rc(i).  Pass 1 counts canonical indices per block-sized
 // segment; the host scans the (small) count array; pass 2 writes.

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Developer harness: HIP-event times of the vector kernels (balance, pair distance, strand
+balance, split) on device-resident profiles.   python tools/vbench.py [--k 12]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from kpal_amd import _native
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--k', type=int, default=12)
+ap.add_argument('--reps', type=int, default=5)
+a = ap.parse_args()
+ctx = _native.Context(0)
+n = 4 ** a.k
+rs = np.random.RandomState(1)
+l = rs.poisson(16.6, n).astype(np.int64)
+r = rs.poisson(16.6, n).astype(np.int64)
+dl, dr = ctx.alloc(n * 8), ctx.alloc(n * 8)
+ctx.h2d(dl, l); ctx.h2d(dr, r)
+for rep in range(a.reps + 1):
+    if rep == 1:
+        ctx.prof_enable(True); ctx.prof_reset()
+    for metric in (0, 1, 2):
+        ctx.pair_distance_device(n, dl, dr, metric)
+    ctx.pair_distance_device(n, dl, dr, 0, do_balance=True, k=a.k)
+    ctx.balance_device(a.k, dl)
+prof = ctx.prof_get()
+print('k=%d  n=%d bins (%.0f MB per vector)' % (a.k, n, n * 8 / 1e6))
+for name, (ms, cnt) in sorted(prof.items()):
+    per = ms / cnt
+    print('   %-18s %8.3f ms per launch (%d launches)' % (name, per, cnt))
+print('   pair_distance reads 2 vectors: %.2f TB/s at the mean launch time' % (2 * n * 8 / (prof['pair_distance'][0] / prof['pair_distance'][1]) / 1e9))
+ctx.prof_enable(False)
+if a.k <= 13:
+    import time
+    t0 = time.perf_counter(); ctx.strand_balance(l, a.k, 0); t1 = time.perf_counter()
+    f, rv = ctx.split(l, a.k); t2 = time.perf_counter()
+    print('   host-API strand_balance %.1f ms, split %.1f ms (include PCIe copies)' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
