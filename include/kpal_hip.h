@@ -47,6 +47,7 @@ extern "C" {
 #define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k */
 #define KPAL_STRATEGY_LDS_DIRECT 2    /* whole 4^k table privatised in LDS; k <= 7 */
 #define KPAL_STRATEGY_PARTITION 3     /* radix-partition keys, histogram buckets in LDS; 8 <= k <= 12 */
+#define KPAL_STRATEGY_PARTITION2 4    /* two-level radix partition; 13 <= k <= 15 */
 
 typedef struct kpal_ctx kpal_ctx;
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libkpal_hip.so')
 
 KPAL_MAX_K = 16
 PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN = 0, 1, 2
-STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3}
+STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4}
 
 _E_INVALID, _E_NOMEM, _E_HIP, _E_STATE = -1, -2, -3, -4
 

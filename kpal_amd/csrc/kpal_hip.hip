@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "count_kernels.hpp"
+#include "partition_kernels.hpp"
 #include "vec_kernels.hpp"
 
 #define KPAL_API extern "C" __attribute__((visibility("default")))
@@ -79,6 +80,7 @@ struct kpal_ctx {
     size_t batch_bytes = (size_t)1 << 30;
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start;
+    DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
     void *pinned[2] = {nullptr, nullptr};
@@ -209,6 +211,13 @@ static int prof_collect(kpal_ctx *ctx)
         return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);                   \
     }
 
+#define DISPATCH_K_13_15(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__)                    \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 15 (k=%d)", k); \
+    }
+
 #define DISPATCH_K_8_12(k, ...)                                                                   \
     switch (k) {                                                                                   \
         CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
@@ -262,7 +271,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result};
     for (DevBuf *b : bufs)
@@ -348,7 +357,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -358,10 +367,13 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
 {
     int s = ctx->strategy;
     const int k = ctx->k;
-    if (s == KPAL_STRATEGY_AUTO) s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : KPAL_STRATEGY_GLOBAL_ATOMIC);
+    if (s == KPAL_STRATEGY_AUTO)
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : (k <= 15 ? KPAL_STRATEGY_PARTITION2 : KPAL_STRATEGY_GLOBAL_ATOMIC));
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
     if (s == KPAL_STRATEGY_PARTITION && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
+    if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 15))
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 15 (k=%d)", k);
     *out = s;
     return KPAL_OK;
 }
@@ -405,15 +417,16 @@ static int launch_lds_direct(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
+// One-level partition, k = 8..12 (partition_kernels.hpp: A1, A2, A3, B).
 static int launch_partition(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    // steps per block: a multiple of 24 (= 8 waves x 3 steps = 12 waves x 2 steps), ~4 blocks per CU
+    // steps per block: a multiple of 24 (8 waves x 3 steps per tile), ~4 blocks per CU
     const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
-    uint64_t tpb = (total_steps + want_blocks - 1) / want_blocks;   // kernel argument: steps per block
-    tpb = (tpb + 23) / 24 * 24;
-    const uint32_t G = (uint32_t)((total_steps + tpb - 1) / tpb);
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + kStepsPerBlockQuantum - 1) / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+    const uint32_t G = (uint32_t)((total_steps + spb - 1) / spb);
     const uint64_t max_keys = s.nchunks * 16;
     CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
     CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
@@ -425,46 +438,84 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
     uint64_t *btotal = bstart + kNumBuckets + 1;
     uint16_t *keys = (uint16_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
-    const uint32_t slices = 4;
-    if (getenv("KPAL_OCC")) {  // diagnostic: residency of the partition kernels
-        int a = 0, b = 0, c = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)part_count_kernel<12>, kScatterThreads, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)part_scatter_kernel<12, 0>, kScatterThreads, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, (const void *)part_hist_kernel<12>, 1024, 0);
-        fprintf(stderr, "[occ] blocks/CU: part_count %d, part_scatter %d, part_hist %d; G=%u spw=%llu\n", a, b, c, G, (unsigned long long)tpb);
-    }
-#define SCATTER_ARGS s, tpb, (const uint32_t *)offs, (const uint64_t *)bstart, keys
+    const uint32_t slices = 1;   // one workgroup per bucket: exclusive table slice -> plain RMW merge (measured fastest)
+    const uint64_t *no_base = nullptr;
     DISPATCH_K_8_12(ctx->k, {
-        LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, tpb, cntmat);
+        LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, cntmat);
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
-        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal, bstart);
-        if (getenv("KPAL_STAMP")) {  // diagnostic build of the scatter kernel: per-phase s_memtime sums
-            unsigned long long *dbg = nullptr;
-            HIPCHK(hipMalloc(&dbg, (size_t)G * kScatterWaves * 5 * 8));
-            LAUNCH(ctx, "part_scatter_stamp", (part_scatter_kernel<K, 1>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, dbg);
-            std::vector<unsigned long long> h((size_t)G * kScatterWaves * 5);
-            HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-            HIPCHK(hipFree(dbg));
-            double sum[5] = {0, 0, 0, 0, 0};
-            for (size_t i = 0; i < h.size(); ++i) sum[i % 5] += (double)h[i];
-            const double nw = (double)G * kScatterWaves;
-            fprintf(stderr, "[stamp] per-wave mean cycles: load+encode %.0f  place %.0f  barrier1 %.0f  copyout %.0f  barrier2 %.0f (steps/wave %llu)\n",
-                    sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, (unsigned long long)tpb);
-        } else if (getenv("KPAL_ABLATE")) {  // timing ablations of the scatter kernel (results are wrong)
-            const int mode = atoi(getenv("KPAL_ABLATE"));
-            unsigned long long *nodbg = nullptr;
-            if (mode == 2) LAUNCH(ctx, "part_scatter_nostore", (part_scatter_kernel<K, 2>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
-            else if (mode == 3) LAUNCH(ctx, "part_scatter_nocopy", (part_scatter_kernel<K, 3>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
-            else if (mode == 5) LAUNCH(ctx, "part_scatter_placeonly", (part_scatter_kernel<K, 5>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
-            else LAUNCH(ctx, "part_scatter_noplace", (part_scatter_kernel<K, 4>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
-        } else {
-            unsigned long long *nodbg = nullptr;
-            LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K, 0>), dim3(G), dim3(kScatterThreads), SCATTER_ARGS, nodbg);
-        }
-        LAUNCH(ctx, "part_hist", (part_hist_kernel<K>), dim3(kNumBuckets * slices), dim3(1024),
+        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal,
+               (uint32_t)kNumBuckets, no_base, bstart);
+        LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb,
+               (const uint32_t *)offs, (const uint64_t *)bstart, keys);
+        LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kNumBuckets * slices), dim3(1024),
                (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
     });
-#undef SCATTER_ARGS
+    return KPAL_OK;
+}
+
+// Two-level partition, k = 13..15: coarse count/scan/scatter into 24-bit residuals, then the
+// one-level pipeline on every coarse bucket's residual stream (2-D launches over coarse buckets).
+static int launch_partition2(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    const int NB1 = 1 << (2 * ctx->k - kResidualBits);
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + 7) / 8 * 8;   // 8 waves, one step per wave per tile
+    const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
+    const uint64_t max_keys = s.nchunks * 16;
+    CHK(ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64));
+    CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
+    CHK(ensure(ctx, ctx->cnt1, (size_t)NB1 * G1 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs1, (size_t)NB1 * G1 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->start1, (size_t)(2 * NB1 + 2) * sizeof(uint64_t)));
+    uint32_t *res = (uint32_t *)ctx->residuals.p;
+    uint32_t *cnt1 = (uint32_t *)ctx->cnt1.p;
+    uint32_t *offs1 = (uint32_t *)ctx->offs1.p;
+    uint64_t *start1 = (uint64_t *)ctx->start1.p;
+    uint64_t *total1 = start1 + NB1 + 1;
+    uint16_t *keys = (uint16_t *)ctx->keys.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    const uint64_t *no_base = nullptr;
+    DISPATCH_K_13_15(ctx->k, {
+        LAUNCH(ctx, "coarse_count", (coarse_count_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb, cnt1);
+        LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(NB1), dim3(256), (const uint32_t *)cnt1, G1, offs1, total1);
+        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)total1,
+               (uint32_t)NB1, no_base, start1);
+        LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
+               (const uint32_t *)offs1, (const uint64_t *)start1, res);
+    });
+    // coarse bucket sizes size the level-2 launches (one small D2H + sync per batch)
+    std::vector<uint64_t> h1((size_t)NB1 + 1);
+    HIPCHK(hipMemcpyAsync(h1.data(), start1, h1.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint64_t maxn = 0;
+    for (int c = 0; c < NB1; ++c) maxn = std::max(maxn, h1[c + 1] - h1[c]);
+    if (maxn == 0) return KPAL_OK;
+    const uint64_t g2_target = std::max<uint64_t>(8, (uint64_t)ctx->num_cu * 8 / NB1);
+    uint64_t kpb = (maxn + g2_target - 1) / g2_target;
+    kpb = (kpb + kKeysPerBlockQuantum - 1) / kKeysPerBlockQuantum * kKeysPerBlockQuantum;
+    if (kpb > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
+    const uint32_t G2 = (uint32_t)((maxn + kpb - 1) / kpb);
+    const size_t rows2 = (size_t)NB1 * kNumBuckets;
+    CHK(ensure(ctx, ctx->cntmat, rows2 * G2 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs, rows2 * G2 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->bucket_start, ((size_t)NB1 * (kNumBuckets + 1) + rows2) * sizeof(uint64_t)));
+    uint32_t *cntmat2 = (uint32_t *)ctx->cntmat.p;
+    uint32_t *offs2 = (uint32_t *)ctx->offs.p;
+    uint64_t *bstart2 = (uint64_t *)ctx->bucket_start.p;
+    uint64_t *total2 = bstart2 + (size_t)NB1 * (kNumBuckets + 1);
+    const uint32_t slices = 1;   // 512 x NB1 >= 2048 workgroups; exclusive table slices -> plain RMW merge
+    LAUNCH(ctx, "key_count", key_count_kernel, dim3(G2, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+           (const uint64_t *)start1, (uint32_t)kpb, cntmat2);
+    LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets, NB1), dim3(256), (const uint32_t *)cntmat2, G2, offs2, total2);
+    LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(NB1), dim3(kNumBuckets), (const uint64_t *)total2,
+           (uint32_t)kNumBuckets, (const uint64_t *)start1, bstart2);
+    LAUNCH(ctx, "key_scatter", key_scatter_kernel, dim3(G2, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+           (const uint64_t *)start1, (uint32_t)kpb, (const uint32_t *)offs2, (const uint64_t *)bstart2, keys);
+    LAUNCH(ctx, "part_hist", (part_hist_kernel<kResKeyBits>), dim3(kNumBuckets * slices, NB1), dim3(1024),
+           (const uint16_t *)keys, (const uint64_t *)bstart2, slices, table);
     return KPAL_OK;
 }
 
@@ -477,6 +528,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
+    else if (strat == KPAL_STRATEGY_PARTITION2) piece = std::min<size_t>(ctx->batch_bytes * 4, (size_t)0xF0000000u);  // few table merges; < 2^32 keys
     else if (strat == KPAL_STRATEGY_LDS_DIRECT) piece = (size_t)1 << 31;
     piece &= ~(size_t)15;
     if (piece == 0) piece = 16;
@@ -486,7 +538,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         const Span s = make_span(addr + off, len, h);
         if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
-        else CHK(launch_partition(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
+        else CHK(launch_partition2(ctx, s));
     }
     return KPAL_OK;
 }

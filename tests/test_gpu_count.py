@@ -23,6 +23,8 @@ def strategies(k):
         s.append('lds_direct')
     if 8 <= k <= 12:
         s.append('partition')
+    if 13 <= k <= 15:
+        s.append('partition2')
     return s
 
 
