@@ -73,6 +73,13 @@ int kpal_count_begin(kpal_ctx *ctx, int k);            /* klib.py:149-151: zeroe
 int kpal_count_set_strategy(kpal_ctx *ctx, int strategy);
 int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);        /* klib.py:154-168 */
 int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous */
+/* FASTA text of whole records (Profile.from_fasta, klib.py:97-112; tokenising the reference
+ * delegates to Bio.SeqIO.parse, klib.py:111): header lines dropped, the lines of a record joined
+ * with all ASCII whitespace removed, records separated; anything before the first header is
+ * ignored.  Flattened on the device, then counted like one kpal_count_feed_device call. */
+int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);
+/* The flattening alone (tests): host_out needs nbytes bytes; records are each preceded by '\n'. */
+int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
 int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
 

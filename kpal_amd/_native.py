@@ -42,6 +42,8 @@ SIGNATURES = {
     'kpal_count_set_strategy': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_count_feed': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_device': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_count_feed_fasta': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_fasta_flatten': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
@@ -181,6 +183,20 @@ class Context(object):
         a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
         if a.size:
             _check(self._L.kpal_count_feed(self._h, a.ctypes.data, a.size))
+
+    def count_feed_fasta(self, buf):
+        """buf: FASTA text (bytes-like) made of whole records; flattened and counted on the GPU."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        if a.size:
+            _check(self._L.kpal_count_feed_fasta(self._h, a.ctypes.data, a.size))
+
+    def fasta_flatten(self, buf):
+        """-> the flat byte stream the counting kernels see for this FASTA text (tests)."""
+        a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
+        out = np.empty(max(a.size, 1), dtype=np.uint8)
+        n = ctypes.c_uint64(0)
+        _check(self._L.kpal_fasta_flatten(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, ctypes.byref(n)))
+        return out[:n.value].tobytes()
 
     def count_feed_device(self, dev_ptr, nbytes):
         _check(self._L.kpal_count_feed_device(self._h, _vp(dev_ptr), int(nbytes)))

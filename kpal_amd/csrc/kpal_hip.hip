@@ -16,6 +16,7 @@
 
 #include "count_kernels.hpp"
 #include "partition_kernels.hpp"
+#include "fasta_kernels.hpp"
 #include "vec_kernels.hpp"
 
 #define KPAL_API extern "C" __attribute__((visibility("default")))
@@ -81,6 +82,7 @@ struct kpal_ctx {
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
+    DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
     void *pinned[2] = {nullptr, nullptr};
@@ -271,7 +273,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result};
     for (DevBuf *b : bufs)
@@ -588,6 +590,80 @@ KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbyt
         HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
         ctx->stage_used[slot] = true;
     }
+    return KPAL_OK;
+}
+
+// Position of the first header ('>' at a line start) in a FASTA buffer, or nbytes if none.
+static size_t fasta_first_header(const uint8_t *buf, size_t nbytes)
+{
+    size_t i = 0;
+    while (i < nbytes) {
+        if (buf[i] == '>') return i;
+        const void *nl = memchr(buf + i, '\n', nbytes - i);
+        const void *cr = memchr(buf + i, '\r', nbytes - i);
+        const uint8_t *e = (const uint8_t *)nl;
+        if (cr && (!e || (const uint8_t *)cr < e)) e = (const uint8_t *)cr;
+        if (!e) return nbytes;
+        i = (size_t)(e - buf) + 1;
+    }
+    return nbytes;
+}
+
+// FASTA text (host) -> flat stream on the device: ctx->fa_flat holds *n_flat bytes afterwards.
+static int fasta_flatten_to_device(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint64_t *n_flat)
+{
+    *n_flat = 0;
+    const size_t first = fasta_first_header(host_buf, nbytes);
+    if (first >= nbytes) return KPAL_OK;   // no record: nothing to count (klib.py:111 yields nothing)
+    const uint64_t n = nbytes - first;
+    const uint32_t nblocks = (uint32_t)((n + kFaBlockBytes - 1) / kFaBlockBytes);
+    CHK(ensure(ctx, ctx->fa_raw, n + 64));
+    CHK(ensure(ctx, ctx->fa_flat, n + 64));
+    const size_t meta = (size_t)nblocks * (8 + 8 + 4) + (size_t)(nblocks + 1) * 8 + 64;
+    CHK(ensure(ctx, ctx->fa_meta, meta));
+    uint8_t *raw = (uint8_t *)ctx->fa_raw.p;
+    uint8_t *flat = (uint8_t *)ctx->fa_flat.p;
+    long long *last_eol = (long long *)ctx->fa_meta.p;
+    long long *carry = last_eol + nblocks;
+    uint64_t *offs = (uint64_t *)(carry + nblocks);
+    uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
+    HIPCHK(hipMemcpyAsync(raw, host_buf + first, n, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, last_eol);
+    LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
+    LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, (const long long *)carry, kept);
+    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
+    LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n,
+           (const long long *)carry, (const uint64_t *)offs, flat);
+    HIPCHK(hipMemcpyAsync(n_flat, offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_fasta before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
+    uint64_t n_flat = 0;
+    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
+    if (n_flat == 0) return KPAL_OK;
+    return count_device_range(ctx, (const uint8_t *)ctx->fa_flat.p, (size_t)n_flat, 0);
+}
+
+KPAL_API int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out)
+{
+    CTX_ENTER(ctx);
+    if (!n_out || (nbytes && (!host_buf || !host_out))) return set_err(KPAL_E_INVALID, "NULL pointer");
+    *n_out = 0;
+    if (nbytes == 0) return KPAL_OK;
+    uint64_t n_flat = 0;
+    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
+    if (n_flat) {
+        HIPCHK(hipMemcpyAsync(host_out, ctx->fa_flat.p, n_flat, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n_flat;
     return KPAL_OK;
 }
 

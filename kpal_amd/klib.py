@@ -26,6 +26,8 @@ import numpy as np
 from . import _native, metrics
 
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
+_FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
+_WHITESPACE = {ord(c): None for c in ' \t\n\v\f\r'}
 
 
 def _fasta_records(handle):
@@ -42,7 +44,7 @@ def _fasta_records(handle):
             name = title.split(None, 1)[0] if title else ''
             parts = []
         elif name is not None:
-            parts.append(''.join(line.split()))
+            parts.append(line.translate(_WHITESPACE))
     if name is not None:
         yield name, ''.join(parts)
 
@@ -87,8 +89,30 @@ class Profile(object):
 
     @classmethod
     def from_fasta(cls, handle, length, name=None):
-        """One profile over all records of a FASTA handle (kpal/klib.py:97-112)."""
-        return cls.from_sequences((seq for _, seq in _fasta_records(handle)), length, name=name)
+        """One profile over all records of a FASTA handle (kpal/klib.py:97-112).
+
+        The text is handed to the GPU in chunks of whole records; header removal, line joining
+        and record separation happen on the device (``kpal_count_feed_fasta``), so there is no
+        per-character or per-line Python work."""
+        length = int(length)
+        if length < 1 or length > _native.KPAL_MAX_K:
+            raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
+        ctx = _native.context()
+        ctx.count_begin(length)
+        pending = b''
+        while True:
+            text = handle.read(_FASTA_CHUNK)
+            if not text:
+                break
+            pending += text if isinstance(text, bytes) else text.encode('latin-1', 'replace')
+            # keep the (possibly unfinished) last record for the next round
+            cut = max(pending.rfind(b'\n>'), pending.rfind(b'\r>'))
+            if cut > 0:
+                ctx.count_feed_fasta(pending[:cut + 1])
+                pending = pending[cut + 1:]
+        if pending:
+            ctx.count_feed_fasta(pending)
+        return cls(ctx.count_finish(), name=name)
 
     @classmethod
     def from_fasta_by_record(cls, handle, length, prefix=None):

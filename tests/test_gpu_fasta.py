@@ -1,0 +1,102 @@
+"""FASTA ingest on the device (kpal_count_feed_fasta / kpal_fasta_flatten) against the host-side
+tokeniser kpal_amd.klib._fasta_records (the rules are listed in csrc/fasta_kernels.hpp) and the
+oracle's counts.  Run on the GPU box: pytest -m gpu."""
+import io
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from kpal_amd import _native
+    return _native.context()
+
+
+def expected_flat(text):
+    from kpal_amd import klib
+    recs = list(klib._fasta_records(io.StringIO(text, newline='')))   # newline='': keep \r as data
+    return b''.join(b'\n' + seq.encode('latin-1') for _, seq in recs)
+
+
+def random_fasta(rnd, n_records, max_len, eol='\n'):
+    parts = []
+    if rnd.random() < 0.3:
+        parts.append('leading junk ACGT' + eol)
+    for r in range(n_records):
+        title = ''.join(rnd.choice('abc >|_0123') for _ in range(rnd.choice([0, 3, 20, 200])))
+        if rnd.random() < 0.05:
+            title += 'x' * 5000                      # header longer than a 4 KiB block
+        parts.append('>' + title + eol)
+        n = rnd.choice([0, 1, 5, rnd.randint(0, max_len)])
+        seq = ''.join(rnd.choice('ACGT' * 6 + 'acgtNnRY->') for _ in range(n))
+        width = rnd.choice([1, 7, 60, 70, 80, 10 ** 9])
+        for i in range(0, len(seq), width):
+            line = seq[i:i + width]
+            if rnd.random() < 0.1:
+                line = line[:len(line) // 2] + rnd.choice([' ', '\t', '  ']) + line[len(line) // 2:]
+            parts.append(line + (eol if rnd.random() < 0.97 else eol + eol))
+    text = ''.join(parts)
+    if rnd.random() < 0.3:
+        text = text.rstrip('\r\n')                   # no trailing newline
+    return text
+
+
+def test_flatten_matches_host_tokeniser(ctx):
+    rnd = random.Random(5)
+    cases = ['', 'no header at all\nACGT\n', '>only header', '>h\n', '>h\nACGT', '>a\nAC\nGT\n>b\n\n>c\nTT',
+             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\n', 'x\n>a\nAC>GT\n>b\n A C\tG T \n']
+    for _ in range(60):
+        cases.append(random_fasta(rnd, rnd.randint(1, 12), 3000, eol=rnd.choice(['\n', '\n', '\r\n'])))
+    for _ in range(6):
+        cases.append(random_fasta(rnd, rnd.randint(1, 4), 60000))   # many 4 KiB blocks, long single-line records
+    for text in cases:
+        got = ctx.fasta_flatten(text.encode('latin-1'))
+        assert got == expected_flat(text), repr(text[:200])
+
+
+def test_from_fasta_counts(ctx, tutorial_dir):
+    from kpal_amd import klib
+    rnd = random.Random(9)
+    for k in (3, 8, 12):
+        text = random_fasta(rnd, 30, 5000)
+        p = klib.Profile.from_fasta(io.StringIO(text), k)
+        seqs = [s for _, s in klib._fasta_records(io.StringIO(text))]
+        np.testing.assert_array_equal(p.counts, oracle.from_sequences(seqs, k))
+    # binary handle and a real file (60-column wrapped tutorial data)
+    path = os.path.join(tutorial_dir, 'a_1.fa')
+    with open(path, 'rb') as fb, open(path) as ft:
+        pb = klib.Profile.from_fasta(fb, 8)
+        pt = klib.Profile.from_fasta(ft, 8)
+    np.testing.assert_array_equal(pb.counts, pt.counts)
+    assert (int(pb.total), int(pb.non_zero)) == (18600, 16141)     # doc/tutorial.rst:44-58
+
+
+def test_from_fasta_chunked_reads(ctx, monkeypatch):
+    """Records straddling read chunks: the host cuts feeds back to a record boundary."""
+    from kpal_amd import klib
+    rnd = random.Random(13)
+    text = random_fasta(rnd, 400, 900)
+    seqs = [s for _, s in klib._fasta_records(io.StringIO(text))]
+    want = oracle.from_sequences(seqs, 9)
+    for chunk in (1 << 10, 4097, 1 << 16):
+        monkeypatch.setattr(klib, '_FASTA_CHUNK', chunk)
+        p = klib.Profile.from_fasta(io.StringIO(text), 9)
+        np.testing.assert_array_equal(p.counts, want)
+
+
+def test_large_single_record(ctx):
+    """One 30 Mbase record wrapped at 60 columns: line joins across thousands of blocks."""
+    buf = oracle.synth_reads(17, 0, 200000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    lines = seq.reshape(-1, 60)
+    text = b'>chr1 synthetic\n' + b'\n'.join(bytes(l) for l in lines) + b'\n'
+    from kpal_amd import klib
+    p = klib.Profile.from_fasta(io.BytesIO(text), 12)
+    np.testing.assert_array_equal(p.counts, oracle.count_flat(seq, 12, threads=8))
