@@ -22,12 +22,9 @@ namespace kpal {
 
 constexpr int kPartBits = 9;
 constexpr int kNumBuckets = 1 << kPartBits;  // 512
-constexpr int kScatterThreads = 512;         // 8 waves; two workgroups per CU (LDS 70 KiB each)
+constexpr int kScatterThreads = 512;         // count kernels: 8 waves, two workgroups per CU
 constexpr int kScatterWaves = kScatterThreads / 64;
-constexpr int kScatterSteps = 3;             // wave-steps per wave per tile (24 KiB of input per tile)
-constexpr int kBucketsPerWave = kNumBuckets / kScatterWaves;  // 64: copy-out share of a wave
-constexpr int kSlotCap = 64;  // LDS staging slots per bucket per tile (mean fill 44 for 150 bp reads)
-constexpr int kStepsPerBlockQuantum = kScatterWaves * kScatterSteps;  // block ranges are multiples of 24 steps
+constexpr int kStepsPerBlockQuantum = 16;  // block ranges: whole steps for 8 (count) and 16 (scatter) waves
 
 template <int K>
 struct PartCfg {
@@ -42,86 +39,6 @@ __device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &c
     const int lane = threadIdx.x & 63;
     if (interior_range(s, step * 64, step * 64 + 64)) wave_step<K, false>(s, (int64_t)(step * 64 + lane), carry, window, mask);
     else wave_step<K, true>(s, (int64_t)(step * 64 + lane), carry, window, mask);
-}
-
-// ------------------------------------------------------------------------------------------
-// LDS staging shared by the two scatter kernels (ASCII source and residual-key source).
-//   rows : 512 rows x 64 u16 slots (64 KiB), slot index rotated by the bucket so that buckets
-//          filling in lock-step hit different banks; one dummy halfword after the rows
-//   pos  : slots taken per bucket in the current tile
-//   gcur : global cursor (key index) per bucket
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t kRowsBytes = kNumBuckets * kSlotCap * 2;
-
-// Place 16 values v[j] = (bucket << KB) | key; bit (15-j) of `valid` says whether v[j] counts.
-// 16 returning ds_add are in flight (an uncounted value adds 0 and its store is diverted to the
-// dummy halfword), then 16 ds_write_b16.  Slots >= kSlotCap -- rare for unskewed input, the
-// whole stream for a homopolymer -- are stored straight to their final global position.
-template <int KB>
-__device__ __forceinline__ void place16(unsigned char *rows, uint32_t *pos, const uint64_t *gcur,
-                                        uint16_t *__restrict__ keys_out, const uint32_t (&v)[16], uint32_t valid)
-{
-    constexpr uint32_t kKeyMask = (1u << KB) - 1u;
-    uint32_t slot[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;  // 4 * bucket
-        slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (valid >> (15 - j)) & 1u);
-    }
-    uint32_t smax = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;
-        const uint32_t x = slot[j] | (((~valid >> (15 - j)) & 1u) << 6);      // >= 64: not counted, or row full
-        const uint32_t at = ((2u * slot[j] + b4) & 126u) | (b4 << 5);        // byte offset of the rotated slot
-        *(uint16_t *)(rows + (x < 64u ? at : kRowsBytes)) = (uint16_t)(v[j] & kKeyMask);
-        smax = max(smax, slot[j]);
-    }
-    if (smax >= (uint32_t)kSlotCap) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (((valid >> (15 - j)) & 1u) && slot[j] >= (uint32_t)kSlotCap)
-                keys_out[gcur[v[j] >> KB] + slot[j]] = (uint16_t)(v[j] & kKeyMask);
-        }
-    }
-}
-
-// Copy-out of one tile.  Wave w owns buckets [64w, 64w+64); lane l holds bucket 64w+l's byte
-// count and global byte address.  Per bucket: three v_readlane build a buffer descriptor
-// {base = run start, num_records = run bytes} in SGPRs and ONE buffer_store_short writes the
-// staged row -- lanes beyond the run are dropped by the hardware range check, so there is no
-// exec-mask juggling and no branch.  Then the cursors advance by the full slot count.
-__device__ __forceinline__ void copy_out_tile(const unsigned char *rows, uint32_t *pos, uint64_t *gcur,
-                                              uint16_t *__restrict__ keys_out)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = wave * kBucketsPerWave;
-    const int mine = first + lane;
-    const uint32_t my_n = pos[mine];
-    const uint64_t my_g = gcur[mine];
-    const uint64_t my_addr = (uint64_t)keys_out + 2ULL * my_g;
-    const uint32_t my_lo = (uint32_t)my_addr, my_hi = (uint32_t)(my_addr >> 32);
-    const uint32_t my_bytes = 2u * min(my_n, (uint32_t)kSlotCap);
-    const uint32_t r0 = 2u * lane + 4u * first;
-    const unsigned char *wrows = rows + (uint32_t)first * 128u;
-#pragma unroll
-    for (int i0 = 0; i0 < kBucketsPerWave; i0 += 8) {
-        uint16_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)   // unconditional LDS reads first (8 in flight)
-            v[u] = *(const uint16_t *)(wrows + (i0 + u) * 128 + ((r0 + 4u * (i0 + u)) & 126u));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t lo = __builtin_amdgcn_readlane(my_lo, i0 + u);
-            const uint32_t hi = __builtin_amdgcn_readlane(my_hi, i0 + u);
-            const uint32_t nb = __builtin_amdgcn_readlane(my_bytes, i0 + u);
-            __amdgpu_buffer_rsrc_t rsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b16((short)v[u], rsrc, 2 * lane, 0, 0);
-        }
-    }
-    gcur[mine] = my_g + my_n;
-    pos[mine] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -230,43 +147,201 @@ __global__ __launch_bounds__(kNumBuckets) void part_bucketscan_kernel(const uint
     if (threadIdx.x == n - 1) out[n] = off + incl;
 }
 
-// A3: scatter of an ASCII span.  Per tile (3 steps per wave, 24 KiB per workgroup): place, barrier,
-// copy-out, barrier.  Bound by the global store-run rate (one ~88-byte run per bucket per tile).
-template <int K>
-__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_block,
-                                                                       const uint32_t *__restrict__ offs32,
-                                                                       const uint64_t *__restrict__ bucket_start,
-                                                                       uint16_t *__restrict__ keys_out)
+// ------------------------------------------------------------------------------------------
+// A3: scatter.  Measured (tools/store_bench2.hip): a scattered, unaligned ~88-byte run
+// costs ~26-38 clk per CU in the store path, a full aligned 128-byte line ~14 clk.  So the rows
+// persist across tiles and only whole aligned lines leave the CU:
+//   * one 1024-thread workgroup per CU; 512 rows x 128 slots (256 B) = 128 KiB of LDS;
+//     row slot i corresponds to global key index gline[b] + i, gline[b] a multiple of 64;
+//   * a tile is ONE step per wave (16 KiB of input, ~30 new keys per bucket), so a row that
+//     holds < 64 leftover keys cannot overflow its 128 slots on unskewed input;
+//   * after every tile wave w flushes, for each of its 32 rows that holds >= 64 keys, line 0
+//     (64 keys = one aligned 128-byte line: 8 lanes x ds_read_b128 + global_store_dwordx4, eight
+//     rows per instruction), moves the < 64 leftover keys down and advances gline by 64;
+//   * lo (kept in the low six bits of gline[b]) marks slots of the current line that must not be stored (the part of the first line
+//     that belongs to the previous block's segment, or keys that went out directly);
+//   * slots >= 128 (skew) are stored directly at gline[b] + slot; the row logic accounts for them.
+// ------------------------------------------------------------------------------------------
+constexpr int kLineThreads = 1024;
+constexpr int kLineWaves = kLineThreads / 64;
+constexpr uint32_t kLineSlots = 128;
+constexpr uint32_t kLineRowBytes = kLineSlots * 2;
+constexpr uint32_t kLineRowsBytes = kNumBuckets * kLineRowBytes;  // 128 KiB
+
+template <int KB>
+__device__ __forceinline__ void place16_lines(unsigned char *rows, uint32_t *pos, const uint64_t *gline,
+                                              uint16_t *__restrict__ keys_out, const uint32_t (&v)[16], uint32_t valid)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char rows[kRowsBytes + 16];
+    constexpr uint32_t kKeyMask = (1u << KB) - 1u;
+    uint32_t slot[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;  // 4 * bucket
+        slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (valid >> (15 - j)) & 1u);
+    }
+    uint32_t smax = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;
+        const uint32_t x = slot[j] | (((~valid >> (15 - j)) & 1u) << 7);     // >= 128: not counted, or row full
+        const uint32_t rot = (b4 << 2) & 0xF0u;                               // 16 * (bucket % 16): bank spread
+        const uint32_t at = ((2u * slot[j] + rot) & 254u) | (b4 << 6);        // row base = bucket * 256
+        *(uint16_t *)(rows + (x < kLineSlots ? at : kLineRowsBytes)) = (uint16_t)(v[j] & kKeyMask);
+        smax = max(smax, slot[j]);
+    }
+    if (smax >= kLineSlots) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (((valid >> (15 - j)) & 1u) && slot[j] >= kLineSlots)
+                keys_out[(gline[v[j] >> KB] & ~63ULL) + slot[j]] = (uint16_t)(v[j] & kKeyMask);
+        }
+    }
+}
+
+// Flush phase of one tile (see above).  Eight lanes share a row: lane = (row_in_group << 3) | piece,
+// a piece is 8 slots = 16 bytes.  gline[row] holds the row's aligned base key index with lo (< 64)
+// in its low six bits.  The common case -- exactly one complete line, lo == 0 -- is branch-free
+// apart from the store predicate; everything else (first line of a segment, rows that overflowed,
+// the final partial line) goes through flush_rows_slow under a wave-uniform test.
+__device__ __forceinline__ void flush_rows_slow(unsigned char *rb, uint32_t rot, uint32_t piece, uint32_t n, uint64_t glw,
+                                                uint32_t *pos_row, uint64_t *gline_row, uint16_t *__restrict__ keys_out,
+                                                bool final)
+{
+    const uint32_t l0 = (uint32_t)(glw & 63);
+    const uint64_t gl = glw & ~63ULL;
+    const uint32_t L = n >> 6, r = n & 63;
+    const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
+    const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
+    if (L >= 1) {
+        const uint16_t *k = (const uint16_t *)&line0;
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e)
+            if (8 * piece + e >= l0) keys_out[gl + 8 * piece + e] = k[e];
+        if (L >= 2) *(uint4 *)(keys_out + gl + 64 + 8 * piece) = line1;
+        if (L == 1 && 8 * piece < r) *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;   // leftover moves down
+    }
+    uint32_t new_n = n, new_lo = l0;
+    uint64_t new_gl = gl;
+    if (L >= 1) {
+        new_n = r;
+        new_lo = L >= 2 ? r : 0u;      // with L >= 2 the remainder went out directly
+        new_gl = gl + 64ull * L;
+    }
+    if (final && new_n > new_lo && L <= 1) {
+        // unfinished last line of this block's segment: slots [new_lo, new_n)
+        const uint4 cur = (L == 1) ? line1 : line0;
+        const uint16_t *k = (const uint16_t *)&cur;
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t sl = 8 * piece + e;
+            if (sl >= new_lo && sl < new_n) keys_out[new_gl + sl] = k[e];
+        }
+    }
+    if (piece == 0) {
+        *pos_row = new_n;
+        *gline_row = new_gl | new_lo;
+    }
+}
+
+__device__ __forceinline__ void flush_lines(unsigned char *rows, uint32_t *pos, uint64_t *gline,
+                                            uint16_t *__restrict__ keys_out, bool final)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t piece = lane & 7;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t row = wave * 32 + g * 8 + (lane >> 3);
+        const uint32_t n = pos[row];
+        const uint64_t glw = gline[row];
+        const uint32_t rot = (row & 15u) << 4;
+        unsigned char *rb = rows + row * kLineRowBytes;
+        const bool fast = (n >> 6) == 1 && (glw & 63) == 0;
+        const bool slow = !fast && ((n >> 6) >= 1 || final);
+        if (__builtin_expect(__any(slow), 0)) {          // wave-uniform
+            if (slow || fast) flush_rows_slow(rb, rot, piece, n, glw, &pos[row], &gline[row], keys_out, final);
+            continue;
+        }
+        const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
+        const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
+        const uint32_t r = n & 63;
+        if (fast) {
+            *(uint4 *)(keys_out + glw + 8 * piece) = line0;                     // one aligned 128-byte line per 8 lanes
+            if (8 * piece < r) *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;   // leftover moves down
+            if (piece == 0) {
+                pos[row] = r;
+                gline[row] = glw + 64;
+            }
+        }
+    }
+}
+
+// Diagnostic stamp (only in the STAMP build; never in the product launch).
+__device__ __forceinline__ unsigned long long phase_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// vector-memory counter, so the line stores issued in the flush phase stay in flight while the
+// next tile is encoded and placed (the two phases use different hardware: HBM writes vs LDS).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int K, bool STAMP = false>
+__global__ __launch_bounds__(kLineThreads) void part_scatter_lines_kernel(Span s, uint64_t steps_per_block,
+                                                                          const uint32_t *__restrict__ offs32,
+                                                                          const uint64_t *__restrict__ bucket_start,
+                                                                          uint16_t *__restrict__ keys_out,
+                                                                          unsigned long long *__restrict__ dbg = nullptr)
+{
+    unsigned long long acc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kLineRowsBytes + 16];
     __shared__ uint32_t pos[kNumBuckets];
-    __shared__ uint64_t gcur[kNumBuckets];
-    static_assert(kScatterThreads == kNumBuckets && kSlotCap == 64, "one lane per slot, one thread per bucket");
-    const int wave = threadIdx.x >> 6;
-    gcur[threadIdx.x] = bucket_start[threadIdx.x] + offs32[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
-    pos[threadIdx.x] = 0;
-    __syncthreads();
+    __shared__ uint64_t gline[kNumBuckets];   // aligned base key index | lo (low six bits)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t total_steps = (s.nchunks + 63) / 64;
-    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
     const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
+    if (block_step0 >= total_steps) return;   // block-uniform; such a block owns no keys
+    if (threadIdx.x < kNumBuckets) {
+        const uint64_t g0 = bucket_start[threadIdx.x] + offs32[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
+        gline[threadIdx.x] = g0;               // = (g0 - skew) | skew: the first line starts at slot skew
+        pos[threadIdx.x] = (uint32_t)(g0 & 63);
+    }
+    __syncthreads();
+    const uint64_t steps_per_wave = steps_per_block / kLineWaves;
     const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
     Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
-    for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
+    uint4 raw = fetch_chunk(s, (int64_t)(step0 * 64 + lane));
+    for (uint64_t t = 0; t < steps_per_wave; ++t) {
         if (block_step0 + t >= total_steps) break;  // block-uniform: wave 0 owns the lowest addresses
-        uint64_t window[kScatterSteps];
-        uint32_t mask[kScatterSteps];
+        uint64_t window;
+        uint32_t mask;
+        if constexpr (STAMP) t0 = phase_stamp();
+        encode_step<K>(s, step0 + t, raw, carry, window, mask);
+        if (t + 1 < steps_per_wave) raw = fetch_chunk(s, (int64_t)((step0 + t + 1) * 64 + lane));   // lands during placement
+        if constexpr (STAMP) { asm volatile("" ::"v"(window)); t1 = phase_stamp(); acc[0] += t1 - t0; t0 = t1; }
+        uint32_t v[16];
 #pragma unroll
-        for (int st = 0; st < kScatterSteps; ++st) part_step<K>(s, step0 + t + st, carry, window[st], mask[st]);
-#pragma unroll
-        for (int st = 0; st < kScatterSteps; ++st) {
-            uint32_t v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window[st], j);
-            place16<PartCfg<K>::kKeyBits>(rows, pos, gcur, keys_out, v, mask[st]);
-        }
-        __syncthreads();
-        copy_out_tile(rows, pos, gcur, keys_out);
-        __syncthreads();
+        for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window, j);
+        place16_lines<PartCfg<K>::kKeyBits>(rows, pos, gline, keys_out, v, mask);
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[1] += t1 - t0; t0 = t1; }
+        lds_barrier();
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[2] += t1 - t0; t0 = t1; }
+        flush_lines(rows, pos, gline, keys_out, false);
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[3] += t1 - t0; t0 = t1; }
+        lds_barrier();
+        if constexpr (STAMP) { t1 = phase_stamp(); acc[4] += t1 - t0; }
+    }
+    flush_lines(rows, pos, gline, keys_out, true);
+    if constexpr (STAMP) {
+        if (lane == 0)
+            for (int q = 0; q < 5; ++q) dbg[((uint64_t)blockIdx.x * kLineWaves + wave) * 5 + q] = acc[q];
     }
 }
 
@@ -498,7 +573,7 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
 // block, a multiple of 8 waves x 3 macro-steps x 1024 keys); a macro-step is 16 keys per lane
 // (four coalesced 1 KiB loads per wave).
 constexpr uint32_t kMacroKeys = 1024;   // keys per wave macro-step
-constexpr uint32_t kKeysPerBlockQuantum = kScatterWaves * kScatterSteps * kMacroKeys;  // 24576
+constexpr uint32_t kKeysPerBlockQuantum = 16 * kMacroKeys;  // 16384: whole macro-steps for 8 (count) and 16 (scatter) waves
 
 __device__ __forceinline__ void load_macro(const uint32_t *__restrict__ res, uint64_t lo, uint64_t hi, uint64_t at,
                                            uint32_t (&v)[16], uint32_t &valid)
@@ -562,38 +637,39 @@ __global__ __launch_bounds__(kScatterThreads) void key_count_kernel(const uint32
     flush_bucket_counts(cnt, out, G);
 }
 
-__global__ __launch_bounds__(kScatterThreads) void key_scatter_kernel(const uint32_t *__restrict__ res,
-                                                                      const uint64_t *__restrict__ start1,
-                                                                      uint32_t keys_per_block,
-                                                                      const uint32_t *__restrict__ offs2,
-                                                                      const uint64_t *__restrict__ bucket_start2,
-                                                                      uint16_t *__restrict__ keys_out)
+__global__ __launch_bounds__(kLineThreads) void key_scatter_kernel(const uint32_t *__restrict__ res,
+                                                                   const uint64_t *__restrict__ start1,
+                                                                   uint32_t keys_per_block,
+                                                                   const uint32_t *__restrict__ offs2,
+                                                                   const uint64_t *__restrict__ bucket_start2,
+                                                                   uint16_t *__restrict__ keys_out)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char rows[kRowsBytes + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kLineRowsBytes + 16];
     __shared__ uint32_t pos[kNumBuckets];
-    __shared__ uint64_t gcur[kNumBuckets];
+    __shared__ uint64_t gline[kNumBuckets];
     const uint32_t c = blockIdx.y, G = gridDim.x;
     const uint64_t lo = start1[c], n = start1[c + 1] - lo;
     const uint64_t b0 = (uint64_t)blockIdx.x * keys_per_block;
     if (b0 >= n) return;  // block-uniform
-    gcur[threadIdx.x] = bucket_start2[(uint64_t)c * (kNumBuckets + 1) + threadIdx.x] +
-                        offs2[((uint64_t)c * kNumBuckets + threadIdx.x) * G + blockIdx.x];
-    pos[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t per_wave = keys_per_block / kScatterWaves;
-    const uint64_t w0 = b0 + (uint64_t)(threadIdx.x >> 6) * per_wave;
-    for (uint64_t t = 0; t < per_wave; t += (uint64_t)kScatterSteps * kMacroKeys) {
-        if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest keys
-#pragma unroll
-        for (int st = 0; st < kScatterSteps; ++st) {
-            uint32_t v[16], valid;
-            load_macro(res, lo, n, w0 + t + (uint64_t)st * kMacroKeys, v, valid);
-            place16<kResKeyBits>(rows, pos, gcur, keys_out, v, valid);
-        }
-        __syncthreads();
-        copy_out_tile(rows, pos, gcur, keys_out);
-        __syncthreads();
+    if (threadIdx.x < kNumBuckets) {
+        const uint64_t g0 = bucket_start2[(uint64_t)c * (kNumBuckets + 1) + threadIdx.x] +
+                            offs2[((uint64_t)c * kNumBuckets + threadIdx.x) * G + blockIdx.x];
+        gline[threadIdx.x] = g0;
+        pos[threadIdx.x] = (uint32_t)(g0 & 63);
     }
+    __syncthreads();
+    const uint64_t per_wave = keys_per_block / kLineWaves;
+    const uint64_t w0 = b0 + (uint64_t)(threadIdx.x >> 6) * per_wave;
+    for (uint64_t t = 0; t < per_wave; t += kMacroKeys) {
+        if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest keys
+        uint32_t v[16], valid;
+        load_macro(res, lo, n, w0 + t, v, valid);
+        place16_lines<kResKeyBits>(rows, pos, gline, keys_out, v, valid);
+        lds_barrier();
+        flush_lines(rows, pos, gline, keys_out, false);
+        lds_barrier();
+    }
+    flush_lines(rows, pos, gline, keys_out, true);
 }
 
 }  // namespace kpal
