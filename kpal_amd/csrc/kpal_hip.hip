@@ -424,7 +424,7 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    // steps per block: whole steps for the 8-wave count and the 16-wave scatter kernels, ~4 blocks per CU
+    // steps per block: a multiple of 24 (8 waves x 3 steps per tile), ~4 blocks per CU
     const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
     uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
     spb = (spb + kStepsPerBlockQuantum - 1) / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
@@ -447,25 +447,8 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
         LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal,
                (uint32_t)kNumBuckets, no_base, bstart);
-        if (getenv("KPAL_STAMP")) {   // diagnostic build: per-phase s_memtime sums
-            unsigned long long *dbg = nullptr;
-            HIPCHK(hipMalloc(&dbg, (size_t)G * kLineWaves * 5 * 8));
-            HIPCHK(hipMemset(dbg, 0, (size_t)G * kLineWaves * 5 * 8));
-            LAUNCH(ctx, "part_scatter_stamp", (part_scatter_lines_kernel<K, true>), dim3(G), dim3(kLineThreads), s, spb,
-                   (const uint32_t *)offs, (const uint64_t *)bstart, keys, dbg);
-            std::vector<unsigned long long> h((size_t)G * kLineWaves * 5);
-            HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-            HIPCHK(hipFree(dbg));
-            double sum[5] = {0, 0, 0, 0, 0};
-            for (size_t i = 0; i < h.size(); ++i) sum[i % 5] += (double)h[i];
-            const double nw = (double)G * kLineWaves;
-            fprintf(stderr, "[stamp] per-wave mean cycles: encode %.0f  place %.0f  barrier1 %.0f  flush %.0f  barrier2 %.0f (steps/wave %llu)\n",
-                    sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, (unsigned long long)(spb / kLineWaves));
-        } else {
-            unsigned long long *nodbg = nullptr;
-            LAUNCH(ctx, "part_scatter", (part_scatter_lines_kernel<K, false>), dim3(G), dim3(kLineThreads), s, spb,
-                   (const uint32_t *)offs, (const uint64_t *)bstart, keys, nodbg);
-        }
+        LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb,
+               (const uint32_t *)offs, (const uint64_t *)bstart, keys);
         LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kNumBuckets * slices), dim3(1024),
                (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
     });

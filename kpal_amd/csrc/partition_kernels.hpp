@@ -22,9 +22,12 @@ namespace kpal {
 
 constexpr int kPartBits = 9;
 constexpr int kNumBuckets = 1 << kPartBits;  // 512
-constexpr int kScatterThreads = 512;         // count kernels: 8 waves, two workgroups per CU
+constexpr int kScatterThreads = 512;         // 8 waves; two workgroups per CU
 constexpr int kScatterWaves = kScatterThreads / 64;
-constexpr int kStepsPerBlockQuantum = 16;  // block ranges: whole steps for 8 (count) and 16 (scatter) waves
+constexpr int kScatterSteps = 3;             // wave-steps per wave per tile (24 KiB of input per tile)
+constexpr int kBucketsPerWave = kNumBuckets / kScatterWaves;  // 64: copy-out share of a wave
+constexpr int kSlotCap = 64;  // LDS staging slots per bucket per tile (mean fill 44 for 150 bp reads)
+constexpr int kStepsPerBlockQuantum = kScatterWaves * kScatterSteps;  // block ranges are multiples of 24 steps
 
 template <int K>
 struct PartCfg {
@@ -39,6 +42,86 @@ __device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &c
     const int lane = threadIdx.x & 63;
     if (interior_range(s, step * 64, step * 64 + 64)) wave_step<K, false>(s, (int64_t)(step * 64 + lane), carry, window, mask);
     else wave_step<K, true>(s, (int64_t)(step * 64 + lane), carry, window, mask);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS staging of the ASCII scatter kernel (per-tile rows, one run per bucket per tile).
+//   rows : 512 rows x 64 u16 slots (64 KiB), slot index rotated by the bucket so that buckets
+//          filling in lock-step hit different banks; one dummy halfword after the rows
+//   pos  : slots taken per bucket in the current tile
+//   gcur : global cursor (key index) per bucket
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kRowsBytes = kNumBuckets * kSlotCap * 2;
+
+// Place 16 values v[j] = (bucket << KB) | key; bit (15-j) of `valid` says whether v[j] counts.
+// 16 returning ds_add are in flight (an uncounted value adds 0 and its store is diverted to the
+// dummy halfword), then 16 ds_write_b16.  Slots >= kSlotCap -- rare for unskewed input, the
+// whole stream for a homopolymer -- are stored straight to their final global position.
+template <int KB>
+__device__ __forceinline__ void place16(unsigned char *rows, uint32_t *pos, const uint64_t *gcur,
+                                        uint16_t *__restrict__ keys_out, const uint32_t (&v)[16], uint32_t valid)
+{
+    constexpr uint32_t kKeyMask = (1u << KB) - 1u;
+    uint32_t slot[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;  // 4 * bucket
+        slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (valid >> (15 - j)) & 1u);
+    }
+    uint32_t smax = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;
+        const uint32_t x = slot[j] | (((~valid >> (15 - j)) & 1u) << 6);      // >= 64: not counted, or row full
+        const uint32_t at = ((2u * slot[j] + b4) & 126u) | (b4 << 5);        // byte offset of the rotated slot
+        *(uint16_t *)(rows + (x < 64u ? at : kRowsBytes)) = (uint16_t)(v[j] & kKeyMask);
+        smax = max(smax, slot[j]);
+    }
+    if (smax >= (uint32_t)kSlotCap) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (((valid >> (15 - j)) & 1u) && slot[j] >= (uint32_t)kSlotCap)
+                keys_out[gcur[v[j] >> KB] + slot[j]] = (uint16_t)(v[j] & kKeyMask);
+        }
+    }
+}
+
+// Copy-out of one tile.  Wave w owns buckets [64w, 64w+64); lane l holds bucket 64w+l's byte
+// count and global byte address.  Per bucket: three v_readlane build a buffer descriptor
+// {base = run start, num_records = run bytes} in SGPRs and ONE buffer_store_short writes the
+// staged row -- lanes beyond the run are dropped by the hardware range check, so there is no
+// exec-mask juggling and no branch.  Then the cursors advance by the full slot count.
+__device__ __forceinline__ void copy_out_tile(const unsigned char *rows, uint32_t *pos, uint64_t *gcur,
+                                              uint16_t *__restrict__ keys_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = wave * kBucketsPerWave;
+    const int mine = first + lane;
+    const uint32_t my_n = pos[mine];
+    const uint64_t my_g = gcur[mine];
+    const uint64_t my_addr = (uint64_t)keys_out + 2ULL * my_g;
+    const uint32_t my_lo = (uint32_t)my_addr, my_hi = (uint32_t)(my_addr >> 32);
+    const uint32_t my_bytes = 2u * min(my_n, (uint32_t)kSlotCap);
+    const uint32_t r0 = 2u * lane + 4u * first;
+    const unsigned char *wrows = rows + (uint32_t)first * 128u;
+#pragma unroll
+    for (int i0 = 0; i0 < kBucketsPerWave; i0 += 8) {
+        uint16_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)   // unconditional LDS reads first (8 in flight)
+            v[u] = *(const uint16_t *)(wrows + (i0 + u) * 128 + ((r0 + 4u * (i0 + u)) & 126u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t lo = __builtin_amdgcn_readlane(my_lo, i0 + u);
+            const uint32_t hi = __builtin_amdgcn_readlane(my_hi, i0 + u);
+            const uint32_t nb = __builtin_amdgcn_readlane(my_bytes, i0 + u);
+            __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b16((short)v[u], rsrc, 2 * lane, 0, 0);
+        }
+    }
+    gcur[mine] = my_g + my_n;
+    pos[mine] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,7 +231,7 @@ __global__ __launch_bounds__(kNumBuckets) void part_bucketscan_kernel(const uint
 }
 
 // ------------------------------------------------------------------------------------------
-// A3: scatter.  Measured (tools/store_bench2.hip): a scattered, unaligned ~88-byte run
+// Aligned-line staging (used by the level-2 key scatter of the two-level path).  Measured (tools/store_bench2.hip): a scattered, unaligned ~88-byte run
 // costs ~26-38 clk per CU in the store path, a full aligned 128-byte line ~14 clk.  So the rows
 // persist across tiles and only whole aligned lines leave the CU:
 //   * one 1024-thread workgroup per CU; 512 rows x 128 slots (256 B) = 128 KiB of LDS;
@@ -261,12 +344,14 @@ __device__ __forceinline__ void flush_lines(unsigned char *rows, uint32_t *pos, 
             if (slow || fast) flush_rows_slow(rb, rot, piece, n, glw, &pos[row], &gline[row], keys_out, final);
             continue;
         }
-        const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
-        const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
         const uint32_t r = n & 63;
-        if (fast) {
+        if (fast) {   // only the lanes of flushing rows touch LDS (roughly half of them per tile)
+            const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
             *(uint4 *)(keys_out + glw + 8 * piece) = line0;                     // one aligned 128-byte line per 8 lanes
-            if (8 * piece < r) *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;   // leftover moves down
+            if (8 * piece < r) {                                                // leftover moves down
+                const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
+                *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;
+            }
             if (piece == 0) {
                 pos[row] = r;
                 gline[row] = glw + 64;
@@ -275,73 +360,51 @@ __device__ __forceinline__ void flush_lines(unsigned char *rows, uint32_t *pos, 
     }
 }
 
-// Diagnostic stamp (only in the STAMP build; never in the product launch).
-__device__ __forceinline__ unsigned long long phase_stamp()
-{
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
-// vector-memory counter, so the line stores issued in the flush phase stay in flight while the
-// next tile is encoded and placed (the two phases use different hardware: HBM writes vs LDS).
+// vector-memory counter, so line stores issued in a flush phase stay in flight while the next
+// tile is placed.
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, bool STAMP = false>
-__global__ __launch_bounds__(kLineThreads) void part_scatter_lines_kernel(Span s, uint64_t steps_per_block,
-                                                                          const uint32_t *__restrict__ offs32,
-                                                                          const uint64_t *__restrict__ bucket_start,
-                                                                          uint16_t *__restrict__ keys_out,
-                                                                          unsigned long long *__restrict__ dbg = nullptr)
+// A3: scatter of an ASCII span.  Per tile (3 steps per wave, 24 KiB per workgroup): place, barrier,
+// copy-out, barrier.  Bound by the global store-run rate (one ~88-byte run per bucket per tile).
+template <int K>
+__global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, uint64_t steps_per_block,
+                                                                       const uint32_t *__restrict__ offs32,
+                                                                       const uint64_t *__restrict__ bucket_start,
+                                                                       uint16_t *__restrict__ keys_out)
 {
-    unsigned long long acc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[kLineRowsBytes + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kRowsBytes + 16];
     __shared__ uint32_t pos[kNumBuckets];
-    __shared__ uint64_t gline[kNumBuckets];   // aligned base key index | lo (low six bits)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t total_steps = (s.nchunks + 63) / 64;
-    const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
-    if (block_step0 >= total_steps) return;   // block-uniform; such a block owns no keys
-    if (threadIdx.x < kNumBuckets) {
-        const uint64_t g0 = bucket_start[threadIdx.x] + offs32[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
-        gline[threadIdx.x] = g0;               // = (g0 - skew) | skew: the first line starts at slot skew
-        pos[threadIdx.x] = (uint32_t)(g0 & 63);
-    }
+    __shared__ uint64_t gcur[kNumBuckets];
+    static_assert(kScatterThreads == kNumBuckets && kSlotCap == 64, "one lane per slot, one thread per bucket");
+    const int wave = threadIdx.x >> 6;
+    gcur[threadIdx.x] = bucket_start[threadIdx.x] + offs32[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
+    pos[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t steps_per_wave = steps_per_block / kLineWaves;
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
+    const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
     const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
     Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
-    uint4 raw = fetch_chunk(s, (int64_t)(step0 * 64 + lane));
-    for (uint64_t t = 0; t < steps_per_wave; ++t) {
+    for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
         if (block_step0 + t >= total_steps) break;  // block-uniform: wave 0 owns the lowest addresses
-        uint64_t window;
-        uint32_t mask;
-        if constexpr (STAMP) t0 = phase_stamp();
-        encode_step<K>(s, step0 + t, raw, carry, window, mask);
-        if (t + 1 < steps_per_wave) raw = fetch_chunk(s, (int64_t)((step0 + t + 1) * 64 + lane));   // lands during placement
-        if constexpr (STAMP) { asm volatile("" ::"v"(window)); t1 = phase_stamp(); acc[0] += t1 - t0; t0 = t1; }
-        uint32_t v[16];
+        uint64_t window[kScatterSteps];
+        uint32_t mask[kScatterSteps];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window, j);
-        place16_lines<PartCfg<K>::kKeyBits>(rows, pos, gline, keys_out, v, mask);
-        if constexpr (STAMP) { t1 = phase_stamp(); acc[1] += t1 - t0; t0 = t1; }
-        lds_barrier();
-        if constexpr (STAMP) { t1 = phase_stamp(); acc[2] += t1 - t0; t0 = t1; }
-        flush_lines(rows, pos, gline, keys_out, false);
-        if constexpr (STAMP) { t1 = phase_stamp(); acc[3] += t1 - t0; t0 = t1; }
-        lds_barrier();
-        if constexpr (STAMP) { t1 = phase_stamp(); acc[4] += t1 - t0; }
-    }
-    flush_lines(rows, pos, gline, keys_out, true);
-    if constexpr (STAMP) {
-        if (lane == 0)
-            for (int q = 0; q < 5; ++q) dbg[((uint64_t)blockIdx.x * kLineWaves + wave) * 5 + q] = acc[q];
+        for (int st = 0; st < kScatterSteps; ++st) part_step<K>(s, step0 + t + st, carry, window[st], mask[st]);
+#pragma unroll
+        for (int st = 0; st < kScatterSteps; ++st) {
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window[st], j);
+            place16<PartCfg<K>::kKeyBits>(rows, pos, gcur, keys_out, v, mask[st]);
+        }
+        __syncthreads();
+        copy_out_tile(rows, pos, gcur, keys_out);
+        __syncthreads();
     }
 }
 
@@ -660,13 +723,20 @@ __global__ __launch_bounds__(kLineThreads) void key_scatter_kernel(const uint32_
     __syncthreads();
     const uint64_t per_wave = keys_per_block / kLineWaves;
     const uint64_t w0 = b0 + (uint64_t)(threadIdx.x >> 6) * per_wave;
+    uint32_t v[16], valid, vn[16], validn;
+    load_macro(res, lo, n, w0, v, valid);
     for (uint64_t t = 0; t < per_wave; t += kMacroKeys) {
         if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest keys
-        uint32_t v[16], valid;
-        load_macro(res, lo, n, w0 + t, v, valid);
+        const bool more = t + kMacroKeys < per_wave;
+        if (more) load_macro(res, lo, n, w0 + t + kMacroKeys, vn, validn);   // next tile's keys land during placement
         place16_lines<kResKeyBits>(rows, pos, gline, keys_out, v, valid);
         lds_barrier();
         flush_lines(rows, pos, gline, keys_out, false);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = vn[j];
+            valid = validn;
+        }
         lds_barrier();
     }
     flush_lines(rows, pos, gline, keys_out, true);
