@@ -1,0 +1,35 @@
+"""The multi-GPU plumbing on one GPU: a zero-copy torch view of the device count table and RCCL
+collectives on it (world size 1 -- the 8-GPU run is the driver's).  Run on the GPU box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_collectives_on_table_view():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', GRAFT_REPO_ROOT=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'nccl_view_check.py')], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    assert 'NCCL_VIEW_OK' in out
+
+
+def test_bench_single_gpu_small():
+    """bench.py contract on a small workload: one JSON line with roofline and a true checksum."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                        '--reads', '2000000', '--cpu-reads', '200000'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line
+    assert line['checksum_ok'] and line['n_gpus'] == 1 and line['unit'] == 'Gbases/s'
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] == 1
