@@ -822,12 +822,17 @@ KPAL_API int kpal_strand_balance(kpal_ctx *ctx, int k, const int64_t *host_count
     const uint64_t n = 1ULL << (2 * k);
     CHK(ensure(ctx, ctx->scratch[0], n * 8));
     HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_counts, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = stream_grid(ctx, n);
+    const unsigned grid = k >= 6 ? (1u << (2 * (k - 6))) : stream_grid(ctx, n);
     CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
-    if (pairwise == KPAL_PAIRWISE_PROD)
-        LAUNCH(ctx, "strand_balance", (strand_balance_kernel<0>), dim3(grid), dim3(256), (const int64_t *)ctx->scratch[0].p, k, n, (Partial *)ctx->partials.p);
-    else
-        LAUNCH(ctx, "strand_balance", (strand_balance_kernel<1>), dim3(grid), dim3(256), (const int64_t *)ctx->scratch[0].p, k, n, (Partial *)ctx->partials.p);
+    const int64_t *dc = (const int64_t *)ctx->scratch[0].p;
+    Partial *pp = (Partial *)ctx->partials.p;
+    if (k >= 6) {
+        if (pairwise == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "strand_balance_tiled", (strand_balance_tiled_kernel<0>), dim3(grid), dim3(1024), dc, k, pp);
+        else LAUNCH(ctx, "strand_balance_tiled", (strand_balance_tiled_kernel<1>), dim3(grid), dim3(1024), dc, k, pp);
+    } else {
+        if (pairwise == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "strand_balance", (strand_balance_kernel<0>), dim3(grid), dim3(256), dc, k, n, pp);
+        else LAUNCH(ctx, "strand_balance", (strand_balance_kernel<1>), dim3(grid), dim3(256), dc, k, n, pp);
+    }
     std::vector<Partial> res;
     CHK(finish_partials(ctx, 1, grid, res));
     *out = finish_value(pairwise, res[0], nullptr);
@@ -864,6 +869,18 @@ KPAL_API int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *d
     const int64_t *l = dev_left, *r = dev_right;
     if (do_balance) {
         if (k < 1 || k > KPAL_MAX_K || n != (1ULL << (2 * k))) return set_err(KPAL_E_INVALID, "do_balance needs n == 4^k");
+        if (k >= 6) {   // fused balance + distance: balanced values are formed in LDS tiles, never written
+            const unsigned grid = 1u << (2 * (k - 6));
+            CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
+            Partial *pp = (Partial *)ctx->partials.p;
+            if (metric == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<0>), dim3(grid), dim3(1024), l, r, k, pp);
+            else if (metric == KPAL_PAIRWISE_SUM) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<1>), dim3(grid), dim3(1024), l, r, k, pp);
+            else LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<2>), dim3(grid), dim3(1024), l, r, k, pp);
+            std::vector<Partial> res;
+            CHK(finish_partials(ctx, 1, grid, res));
+            *out = finish_value(metric, res[0], aux_out);
+            return KPAL_OK;
+        }
         CHK(ensure(ctx, ctx->scratch[2], n * 8));
         CHK(ensure(ctx, ctx->scratch[3], n * 8));
         CHK(launch_balance(ctx, k, l, (int64_t *)ctx->scratch[2].p));

@@ -243,6 +243,113 @@ __global__ __launch_bounds__(256) void pair_distance_kernel(const T *__restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = p;
 }
 
+// ---- fused balance + distance, fused split + multiset (k >= 6) ----------------------------------
+// Same tiling as balance_tiled_kernel: the workgroup of tile pair (M, rc(M)) holds both tiles of
+// both profiles in LDS (4 x 64 x 65 x 8 B = 130 KiB), forms the balanced values
+// x = l[i] + l[rc(i)], y = r[i] + r[rc(i)] on the fly (kpal/kdistlib.py:139-141) and reduces the
+// metric over the 2 x 4096 bins of the pair -- 16 B of HBM traffic per bin, no balanced copies.
+template <int METRIC>
+__global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int64_t *__restrict__ l,
+                                                                      const int64_t *__restrict__ r, int k,
+                                                                      Partial *__restrict__ partials)
+{
+    constexpr int T = 3, S = 64;
+    __shared__ unsigned long long Al[S][S + 1], Bl[S][S + 1], Ar[S][S + 1], Br[S][S + 1];
+    const int md = k - 2 * T;
+    const uint64_t M = blockIdx.x;
+    const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+    Partial p = {0.0, 0ULL};
+    if (M <= Mr) {   // block-uniform
+        const bool self = M == Mr;
+        const uint64_t rowstride = 1ULL << (2 * (k - T));
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const unsigned long long *ul = reinterpret_cast<const unsigned long long *>(l);
+        const unsigned long long *ur = reinterpret_cast<const unsigned long long *>(r);
+        for (int h = w; h < S; h += 16) {
+            Al[h][lane] = ul[(uint64_t)h * rowstride + M * S + lane];
+            Ar[h][lane] = ur[(uint64_t)h * rowstride + M * S + lane];
+            if (!self) {
+                Bl[h][lane] = ul[(uint64_t)h * rowstride + Mr * S + lane];
+                Br[h][lane] = ur[(uint64_t)h * rowstride + Mr * S + lane];
+            }
+        }
+        __syncthreads();
+        auto term = [&](unsigned long long xu, unsigned long long yu) {
+            const int64_t x = (int64_t)xu, y = (int64_t)yu;
+            if constexpr (METRIC == 2) {
+                const uint64_t d = (uint64_t)x - (uint64_t)y;
+                p.m += d * d;
+            } else {
+                if (x != 0 || y != 0) {
+                    p.s += METRIC == 0 ? pw_prod(x, y) : pw_sum(x, y);
+                    p.m += 1;
+                }
+            }
+        };
+        const int rl = (int)revcomp((uint64_t)lane, T);
+        for (int h = w; h < S; h += 16) {
+            const int rh = (int)revcomp((uint64_t)h, T);
+            term(Al[h][lane] + (self ? Al[rl][rh] : Bl[rl][rh]), Ar[h][lane] + (self ? Ar[rl][rh] : Br[rl][rh]));
+            if (!self) term(Bl[h][lane] + Al[rl][rh], Br[h][lane] + Ar[rl][rh]);
+        }
+    }
+    p = block_reduce(p);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+// kmer.get_balance score (kpal/kmer.py:243-245) with the split halves never materialised: every
+// unordered pair {i, rc(i)} is visited once -- from the tile of the smaller M, or, inside a
+// self-paired tile, from its smaller index (palindromes contribute f = r = c[i], klib.py:322-323).
+template <int PW>
+__global__ __launch_bounds__(1024) void strand_balance_tiled_kernel(const int64_t *__restrict__ c, int k,
+                                                                    Partial *__restrict__ partials)
+{
+    constexpr int T = 3, S = 64;
+    __shared__ unsigned long long A[S][S + 1], B[S][S + 1];
+    const int md = k - 2 * T;
+    const uint64_t M = blockIdx.x;
+    const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+    Partial p = {0.0, 0ULL};
+    if (M <= Mr) {
+        const bool self = M == Mr;
+        const uint64_t rowstride = 1ULL << (2 * (k - T));
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const unsigned long long *uc = reinterpret_cast<const unsigned long long *>(c);
+        for (int h = w; h < S; h += 16) {
+            A[h][lane] = uc[(uint64_t)h * rowstride + M * S + lane];
+            if (!self) B[h][lane] = uc[(uint64_t)h * rowstride + Mr * S + lane];
+        }
+        __syncthreads();
+        const int rl = (int)revcomp((uint64_t)lane, T);
+        for (int h = w; h < S; h += 16) {
+            const int rh = (int)revcomp((uint64_t)h, T);
+            const unsigned long long mine = A[h][lane];
+            const unsigned long long other = self ? A[rl][rh] : B[rl][rh];
+            int64_t f, v;
+            bool take = true;
+            if (self) {
+                const int i_loc = h * S + lane, r_loc = rl * S + rh;   // order inside the tile == global order
+                take = i_loc <= r_loc;
+                if (i_loc == r_loc) {
+                    f = v = (int64_t)mine;
+                } else {
+                    f = (int64_t)(mine * 2ULL);
+                    v = (int64_t)(other * 2ULL);
+                }
+            } else {
+                f = (int64_t)(mine * 2ULL);
+                v = (int64_t)(other * 2ULL);
+            }
+            if (take && (f != 0 || v != 0)) {
+                p.s += PW == 0 ? pw_prod(f, v) : pw_sum(f, v);
+                p.m += 1;
+            }
+        }
+    }
+    p = block_reduce(p);
+    if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
 // Final fixed-order reduction of per-block partials: out[q] = sum over blocks of partials[q*nblocks + b].
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const Partial *__restrict__ partials, uint32_t nblocks,
                                                               Partial *__restrict__ out)

@@ -30,6 +30,8 @@ for name, (ms, cnt) in sorted(prof.items()):
     per = ms / cnt
     print('   %-18s %8.3f ms per launch (%d launches)' % (name, per, cnt))
 print('   pair_distance reads 2 vectors: %.2f TB/s at the mean launch time' % (2 * n * 8 / (prof['pair_distance'][0] / prof['pair_distance'][1]) / 1e9))
+if 'pair_distance_balanced' in prof:
+    print('   pair_distance_balanced (fused): %.2f TB/s of the 2 input vectors' % (2 * n * 8 / (prof['pair_distance_balanced'][0] / prof['pair_distance_balanced'][1]) / 1e9))
 ctx.prof_enable(False)
 if a.k <= 13:
     import time
