@@ -128,16 +128,18 @@ __device__ __forceinline__ void copy_out_tile(const unsigned char *rows, uint32_
 // A1: per-(bucket, block) key counts of an ASCII span.  cntmat is bucket-major: cntmat[b*G + blk].
 // Block `blk` owns steps [blk*SPB, (blk+1)*SPB); wave w streams the w-th eighth of it, carrying its
 // left-neighbour chunk in registers.  The 512 counters are kept in 32 bank-interleaved replicas
-// (replica = lane % 32 lives in LDS bank lane % 32), so a wave's 64 ds_add_u32 never conflict;
+// (replica = lane % 16), so a wave's 64 ds_add_u32 rarely conflict;
 // a k-mer that must not be counted adds 0 (branch-free).
 // ------------------------------------------------------------------------------------------
+constexpr int kCountReplicas = 16;   // bank-interleaved copies of the 512 bucket counters (32 KiB: four workgroups per CU)
+
 __device__ __forceinline__ void flush_bucket_counts(const uint32_t *cnt, uint32_t *__restrict__ cntmat_block,
                                                     uint64_t stride)
 {
     for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) {
         uint32_t v = 0;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) v += cnt[b * 32 + ((r + b) & 31)];
+        for (int r = 0; r < kCountReplicas; ++r) v += cnt[b * kCountReplicas + ((r + b) & (kCountReplicas - 1))];
         cntmat_block[(uint64_t)b * stride] = v;
     }
 }
@@ -146,10 +148,10 @@ template <int K>
 __global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uint64_t steps_per_block,
                                                                      uint32_t *__restrict__ cntmat)
 {
-    __shared__ uint32_t cnt[kNumBuckets * 32];  // 64 KiB
-    for (int i = threadIdx.x; i < kNumBuckets * 32; i += blockDim.x) cnt[i] = 0;
+    __shared__ uint32_t cnt[kNumBuckets * kCountReplicas];
+    for (int i = threadIdx.x; i < kNumBuckets * kCountReplicas; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const uint32_t rep = threadIdx.x & 31;
+    const uint32_t rep = threadIdx.x & (kCountReplicas - 1);
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
     const uint64_t step0 = (uint64_t)blockIdx.x * steps_per_block + (uint64_t)(threadIdx.x >> 6) * steps_per_wave;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kScatterThreads) void part_count_kernel(Span s, uin
             part_step<K>(s, st, carry, window, mask);
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                atomicAdd(&cnt[(kmer_at<K>(window, j) >> PartCfg<K>::kKeyBits) * 32 + rep], (mask >> (15 - j)) & 1u);
+                atomicAdd(&cnt[(kmer_at<K>(window, j) >> PartCfg<K>::kKeyBits) * kCountReplicas + rep], (mask >> (15 - j)) & 1u);
         }
     }
     __syncthreads();
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kScatterThreads) void key_count_kernel(const uint32
                                                                     const uint64_t *__restrict__ start1,
                                                                     uint32_t keys_per_block, uint32_t *__restrict__ cntmat2)
 {
-    __shared__ uint32_t cnt[kNumBuckets * 32];
+    __shared__ uint32_t cnt[kNumBuckets * kCountReplicas];
     const uint32_t c = blockIdx.y, G = gridDim.x;
     const uint64_t lo = start1[c], n = start1[c + 1] - lo;
     const uint64_t b0 = (uint64_t)blockIdx.x * keys_per_block;
@@ -685,16 +687,16 @@ __global__ __launch_bounds__(kScatterThreads) void key_count_kernel(const uint32
         for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) out[(uint64_t)b * G] = 0;
         return;
     }
-    for (int i = threadIdx.x; i < kNumBuckets * 32; i += blockDim.x) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kNumBuckets * kCountReplicas; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const uint32_t rep = threadIdx.x & 31;
+    const uint32_t rep = threadIdx.x & (kCountReplicas - 1);
     const uint64_t per_wave = keys_per_block / kScatterWaves;
     const uint64_t w0 = b0 + (uint64_t)(threadIdx.x >> 6) * per_wave;
     for (uint64_t at = w0; at < w0 + per_wave && at < n; at += kMacroKeys) {
         uint32_t v[16], valid;
         load_macro(res, lo, n, at, v, valid);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) atomicAdd(&cnt[(v[j] >> kResKeyBits) * 32 + rep], (valid >> (15 - j)) & 1u);
+        for (int j = 0; j < 16; ++j) atomicAdd(&cnt[(v[j] >> kResKeyBits) * kCountReplicas + rep], (valid >> (15 - j)) & 1u);
     }
     __syncthreads();
     flush_bucket_counts(cnt, out, G);
