@@ -42,6 +42,13 @@ extern "C" {
 #define KPAL_PAIRWISE_SUM 1  /* metrics.pairwise['sum'],  metrics.py:161 */
 #define KPAL_EUCLIDEAN 2     /* metrics.euclidean,        metrics.py:126-135 */
 
+#define KPAL_COSINE 3        /* metrics.cosine_similarity, metrics.py:138-147 (kpal_profile_distance only) */
+
+/* summary functions of dynamic smoothing: the keys of metrics.summary, metrics.py:165-170 */
+#define KPAL_SUMMARY_MIN 0
+#define KPAL_SUMMARY_AVERAGE 1
+#define KPAL_SUMMARY_MEDIAN 2
+
 /* counting strategies (kpal_count_set_strategy) */
 #define KPAL_STRATEGY_AUTO 0
 #define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k */
@@ -120,6 +127,33 @@ int kpal_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host
                          int do_balance, double *out_lower);
 int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles /* P x 4^k */,
                                 int metric, int do_balance, double *out_lower);
+
+/* ---- ProfileDistance with its full option set, kdistlib.py:25-51,126-161 ----
+ * The constructor arguments of kdistlib.ProfileDistance that select built-in behaviour; a
+ * user-supplied summary / pairwise / distance callable cannot enter a kernel and stays in Python. */
+typedef struct kpal_distance_options {
+    int do_balance;   /* kdistlib.py:139-141: balance copies of both profiles */
+    int do_positive;  /* kdistlib.py:143-145: zero every bin that is zero in either profile */
+    int do_smooth;    /* kdistlib.py:147-148: dynamic smoothing */
+    int summary;      /* KPAL_SUMMARY_*: the `summary` function of the smoothing test */
+    double threshold; /* collapse iff min(summary(left quarters), summary(right quarters)) <= threshold */
+    int do_scale;     /* kdistlib.py:149-157: scale by the totals (metrics.get_scale) -> float64 profiles */
+    int down;         /* metrics.scale_down: both factors <= 1 */
+    int metric;       /* KPAL_PAIRWISE_PROD / _SUM (multiset), KPAL_EUCLIDEAN, KPAL_COSINE */
+} kpal_distance_options;
+
+/* ProfileDistance.distance(left, right), kdistlib.py:126-161; inputs are never modified. */
+int kpal_profile_distance(kpal_ctx *ctx, int k, const int64_t *host_left, const int64_t *host_right,
+                          const kpal_distance_options *opt, double *out);
+int kpal_profile_distance_device(kpal_ctx *ctx, int k, const int64_t *dev_left, const int64_t *dev_right,
+                                 const kpal_distance_options *opt, double *out);
+/* ProfileDistance.dynamic_smooth(left, right), kdistlib.py:112-124: both vectors smoothed in place. */
+int kpal_dynamic_smooth(kpal_ctx *ctx, int k, int64_t *host_left_inout, int64_t *host_right_inout,
+                        int summary, double threshold);
+/* kdistlib.distance_matrix values (kdistlib.py:179-186) for any option set: profiles are uploaded
+ * (and balanced) once, every pair runs the option pipeline on the device. */
+int kpal_profile_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host_profiles,
+                                 const kpal_distance_options *opt, double *out_lower);
 
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) ---- */
 int kpal_prof_enable(kpal_ctx *ctx, int on);

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('KPAL_HIP_LIBRARY', os.path.join(_HERE, 'libkpal_hip.so'))   # override: A/B timing of builds
 
 KPAL_MAX_K = 16
-PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN = 0, 1, 2
+PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN, COSINE = 0, 1, 2, 3
+SUMMARY_MIN, SUMMARY_AVERAGE, SUMMARY_MEDIAN = 0, 1, 2
 STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4}
 
 _E_INVALID, _E_NOMEM, _E_HIP, _E_STATE = -1, -2, -3, -4
@@ -25,6 +26,16 @@ _lib_lock = threading.Lock()
 _vp = ctypes.c_void_p
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _f64p = ctypes.POINTER(ctypes.c_double)
+
+class DistanceOptions(ctypes.Structure):
+    """``kpal_distance_options`` of include/kpal_hip.h: the ProfileDistance constructor arguments
+    (kpal/kdistlib.py:25-51) that select built-in behaviour."""
+    _fields_ = [('do_balance', ctypes.c_int), ('do_positive', ctypes.c_int), ('do_smooth', ctypes.c_int),
+                ('summary', ctypes.c_int), ('threshold', ctypes.c_double), ('do_scale', ctypes.c_int),
+                ('down', ctypes.c_int), ('metric', ctypes.c_int)]
+
+
+_optp = ctypes.POINTER(DistanceOptions)
 
 # name -> (restype, argtypes); one entry per symbol declared in include/kpal_hip.h
 SIGNATURES = {
@@ -62,6 +73,11 @@ SIGNATURES = {
                                             ctypes.c_int, _f64p]),
     'kpal_distance_matrix_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int,
                                                    ctypes.c_int, _f64p]),
+    'kpal_profile_distance': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _optp, _f64p]),
+    'kpal_profile_distance_device': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _optp, _f64p]),
+    'kpal_dynamic_smooth': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_double]),
+    'kpal_profile_distance_matrix': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp), _optp,
+                                                    _f64p]),
     'kpal_prof_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_prof_reset': (ctypes.c_int, [_vp]),
     'kpal_prof_count': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
@@ -300,6 +316,35 @@ class Context(object):
         out = np.zeros(P * (P - 1) // 2, dtype=np.float64)
         _check(self._L.kpal_distance_matrix_device(self._h, int(P), int(k), _vp(dev_profiles), int(metric),
                                                    int(bool(do_balance)), out.ctypes.data_as(_f64p)))
+        return out
+
+    # -- ProfileDistance with options ------------------------------------------------------------
+    def profile_distance(self, left, right, k, options):
+        """ProfileDistance.distance for a DistanceOptions (kdistlib.py:126-161)."""
+        l = _as_i64(left, 'left')
+        r = _as_i64(right, 'right')
+        if l.size != 4 ** k or r.size != 4 ** k:
+            raise ValueError('profile length != 4**%d' % k)
+        out = ctypes.c_double(0.0)
+        _check(self._L.kpal_profile_distance(self._h, int(k), l.ctypes.data, r.ctypes.data, ctypes.byref(options),
+                                             ctypes.byref(out)))
+        return out.value
+
+    def dynamic_smooth(self, left, right, k, summary, threshold):
+        """In place on two writable contiguous int64 vectors (kdistlib.py:112-124)."""
+        _check(self._L.kpal_dynamic_smooth(self._h, int(k), left.ctypes.data, right.ctypes.data, int(summary),
+                                           float(threshold)))
+
+    def profile_distance_matrix(self, profiles, k, options):
+        arrs = [_as_i64(p) for p in profiles]
+        P = len(arrs)
+        for a in arrs:
+            if a.size != 4 ** k:
+                raise ValueError('profile length %d != 4**%d' % (a.size, k))
+        out = np.zeros(P * (P - 1) // 2, dtype=np.float64)
+        ptrs = (_vp * P)(*[a.ctypes.data for a in arrs])
+        _check(self._L.kpal_profile_distance_matrix(self._h, P, int(k), ptrs, ctypes.byref(options),
+                                                    out.ctypes.data_as(_f64p)))
         return out
 
     # -- profiling ---------------------------------------------------------------------------

@@ -18,6 +18,7 @@
 #include "partition_kernels.hpp"
 #include "fasta_kernels.hpp"
 #include "vec_kernels.hpp"
+#include "option_kernels.hpp"
 
 #define KPAL_API extern "C" __attribute__((visibility("default")))
 
@@ -93,6 +94,7 @@ struct kpal_ctx {
     // scratch for vector ops
     DevBuf scratch[4];
     DevBuf partials, result;
+    DevBuf opt_l, opt_r, opt_levels, opt_profiles;   // ProfileDistance option pipeline
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -275,7 +277,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
-                      &ctx->partials, &ctx->result};
+                      &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 2; ++i) {
@@ -979,6 +981,198 @@ KPAL_API int kpal_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *co
                               hipMemcpyHostToDevice, ctx->stream));
     }
     return kpal_distance_matrix_device(ctx, P, k, (const int64_t *)ctx->scratch[0].p, metric, do_balance, out_lower);
+}
+
+// ----------------------------------------------------------------------------------------------
+// ProfileDistance with options (kdistlib.py:126-161)
+// ----------------------------------------------------------------------------------------------
+static int check_options(const kpal_distance_options *opt)
+{
+    if (!opt) return set_err(KPAL_E_INVALID, "options are NULL");
+    if (opt->metric < 0 || opt->metric > KPAL_COSINE) return set_err(KPAL_E_INVALID, "unknown metric %d", opt->metric);
+    if (opt->do_smooth && (opt->summary < KPAL_SUMMARY_MIN || opt->summary > KPAL_SUMMARY_MEDIAN))
+        return set_err(KPAL_E_INVALID, "unknown summary function %d", opt->summary);
+    return KPAL_OK;
+}
+
+// Dynamic smoothing of (l, r) into (lo, ro); in == out allowed.
+static int launch_smooth(kpal_ctx *ctx, int k, const int64_t *l, const int64_t *r, int64_t *lo, int64_t *ro,
+                         int summary, double threshold)
+{
+    // level d = 0..k-1 has 4^d nodes: two int64 sums and one decision byte each
+    // (level starts padded to even entries: the kernels read 16 bytes at a time)
+    const uint64_t total = ((1ULL << (2 * k)) - 1) / 3 + (uint64_t)k;
+    CHK(ensure(ctx, ctx->opt_levels, (size_t)total * 17 + 64));
+    int64_t *sl = (int64_t *)ctx->opt_levels.p, *sr = sl + total;
+    uint8_t *dec = (uint8_t *)(sr + total);
+    SmoothLevels lv = {};
+    uint64_t at = 0;
+    for (int d = 0; d < k; ++d) {
+        lv.sum_l[d] = sl + at;
+        lv.sum_r[d] = sr + at;
+        lv.decide[d] = dec + at;
+        at += (1ULL << (2 * d)) + (d == 0 ? 1 : 0);
+    }
+    for (int d = k - 1; d >= 0; --d) {
+        const uint64_t nparent = 1ULL << (2 * d);
+        const int64_t *cl = d == k - 1 ? l : lv.sum_l[d + 1];
+        const int64_t *cr = d == k - 1 ? r : lv.sum_r[d + 1];
+        LAUNCH(ctx, "smooth_level", smooth_level_kernel, dim3(stream_grid(ctx, nparent)), dim3(256), cl, cr, nparent,
+               (int64_t *)lv.sum_l[d], (int64_t *)lv.sum_r[d], (uint8_t *)lv.decide[d], summary, threshold);
+    }
+    LAUNCH(ctx, "smooth_apply", smooth_apply_kernel, dim3(stream_grid(ctx, 1ULL << (2 * (k - 1)))), dim3(256), l, r, k, lv, lo, ro);
+    return KPAL_OK;
+}
+
+template <int METRIC>
+static void launch_option_distance(kpal_ctx *ctx, unsigned grid, bool scaled, const int64_t *l, const int64_t *r, uint64_t n,
+                                   double ls, double rs, Partial *pp)
+{
+    ProfScope ps_(ctx, "option_distance");
+    if (scaled) hipLaunchKernelGGL((option_distance_kernel<METRIC, true>), dim3(grid), dim3(256), 0, ctx->stream, l, r, n, ls, rs, pp);
+    else hipLaunchKernelGGL((option_distance_kernel<METRIC, false>), dim3(grid), dim3(256), 0, ctx->stream, l, r, n, ls, rs, pp);
+}
+
+// One pair, both vectors on the device and 16-byte aligned; `balanced`: the inputs are already
+// balanced (matrix path), so opt->do_balance is not applied again.
+static int profile_distance_pair(kpal_ctx *ctx, int k, const int64_t *dl, const int64_t *dr,
+                                 const kpal_distance_options *opt, bool balanced, double *out)
+{
+    const uint64_t n = 1ULL << (2 * k);
+    const bool do_balance = opt->do_balance && !balanced;
+    if (!opt->do_positive && !opt->do_smooth && !opt->do_scale && opt->metric <= KPAL_EUCLIDEAN)
+        return kpal_pair_distance_device(ctx, n, dl, dr, opt->metric, do_balance, k, out, nullptr);
+    const int64_t *l = dl, *r = dr;
+    if (do_balance || opt->do_positive || opt->do_smooth) {
+        CHK(ensure(ctx, ctx->opt_l, n * 8));
+        CHK(ensure(ctx, ctx->opt_r, n * 8));
+    }
+    int64_t *wl = (int64_t *)ctx->opt_l.p, *wr = (int64_t *)ctx->opt_r.p;
+    if (do_balance) {
+        CHK(launch_balance(ctx, k, l, wl));
+        CHK(launch_balance(ctx, k, r, wr));
+        l = wl;
+        r = wr;
+    }
+    if (opt->do_positive) {
+        LAUNCH(ctx, "positive", positive_kernel, dim3(stream_grid(ctx, n)), dim3(256), l, r, wl, wr, n);
+        l = wl;
+        r = wr;
+    }
+    if (opt->do_smooth) {
+        CHK(launch_smooth(ctx, k, l, r, wl, wr, opt->summary, opt->threshold));
+        l = wl;
+        r = wr;
+    }
+    const unsigned grid = stream_grid(ctx, n);
+    CHK(ensure(ctx, ctx->partials, (size_t)grid * 3 * sizeof(Partial)));
+    Partial *pp = (Partial *)ctx->partials.p;
+    std::vector<Partial> res;
+    double ls = 1.0, rs = 1.0;
+    if (opt->do_scale) {
+        LAUNCH(ctx, "totals", totals_kernel, dim3(grid), dim3(256), l, r, n, pp);
+        CHK(finish_partials(ctx, 2, grid, res));
+        // metrics.get_scale, metrics.py:49-72: int64 totals, true division
+        const int64_t tl = (int64_t)res[0].m, tr = (int64_t)res[1].m;
+        if (tl < tr) ls = (double)tr / (double)tl;
+        else rs = (double)tl / (double)tr;
+        if (opt->down) {   // metrics.scale_down, metrics.py:75-86
+            const double top = ls > rs ? ls : rs;
+            ls /= top;
+            rs /= top;
+        }
+    }
+    const bool scaled = opt->do_scale != 0;
+    switch (opt->metric) {
+    case KPAL_PAIRWISE_PROD: launch_option_distance<0>(ctx, grid, scaled, l, r, n, ls, rs, pp); break;
+    case KPAL_PAIRWISE_SUM: launch_option_distance<1>(ctx, grid, scaled, l, r, n, ls, rs, pp); break;
+    case KPAL_EUCLIDEAN: launch_option_distance<2>(ctx, grid, scaled, l, r, n, ls, rs, pp); break;
+    default: launch_option_distance<3>(ctx, grid, scaled, l, r, n, ls, rs, pp); break;
+    }
+    HIPCHK(hipGetLastError());
+    CHK(finish_partials(ctx, opt->metric == KPAL_COSINE ? 3 : 1, grid, res));
+    if (opt->metric <= KPAL_PAIRWISE_SUM) {
+        *out = res[0].s / (double)(res[0].m + 1ULL);   // metrics.py:123
+    } else if (opt->metric == KPAL_EUCLIDEAN) {
+        *out = scaled ? std::sqrt(res[0].s) : std::sqrt((double)(int64_t)res[0].m);   // metrics.py:135,46
+    } else {   // metrics.py:147: dot(l, r) / (|l| * |r|)
+        if (scaled) *out = res[0].s / (std::sqrt(res[1].s) * std::sqrt(res[2].s));
+        else *out = (double)(int64_t)res[0].m / (std::sqrt((double)(int64_t)res[1].m) * std::sqrt((double)(int64_t)res[2].m));
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_profile_distance_device(kpal_ctx *ctx, int k, const int64_t *dev_left, const int64_t *dev_right,
+                                          const kpal_distance_options *opt, double *out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!dev_left || !dev_right || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (((uintptr_t)dev_left & 15) || ((uintptr_t)dev_right & 15)) return set_err(KPAL_E_INVALID, "device vectors must be 16-byte aligned");
+    CHK(check_options(opt));
+    return profile_distance_pair(ctx, k, dev_left, dev_right, opt, false, out);
+}
+
+KPAL_API int kpal_profile_distance(kpal_ctx *ctx, int k, const int64_t *host_left, const int64_t *host_right,
+                                   const kpal_distance_options *opt, double *out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!host_left || !host_right || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    CHK(check_options(opt));
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_left, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, host_right, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    return profile_distance_pair(ctx, k, (const int64_t *)ctx->scratch[0].p, (const int64_t *)ctx->scratch[1].p, opt, false, out);
+}
+
+KPAL_API int kpal_dynamic_smooth(kpal_ctx *ctx, int k, int64_t *host_left_inout, int64_t *host_right_inout,
+                                 int summary, double threshold)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (!host_left_inout || !host_right_inout) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (summary < KPAL_SUMMARY_MIN || summary > KPAL_SUMMARY_MEDIAN) return set_err(KPAL_E_INVALID, "unknown summary function %d", summary);
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->opt_l, n * 8));
+    CHK(ensure(ctx, ctx->opt_r, n * 8));
+    int64_t *wl = (int64_t *)ctx->opt_l.p, *wr = (int64_t *)ctx->opt_r.p;
+    HIPCHK(hipMemcpyAsync(wl, host_left_inout, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(wr, host_right_inout, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CHK(launch_smooth(ctx, k, wl, wr, wl, wr, summary, threshold));
+    HIPCHK(hipMemcpyAsync(host_left_inout, wl, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(host_right_inout, wr, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_profile_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host_profiles,
+                                          const kpal_distance_options *opt, double *out_lower)
+{
+    CTX_ENTER(ctx);
+    if (P < 1) return set_err(KPAL_E_INVALID, "P must be >= 1");
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    CHK(check_options(opt));
+    if (P == 1) return KPAL_OK;
+    if (!host_profiles || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (!opt->do_positive && !opt->do_smooth && !opt->do_scale && opt->metric <= KPAL_EUCLIDEAN)
+        return kpal_distance_matrix(ctx, P, k, host_profiles, opt->metric, opt->do_balance, out_lower);
+    const uint64_t n = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->opt_profiles, (size_t)P * n * 8));
+    int64_t *prof = (int64_t *)ctx->opt_profiles.p;
+    for (int p = 0; p < P; ++p) {
+        if (!host_profiles[p]) return set_err(KPAL_E_INVALID, "profile %d is NULL", p);
+        HIPCHK(hipMemcpyAsync(prof + (uint64_t)p * n, host_profiles[p], n * 8, hipMemcpyHostToDevice, ctx->stream));
+        // balancing copies inside every pair (kdistlib.py:136-141) == balancing each profile once
+        if (opt->do_balance) CHK(launch_balance(ctx, k, prof + (uint64_t)p * n, prof + (uint64_t)p * n));
+    }
+    for (int i = 1; i < P; ++i)
+        for (int j = 0; j < i; ++j)
+            CHK(profile_distance_pair(ctx, k, prof + (uint64_t)i * n, prof + (uint64_t)j * n, opt, true,
+                                      &out_lower[(size_t)i * (i - 1) / 2 + j]));
+    return KPAL_OK;
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -5,12 +5,23 @@ euclidean (kpal/kdistlib.py:126-161) -- runs as fused HIP kernels (``kpal_pair_d
 ``distance_matrix`` over P profiles is ONE tiled kernel launch (``kpal_distance_matrix``) instead
 of P(P-1)/2 Python-level distances; profiles are balanced once each, which is identical to the
 reference balancing copies inside every pair.  The optional positive / dynamic-smooth / scale
-steps (kpal/kdistlib.py:143-157) keep the reference's NumPy formulation and hand the resulting
-vectors to the same HIP reductions.
+steps (kpal/kdistlib.py:143-157) and cosine similarity run on the device too
+(``kpal_profile_distance``) whenever every callable is one of kPAL's built-ins (the values of
+``metrics.summary`` / ``metrics.pairwise`` / ``metrics.vector_distance``, recognised by identity);
+a user-supplied callable cannot enter a kernel and keeps the reference's NumPy formulation.
 """
 import numpy as np
 
 from . import _native, metrics
+
+
+def _plain_int64(a):
+    return (isinstance(a, np.ndarray) and a.dtype == np.int64 and a.ndim == 1 and a.flags['C_CONTIGUOUS']
+            and a.flags['WRITEABLE'])
+
+
+def _is_number(x):
+    return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
 
 
 class ProfileDistance(object):
@@ -30,7 +41,7 @@ class ProfileDistance(object):
         self._pairwise = pairwise
         self._function = summary
 
-    # ---- dynamic smoothing (kpal/kdistlib.py:53-124); NumPy, "next" for the GPU ---------------
+    # ---- dynamic smoothing (kpal/kdistlib.py:53-124) ---------------------------------------------
     def _collapse(self, vector, start, length):
         """Sums of the four quarters of ``vector[start:start+length]``."""
         return np.reshape(vector[start:start + length], (4, length // 4)).sum(axis=1)
@@ -51,17 +62,44 @@ class ProfileDistance(object):
             self._dynamic_smooth(left, right, start + i * quarter, quarter)
 
     def dynamic_smooth(self, left, right):
-        """Collapse sub-profiles that fail the summary/threshold test, in place."""
+        """Collapse sub-profiles that fail the summary/threshold test, in place
+        (kpal/kdistlib.py:112-124).  Built-in summary functions on int64 profiles run as a
+        level-wise tree reduction on the GPU; anything else takes the reference's recursion."""
+        code = metrics.summary_code(self._function)
+        lc, rc = left.counts, right.counts
+        if (code is not None and _plain_int64(lc) and _plain_int64(rc) and lc.size == rc.size
+                and _is_number(self._threshold)):
+            _native.context().dynamic_smooth(lc, rc, left.length, code, self._threshold)
+            return
         self._dynamic_smooth(left, right, 0, left.number)
 
     # ---- routing -------------------------------------------------------------------------------
     def _native_metric(self):
         """Metric code when the final reduction can run on the GPU, else None."""
-        if self._distance_function is None:
+        if not self._distance_function:
             return metrics.pairwise_code(self._pairwise)
         if self._distance_function is metrics.euclidean:
             return _native.EUCLIDEAN
+        if self._distance_function is metrics.cosine_similarity:
+            return _native.COSINE
         return None
+
+    def _native_options(self):
+        """``kpal_distance_options`` for this configuration, or None if a user-supplied callable
+        or a non-numeric threshold keeps it in Python."""
+        metric = self._native_metric()
+        if metric is None:
+            return None
+        summary = 0
+        if self._do_smooth:
+            summary = metrics.summary_code(self._function)
+            if summary is None or not _is_number(self._threshold):
+                return None
+        return _native.DistanceOptions(
+            do_balance=int(bool(self._do_balance)), do_positive=int(bool(self._do_positive)),
+            do_smooth=int(bool(self._do_smooth)), summary=summary,
+            threshold=float(self._threshold) if self._do_smooth else 0.0,
+            do_scale=int(bool(self._do_scale)), down=int(bool(self._down)), metric=metric)
 
     def _is_plain(self):
         return not (self._do_positive or self._do_smooth or self._do_scale)
@@ -70,11 +108,16 @@ class ProfileDistance(object):
         """Distance between two profiles; the inputs are left unmodified
         (kpal/kdistlib.py:126-161, tests/test_kdistlib.py:124-135)."""
         metric = self._native_metric()
-        if (self._is_plain() and metric is not None and np.asanyarray(left.counts).dtype.kind in 'iub'
-                and np.asanyarray(right.counts).dtype.kind in 'iub'):
+        integer = (np.asanyarray(left.counts).dtype.kind in 'iub' and np.asanyarray(right.counts).dtype.kind in 'iub'
+                   and len(left.counts) == len(right.counts))
+        if self._is_plain() and metric is not None and metric != _native.COSINE and integer:
             # fused: balanced copies are made on the device, nothing is written back
             return _native.context().pair_distance(left.counts, right.counts, metric,
                                                    do_balance=self._do_balance, k=left.length)
+        options = self._native_options() if integer else None
+        if options is not None:
+            # the whole option pipeline on device copies (kdistlib.py:136-161)
+            return _native.context().profile_distance(left.counts, right.counts, left.length, options)
 
         left = left.copy()
         right = right.copy()
@@ -111,9 +154,13 @@ def distance_matrix(profiles, output, precision, dist):
     metric = dist._native_metric()
     same_k = len(set(p.length for p in profiles)) == 1
     integer = all(np.asanyarray(p.counts).dtype.kind in 'iub' for p in profiles)
-    if dist._is_plain() and metric is not None and same_k and integer:
+    options = dist._native_options() if (same_k and integer) else None
+    if dist._is_plain() and metric is not None and metric != _native.COSINE and same_k and integer:
         values = _native.context().distance_matrix([p.counts for p in profiles], profiles[0].length, metric,
                                                    do_balance=dist._do_balance)
+    elif options is not None:
+        # profiles uploaded (and balanced) once, every pair through the option kernels
+        values = _native.context().profile_distance_matrix([p.counts for p in profiles], profiles[0].length, options)
     else:
         values = [dist.distance(profiles[i], profiles[j]) for i in range(1, count) for j in range(i)]
 

@@ -131,6 +131,16 @@ mergers = {
 }
 
 
+def summary_code(function):
+    """-> native code of a built-in summary function (``np.min`` / ``np.mean`` / ``np.median``,
+    the values of :data:`summary`), else None."""
+    for code, builtin in ((_native.SUMMARY_MIN, np.min), (_native.SUMMARY_AVERAGE, np.mean),
+                          (_native.SUMMARY_MEDIAN, np.median)):
+        if function is builtin:
+            return code
+    return None
+
+
 def pairwise_code(function):
     """-> native metric code for a built-in pairwise function, else None."""
     return _PAIRWISE_CODE.get(id(function))

@@ -265,6 +265,144 @@ ORACLE_API double kpal_oracle_distance(const int64_t *left, const int64_t *right
     return d;
 }
 
+/* ------------------------------------------------------------------------------------ *
+ * a11 with every option: ProfileDistance.distance, kpal/kdistlib.py:126-161.
+ *   positive  (143-145, metrics.py:89-98)  left = left*bool(right); right = right*bool(left)
+ *   smoothing (147-148, kdistlib.py:53-124) recursive collapse of sub-profiles, restated as the
+ *             same top-down recursion
+ *   scaling   (149-157, metrics.py:49-86)   get_scale on np.sum totals, optional scale_down,
+ *             profiles become float64
+ *   metric    0/1 multiset prod/sum, 2 euclidean, 3 cosine_similarity (metrics.py:138-147)
+ * summary: 0 = np.min, 1 = np.mean, 2 = np.median of the four quarter sums.
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API void kpal_oracle_positive(int64_t *left, int64_t *right, size_t n)
+{
+    for (size_t i = 0; i < n; i++) left[i] = right[i] != 0 ? left[i] : 0;   /* left * bool(right) */
+    for (size_t i = 0; i < n; i++) right[i] = left[i] != 0 ? right[i] : 0;  /* right * bool(new left) */
+}
+
+static int cmp_i64(const void *a, const void *b)
+{
+    const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+static double summary4(const int64_t *c, int summary)
+{
+    if (summary == 0) {                     /* np.min */
+        int64_t m = c[0];
+        for (int i = 1; i < 4; i++) if (c[i] < m) m = c[i];
+        return (double)m;
+    }
+    if (summary == 1) {                     /* np.mean: float64 accumulation, then / 4 */
+        double s = 0.0;
+        for (int i = 0; i < 4; i++) s += (double)c[i];
+        return s / 4.0;
+    }
+    int64_t t[4] = {c[0], c[1], c[2], c[3]};  /* np.median: mean of the two middle values */
+    qsort(t, 4, sizeof(int64_t), cmp_i64);
+    return ((double)t[1] + (double)t[2]) / 2.0;
+}
+
+static void collapse4(const int64_t *v, size_t start, size_t length, int64_t *out)
+{   /* kdistlib.py:53-69: reshape (4, length/4), sum over axis 1 (int64, wrapping) */
+    const size_t q = length / 4;
+    for (int i = 0; i < 4; i++) {
+        uint64_t s = 0;
+        for (size_t j = 0; j < q; j++) s += (uint64_t)v[start + (size_t)i * q + j];
+        out[i] = (int64_t)s;
+    }
+}
+
+static void dynamic_smooth_rec(int64_t *l, int64_t *r, size_t start, size_t length, int summary, double threshold)
+{   /* kdistlib.py:71-110 */
+    if (length == 1) return;
+    int64_t lc[4], rc[4];
+    collapse4(l, start, length, lc);
+    collapse4(r, start, length, rc);
+    const double fl = summary4(lc, summary), fr = summary4(rc, summary);
+    if ((fl < fr ? fl : fr) <= threshold) {
+        l[start] = (int64_t)((uint64_t)lc[0] + (uint64_t)lc[1] + (uint64_t)lc[2] + (uint64_t)lc[3]);
+        r[start] = (int64_t)((uint64_t)rc[0] + (uint64_t)rc[1] + (uint64_t)rc[2] + (uint64_t)rc[3]);
+        for (size_t i = start + 1; i < start + length; i++) l[i] = r[i] = 0;
+        return;
+    }
+    for (int i = 0; i < 4; i++) dynamic_smooth_rec(l, r, start + (size_t)i * (length / 4), length / 4, summary, threshold);
+}
+
+ORACLE_API void kpal_oracle_dynamic_smooth(int64_t *left, int64_t *right, int k, int summary, double threshold)
+{
+    dynamic_smooth_rec(left, right, 0, (size_t)1 << (2 * k), summary, threshold);
+}
+
+ORACLE_API double kpal_oracle_profile_distance(const int64_t *left, const int64_t *right, int k, int do_balance,
+                                               int do_positive, int do_smooth, int summary, double threshold,
+                                               int do_scale, int down, int metric)
+{
+    const size_t n = (size_t)1 << (2 * k);
+    int64_t *l = (int64_t *)malloc(n * sizeof(int64_t));
+    int64_t *r = (int64_t *)malloc(n * sizeof(int64_t));
+    memcpy(l, left, n * sizeof(int64_t));
+    memcpy(r, right, n * sizeof(int64_t));
+    if (do_balance) {
+        kpal_oracle_balance(l, k);
+        kpal_oracle_balance(r, k);
+    }
+    if (do_positive) kpal_oracle_positive(l, r, n);
+    if (do_smooth) kpal_oracle_dynamic_smooth(l, r, k, summary, threshold);
+    double d;
+    if (do_scale) {
+        uint64_t tl = 0, tr = 0;
+        for (size_t i = 0; i < n; i++) {
+            tl += (uint64_t)l[i];
+            tr += (uint64_t)r[i];
+        }
+        double ls = 1.0, rs = 1.0;              /* metrics.py:59-72 */
+        if ((int64_t)tl < (int64_t)tr) ls = (double)(int64_t)tr / (double)(int64_t)tl;
+        else rs = (double)(int64_t)tl / (double)(int64_t)tr;
+        if (down) {                             /* metrics.py:84-86 */
+            const double top = ls > rs ? ls : rs;
+            ls /= top;
+            rs /= top;
+        }
+        double *fl = (double *)malloc(n * sizeof(double));
+        double *fr = (double *)malloc(n * sizeof(double));
+        for (size_t i = 0; i < n; i++) {
+            fl[i] = (double)l[i] * ls;
+            fr[i] = (double)r[i] * rs;
+        }
+        if (metric <= 1) {
+            d = kpal_oracle_multiset_f64(fl, fr, n, metric, NULL);
+        } else {
+            double lr = 0.0, ll = 0.0, rr = 0.0, dd = 0.0;
+            for (size_t i = 0; i < n; i++) {
+                lr += fl[i] * fr[i];
+                ll += fl[i] * fl[i];
+                rr += fr[i] * fr[i];
+                dd += (fl[i] - fr[i]) * (fl[i] - fr[i]);
+            }
+            d = metric == 2 ? sqrt(dd) : lr / (sqrt(ll) * sqrt(rr));
+        }
+        free(fl);
+        free(fr);
+    } else if (metric <= 1) {
+        d = kpal_oracle_multiset_i64(l, r, n, metric, NULL);
+    } else if (metric == 2) {
+        d = kpal_oracle_euclidean_i64(l, r, n, NULL);
+    } else {
+        uint64_t lr = 0, ll = 0, rr = 0;        /* np.dot on int64: exact, wrapping */
+        for (size_t i = 0; i < n; i++) {
+            lr += (uint64_t)l[i] * (uint64_t)r[i];
+            ll += (uint64_t)l[i] * (uint64_t)l[i];
+            rr += (uint64_t)r[i] * (uint64_t)r[i];
+        }
+        d = (double)(int64_t)lr / (sqrt((double)(int64_t)ll) * sqrt((double)(int64_t)rr));
+    }
+    free(l);
+    free(r);
+    return d;
+}
+
 /* a12: kdistlib.distance_matrix values.  kpal/kdistlib.py:179-186: rows i = 1..P-1,
  * columns j < i, value = dist.distance(profiles[i], profiles[j]).  out holds P(P-1)/2
  * doubles, row-major in that order.  profiles: P contiguous vectors of 4^k int64. */

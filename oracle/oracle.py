@@ -55,6 +55,14 @@ def lib():
         L.kpal_oracle_distance_matrix.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, _c_f64p]
         L.kpal_oracle_distance_matrix.restype = None
+        L.kpal_oracle_positive.argtypes = [_c_i64p, _c_i64p, ctypes.c_size_t]
+        L.kpal_oracle_positive.restype = None
+        L.kpal_oracle_dynamic_smooth.argtypes = [_c_i64p, _c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.kpal_oracle_dynamic_smooth.restype = None
+        L.kpal_oracle_profile_distance.argtypes = [_c_i64p, _c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int]
+        L.kpal_oracle_profile_distance.restype = ctypes.c_double
         L.kpal_oracle_strand_balance.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int]
         L.kpal_oracle_strand_balance.restype = ctypes.c_double
         L.kpal_oracle_synth_reads.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
@@ -65,7 +73,8 @@ def lib():
 
 
 PAIRWISE = {'prod': 0, 'sum': 1}
-METRIC = {'prod': 0, 'sum': 1, 'euclidean': 2}
+METRIC = {'prod': 0, 'sum': 1, 'euclidean': 2, 'cosine': 3}
+SUMMARY = {'min': 0, 'average': 1, 'median': 2}
 
 
 def _i64(a):
@@ -164,6 +173,25 @@ def distance(left, right, length, do_balance=False, metric='prod'):
     l, lp = _i64(left)
     r, rp = _i64(right)
     return lib().kpal_oracle_distance(lp, rp, length, int(do_balance), METRIC[metric])
+
+
+def dynamic_smooth(left, right, length, summary='min', threshold=0):
+    """Restates ProfileDistance.dynamic_smooth (kdistlib.py:53-124); returns smoothed copies."""
+    l = np.array(left, dtype=np.int64)
+    r = np.array(right, dtype=np.int64)
+    lib().kpal_oracle_dynamic_smooth(l.ctypes.data_as(_c_i64p), r.ctypes.data_as(_c_i64p), length,
+                                     SUMMARY[summary], float(threshold))
+    return l, r
+
+
+def profile_distance(left, right, length, do_balance=False, do_positive=False, do_smooth=False, summary='min',
+                     threshold=0, do_scale=False, down=False, metric='prod'):
+    """Restates ProfileDistance.distance with every option (kdistlib.py:126-161)."""
+    l, lp = _i64(left)
+    r, rp = _i64(right)
+    return lib().kpal_oracle_profile_distance(lp, rp, length, int(do_balance), int(do_positive), int(do_smooth),
+                                              SUMMARY[summary], float(threshold), int(do_scale), int(down),
+                                              METRIC[metric])
 
 
 def distance_matrix_values(profiles, length, do_balance=False, metric='prod'):

@@ -155,3 +155,27 @@ def test_g4_tutorial(golden_scalars, tutorial_dir):
     assert oracle.distance_matrix_text(list('abcd'), vals, 3) == g['matrix_abcd_p3']
     assert oracle.distance(merged[0], merged[1], 8, do_balance=True) == pytest.approx(g['distance_balanced_a_b'], rel=1e-14)
     assert oracle.strand_balance(merged[0], 8) == pytest.approx(g['showbalance_a'], rel=1e-14)
+
+
+def test_g9_profile_distance_options(golden_options):
+    """Oracle restatement of positive / dynamic smoothing / scaling / cosine == the reference on the
+    G9 option grid (672 cases); smoothed vectors bit-exact."""
+    import math
+    g, z = golden_options
+    for c in g['cases']:
+        l, r = z['g9_%d_l' % c['pair']], z['g9_%d_r' % c['pair']]
+        v = oracle.profile_distance(l, r, c['k'], c['do_balance'], c['do_positive'], c['do_smooth'], c['summary'],
+                                    c['threshold'], c['do_scale'], c['down'], c['metric'])
+        assert abs(v - c['distance']) <= 1e-12 * abs(c['distance']) + 1e-300, c
+    checked = 0
+    for pi in range(g['n_pairs']):
+        for name, fn, th in g['smoothed']:
+            key = 'g9_%d_%s_l' % (pi, name)
+            if key not in z:
+                continue
+            k = int(round(math.log(z['g9_%d_l' % pi].size, 4)))
+            a, b = oracle.dynamic_smooth(z['g9_%d_l' % pi], z['g9_%d_r' % pi], k, fn, th)
+            np.testing.assert_array_equal(a, z[key])
+            np.testing.assert_array_equal(b, z['g9_%d_%s_r' % (pi, name)])
+            checked += 1
+    assert checked >= 20

@@ -9,8 +9,9 @@ tools/oracle_stubs holds import shims for two third-party packages the image lac
 (Bio.SeqIO, semantic_version); everything that computes an expected value below is the
 reference's own code: kpal.klib.Profile, kpal.metrics, kpal.kdistlib, kpal.kmer.
 
-Fixture groups follow SURVEY.md section 8c (G1..G8).  Only DATA is written: inputs and the
-reference's outputs.
+Fixture groups follow SURVEY.md section 8c (G1..G8); G9 pins every ProfileDistance option
+(balance, positive, dynamic smoothing with each summary function, scaling, every metric:
+kpal/kdistlib.py:126-161).  Only DATA is written: inputs and the reference's outputs.
 """
 from __future__ import print_function
 
@@ -332,6 +333,57 @@ def g8():
     return {'sets': sets, 'names': names, 'k': 8, 'cases': out}
 
 
+def g9(arrays):
+    """ProfileDistance option grid on random profile pairs (kdistlib.py:126-161)."""
+    rs = np.random.RandomState(9)
+    summaries = {'min': metrics.summary['min'], 'average': metrics.summary['average'],
+                 'median': metrics.summary['median']}
+    dist_funcs = {'prod': None, 'sum': None, 'euclidean': metrics.vector_distance['euclidean'],
+                  'cosine': metrics.vector_distance['cosine']}
+    pairs = []
+    for k, lam in ((2, 3.0), (3, 0.7), (3, 6.0), (4, 0.5), (4, 2.0), (4, 40.0), (5, 0.3), (5, 1.5), (5, 12.0),
+                   (6, 0.8), (6, 3.0), (7, 1.1)):
+        n = 4 ** k
+        l = rs.poisson(lam, n).astype('int64')
+        r = rs.poisson(lam * rs.uniform(0.5, 2.0), n).astype('int64')
+        if k >= 4:   # long empty stretches so that whole sub-profiles collapse
+            a, b = sorted(rs.randint(0, n, 2))
+            l[a:b] //= 3
+            r[a // 2:b // 2] = 0
+        pairs.append((k, l, r))
+    cases = []
+    for pi, (k, l, r) in enumerate(pairs):
+        arrays['g9_%d_l' % pi] = l
+        arrays['g9_%d_r' % pi] = r
+        left, right = klib.Profile(l.copy(), 'l'), klib.Profile(r.copy(), 'r')
+        for ci in range(56):
+            o = {'pair': pi, 'k': k,
+                 'do_balance': bool(rs.rand() < 0.4), 'do_positive': bool(rs.rand() < 0.3),
+                 'do_smooth': bool(rs.rand() < 0.6),
+                 'summary': ['min', 'average', 'median'][rs.randint(3)],
+                 'threshold': [0, 1, 2, 5, 0.5, 2.5, 7.25][rs.randint(7)],
+                 'do_scale': bool(rs.rand() < 0.4), 'down': bool(rs.rand() < 0.5),
+                 'metric': ['prod', 'sum', 'euclidean', 'cosine'][rs.randint(4)]}
+            d = kdistlib.ProfileDistance(
+                do_balance=o['do_balance'], do_positive=o['do_positive'], do_smooth=o['do_smooth'],
+                summary=summaries[o['summary']], threshold=o['threshold'], do_scale=o['do_scale'],
+                down=o['down'], distance_function=dist_funcs[o['metric']],
+                pairwise=metrics.pairwise[o['metric'] if o['metric'] in ('prod', 'sum') else 'prod'])
+            with np.errstate(all='ignore'):
+                o['distance'] = float(d.distance(left, right))
+            assert (left.counts == l).all() and (right.counts == r).all()
+            cases.append(o)
+        # the smoothed vectors themselves, for three settings per pair
+        if k <= 5:
+            for name, fn, th in (('min0', 'min', 0), ('avg2', 'average', 2), ('med25', 'median', 2.5)):
+                a, b = left.copy(), right.copy()
+                kdistlib.ProfileDistance(do_smooth=True, summary=summaries[fn], threshold=th).dynamic_smooth(a, b)
+                arrays['g9_%d_%s_l' % (pi, name)] = a.counts
+                arrays['g9_%d_%s_r' % (pi, name)] = b.counts
+    return {'n_pairs': len(pairs), 'smoothed': [['min0', 'min', 0], ['avg2', 'average', 2], ['med25', 'median', 2.5]],
+            'cases': cases}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     arrays = {}
@@ -345,6 +397,10 @@ def main():
     with open(os.path.join(OUT, 'scalars.json'), 'w') as fh:
         json.dump(scal, fh, indent=1)
     np.savez_compressed(os.path.join(OUT, 'vectors.npz'), **arrays)
+    opt_arrays = {}
+    with open(os.path.join(OUT, 'options.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G9': g9(opt_arrays)}, fh, indent=0)
+    np.savez_compressed(os.path.join(OUT, 'options.npz'), **opt_arrays)
     print('wrote', sorted(os.listdir(OUT)))
 
 
