@@ -330,6 +330,12 @@ class Context(object):
                                              ctypes.byref(out)))
         return out.value
 
+    def profile_distance_device(self, k, dev_left, dev_right, options):
+        out = ctypes.c_double(0.0)
+        _check(self._L.kpal_profile_distance_device(self._h, int(k), _vp(dev_left), _vp(dev_right),
+                                                    ctypes.byref(options), ctypes.byref(out)))
+        return out.value
+
     def dynamic_smooth(self, left, right, k, summary, threshold):
         """In place on two writable contiguous int64 vectors (kdistlib.py:112-124)."""
         _check(self._L.kpal_dynamic_smooth(self._h, int(k), left.ctypes.data, right.ctypes.data, int(summary),

@@ -872,7 +872,7 @@ KPAL_API int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *d
     if (do_balance) {
         if (k < 1 || k > KPAL_MAX_K || n != (1ULL << (2 * k))) return set_err(KPAL_E_INVALID, "do_balance needs n == 4^k");
         if (k >= 6) {   // fused balance + distance: balanced values are formed in LDS tiles, never written
-            const unsigned grid = 1u << (2 * (k - 6));
+            const unsigned grid = std::min<unsigned>(1u << (2 * (k - 6)), (unsigned)ctx->num_cu * 2);   // persistent
             CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
             Partial *pp = (Partial *)ctx->partials.p;
             if (metric == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<0>), dim3(grid), dim3(1024), l, r, k, pp);

@@ -244,54 +244,95 @@ __global__ __launch_bounds__(256) void pair_distance_kernel(const T *__restrict_
 }
 
 // ---- fused balance + distance, fused split + multiset (k >= 6) ----------------------------------
-// Same tiling as balance_tiled_kernel: the workgroup of tile pair (M, rc(M)) holds both tiles of
-// both profiles in LDS (4 x 64 x 65 x 8 B = 130 KiB), forms the balanced values
-// x = l[i] + l[rc(i)], y = r[i] + r[rc(i)] on the fly (kpal/kdistlib.py:139-141) and reduces the
-// metric over the 2 x 4096 bins of the pair -- 16 B of HBM traffic per bin, no balanced copies.
+// Same tiling as balance_tiled_kernel: the workgroup of tile pair (M, rc(M)) forms the balanced
+// values x = l[i] + l[rc(i)], y = r[i] + r[rc(i)] on the fly (kpal/kdistlib.py:139-141) and
+// reduces the metric over the 2 x 4096 bins of the pair -- 16 B of HBM traffic per bin, no balanced
+// copies.  The two LDS tiles (66 KiB: two workgroups per CU) are used twice: first for the left
+// profile, whose balanced values stay in registers (8 per thread), then for the right profile,
+// whose global loads are already in flight while the left one is transposed.
 template <int METRIC>
 __global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int64_t *__restrict__ l,
                                                                       const int64_t *__restrict__ r, int k,
                                                                       Partial *__restrict__ partials)
 {
     constexpr int T = 3, S = 64;
-    __shared__ unsigned long long Al[S][S + 1], Bl[S][S + 1], Ar[S][S + 1], Br[S][S + 1];
+    __shared__ unsigned long long A[S][S + 1], B[S][S + 1];
     const int md = k - 2 * T;
-    const uint64_t M = blockIdx.x;
-    const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+    const uint64_t nM = 1ULL << (2 * md);
+    const uint64_t rowstride = 1ULL << (2 * (k - T));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rl = (int)revcomp((uint64_t)lane, T);
+    const unsigned long long *ul = reinterpret_cast<const unsigned long long *>(l);
+    const unsigned long long *ur = reinterpret_cast<const unsigned long long *>(r);
     Partial p = {0.0, 0ULL};
-    if (M <= Mr) {   // block-uniform
-        const bool self = M == Mr;
-        const uint64_t rowstride = 1ULL << (2 * (k - T));
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const unsigned long long *ul = reinterpret_cast<const unsigned long long *>(l);
-        const unsigned long long *ur = reinterpret_cast<const unsigned long long *>(r);
-        for (int h = w; h < S; h += 16) {
-            Al[h][lane] = ul[(uint64_t)h * rowstride + M * S + lane];
-            Ar[h][lane] = ur[(uint64_t)h * rowstride + M * S + lane];
-            if (!self) {
-                Bl[h][lane] = ul[(uint64_t)h * rowstride + Mr * S + lane];
-                Br[h][lane] = ur[(uint64_t)h * rowstride + Mr * S + lane];
+    // persistent workgroups over the canonical tile pairs (M <= rc(M)); the next pair's 16 values
+    // per thread are loaded before the current pair is transposed and reduced
+    auto canonical_from = [&](uint64_t m) {
+        while (m < nM && md > 0 && m > revcomp(m, md)) m += gridDim.x;
+        return m;
+    };
+    auto fetch = [&](uint64_t M, unsigned long long (&la)[4], unsigned long long (&lb)[4], unsigned long long (&ra)[4],
+                     unsigned long long (&rb)[4]) {
+        const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t row = (uint64_t)(w + 16 * q) * rowstride;
+            la[q] = ul[row + M * S + lane];
+            lb[q] = ul[row + Mr * S + lane];
+            ra[q] = ur[row + M * S + lane];
+            rb[q] = ur[row + Mr * S + lane];
+        }
+    };
+    auto term = [&](unsigned long long xu, unsigned long long yu) {
+        const int64_t x = (int64_t)xu, y = (int64_t)yu;
+        if constexpr (METRIC == 2) {
+            const uint64_t d = (uint64_t)x - (uint64_t)y;
+            p.m += d * d;
+        } else {
+            if (x != 0 || y != 0) {
+                p.s += METRIC == 0 ? pw_prod(x, y) : pw_sum(x, y);
+                p.m += 1;
             }
         }
-        __syncthreads();
-        auto term = [&](unsigned long long xu, unsigned long long yu) {
-            const int64_t x = (int64_t)xu, y = (int64_t)yu;
-            if constexpr (METRIC == 2) {
-                const uint64_t d = (uint64_t)x - (uint64_t)y;
-                p.m += d * d;
-            } else {
-                if (x != 0 || y != 0) {
-                    p.s += METRIC == 0 ? pw_prod(x, y) : pw_sum(x, y);
-                    p.m += 1;
-                }
+    };
+    unsigned long long la[4], lb[4], ra[4], rb[4], nla[4], nlb[4], nra[4], nrb[4];
+    uint64_t M = canonical_from(blockIdx.x);
+    if (M < nM) fetch(M, la, lb, ra, rb);
+    while (M < nM) {
+        const uint64_t Mn = canonical_from(M + gridDim.x);
+        if (Mn < nM) fetch(Mn, nla, nlb, nra, nrb);
+        const bool self = md == 0 || M == revcomp(M, md);
+        auto exchange = [&](unsigned long long (&a)[4], unsigned long long (&b)[4]) {
+            // a/b: this thread's bins of tile M / rc(M); on return each holds bin + bin[rc]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                A[w + 16 * q][lane] = a[q];
+                B[w + 16 * q][lane] = b[q];   // self: B == A
             }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rh = (int)revcomp((uint64_t)(w + 16 * q), T);
+                a[q] += B[rl][rh];
+                b[q] += A[rl][rh];
+            }
+            __syncthreads();
         };
-        const int rl = (int)revcomp((uint64_t)lane, T);
-        for (int h = w; h < S; h += 16) {
-            const int rh = (int)revcomp((uint64_t)h, T);
-            term(Al[h][lane] + (self ? Al[rl][rh] : Bl[rl][rh]), Ar[h][lane] + (self ? Ar[rl][rh] : Br[rl][rh]));
-            if (!self) term(Bl[h][lane] + Al[rl][rh], Br[h][lane] + Ar[rl][rh]);
+        exchange(la, lb);
+        exchange(ra, rb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            term(la[q], ra[q]);
+            if (!self) term(lb[q], rb[q]);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            la[q] = nla[q];
+            lb[q] = nlb[q];
+            ra[q] = nra[q];
+            rb[q] = nrb[q];
+        }
+        M = Mn;
     }
     p = block_reduce(p);
     if (threadIdx.x == 0) partials[blockIdx.x] = p;

@@ -23,6 +23,9 @@ for rep in range(a.reps + 1):
     for metric in (0, 1, 2):
         ctx.pair_distance_device(n, dl, dr, metric)
     ctx.pair_distance_device(n, dl, dr, 0, do_balance=True, k=a.k)
+    # the full option pipeline: balance + positive + smoothing (median) + scaling + cosine
+    ctx.profile_distance_device(a.k, dl, dr, _native.DistanceOptions(do_balance=1, do_positive=1, do_smooth=1, summary=2,
+                                                                  threshold=3.0, do_scale=1, down=0, metric=3))
     ctx.balance_device(a.k, dl)
 prof = ctx.prof_get()
 print('k=%d  n=%d bins (%.0f MB per vector)' % (a.k, n, n * 8 / 1e6))
