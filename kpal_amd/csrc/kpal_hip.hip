@@ -86,6 +86,7 @@ struct kpal_ctx {
     DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
+    static constexpr size_t kStagePad = 64;
     void *pinned[2] = {nullptr, nullptr};
     DevBuf dstage[2];
     hipEvent_t ev_copied[2] = {nullptr, nullptr};
@@ -557,6 +558,37 @@ KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t n
     return count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
 }
 
+static int ensure_pinned(kpal_ctx *ctx)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->pinned[i]) {
+            hipError_t e = hipHostMalloc(&ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStagePad, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+        }
+    }
+    return KPAL_OK;
+}
+
+// Pageable host memory -> device through the two pinned staging buffers: the memcpy into one
+// overlaps the DMA out of the other.  ctx->stream waits for the last piece.
+static int h2d_staged(kpal_ctx *ctx, uint8_t *dev_dst, const uint8_t *host_src, size_t n)
+{
+    CHK(ensure_pinned(ctx));
+    const size_t stage = kpal_ctx::kStage;
+    int slot = 0, last = -1;
+    for (size_t off = 0; off < n; off += stage, slot ^= 1) {
+        const size_t len = std::min(stage, n - off);
+        if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // its previous DMA is done
+        memcpy(ctx->pinned[slot], host_src + off, len);
+        HIPCHK(hipMemcpyAsync(dev_dst + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        ctx->stage_used[slot] = true;
+        last = slot;
+    }
+    if (last >= 0) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[last], 0));
+    return KPAL_OK;
+}
+
 KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
 {
     CTX_ENTER(ctx);
@@ -565,14 +597,9 @@ KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbyt
     if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
     const size_t km1 = (size_t)ctx->k - 1;
     const size_t stage = kpal_ctx::kStage;
-    const size_t pad = 64;  // room for the halo, keeps the payload 16-byte aligned
-    for (int i = 0; i < 2; ++i) {
-        if (!ctx->pinned[i]) {
-            hipError_t e = hipHostMalloc(&ctx->pinned[i], stage + pad, hipHostMallocDefault);
-            if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
-        }
-        CHK(ensure(ctx, ctx->dstage[i], stage + pad));
-    }
+    const size_t pad = kpal_ctx::kStagePad;  // room for the halo, keeps the payload 16-byte aligned
+    CHK(ensure_pinned(ctx));
+    for (int i = 0; i < 2; ++i) CHK(ensure(ctx, ctx->dstage[i], stage + pad));
     int slot = 0;
     for (size_t off = 0; off < nbytes; off += stage, slot ^= 1) {
         const size_t len = std::min(stage, nbytes - off);
@@ -629,7 +656,8 @@ static int fasta_flatten_to_device(kpal_ctx *ctx, const uint8_t *host_buf, size_
     long long *carry = last_eol + nblocks;
     uint64_t *offs = (uint64_t *)(carry + nblocks);
     uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
-    HIPCHK(hipMemcpyAsync(raw, host_buf + first, n, hipMemcpyHostToDevice, ctx->stream));
+    // fa_raw is free: the previous call synchronised after its last reader (fa_scatter)
+    CHK(h2d_staged(ctx, raw, host_buf + first, n));
     LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, last_eol);
     LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
     LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, (const long long *)carry, kept);

@@ -26,6 +26,7 @@ import numpy as np
 from . import _native, metrics
 
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
+_JOIN_BLOCK = 4096       # sequences joined per C-level call
 _FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
 _WHITESPACE = {ord(c): None for c in ' \t\n\v\f\r'}
 
@@ -47,6 +48,37 @@ def _fasta_records(handle):
             parts.append(line.translate(_WHITESPACE))
     if name is not None:
         yield name, ''.join(parts)
+
+
+def _first_boundary(text):
+    """Index of the end-of-line byte before the first header line of ``text`` (the first
+    occurrence of EOL followed by ``>``), or -1; a chunk that itself starts with ``>`` starts a
+    record at 0 only if the previous chunk ended with an EOL, which the caller's carry contains."""
+    a = text.find(b'\n>')
+    b = text.find(b'\r>', 0, a + 1) if a >= 0 else text.find(b'\r>')   # only an earlier one matters
+    if a < 0:
+        return b
+    return a if b < 0 else min(a, b)
+
+
+def _last_boundary(text, begin):
+    """Index of the end-of-line byte before the last header line at or after ``begin``, or -1."""
+    a = text.rfind(b'\n>', begin)
+    b = text.rfind(b'\r>', max(begin, a))    # only a later one matters
+    return max(a, b)
+
+
+def _join_block(block):
+    """One flat byte string for a block of sequences, ``\\n`` between them: C-speed joins for the
+    homogeneous cases (all ``str`` / all ``bytes``), per-item encoding otherwise."""
+    try:
+        return '\n'.join(block).encode('latin-1', 'replace')
+    except TypeError:
+        pass
+    try:
+        return b'\n'.join(block)
+    except TypeError:
+        return b'\n'.join(_encode(s) for s in block)
 
 
 def _encode(sequence):
@@ -99,19 +131,33 @@ class Profile(object):
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         ctx = _native.context()
         ctx.count_begin(length)
-        pending = b''
+        carry = b''   # the unfinished last record of the previous chunk (small)
         while True:
             text = handle.read(_FASTA_CHUNK)
             if not text:
                 break
-            pending += text if isinstance(text, bytes) else text.encode('latin-1', 'replace')
-            # keep the (possibly unfinished) last record for the next round
-            cut = max(pending.rfind(b'\n>'), pending.rfind(b'\r>'))
-            if cut > 0:
-                ctx.count_feed_fasta(pending[:cut + 1])
-                pending = pending[cut + 1:]
-        if pending:
-            ctx.count_feed_fasta(pending)
+            if not isinstance(text, bytes):
+                text = text.encode('latin-1', 'replace')
+            view = np.frombuffer(text, dtype=np.uint8)   # zero-copy: slices below are views
+            begin = 0
+            if carry:
+                # finish the straddling record: up to the first record boundary of this chunk
+                first = _first_boundary(text)
+                if first < 0:
+                    carry += text
+                    continue
+                ctx.count_feed_fasta(carry + text[:first + 1])
+                carry = b''
+                begin = first + 1
+            # whole records of this chunk; the (possibly unfinished) last one is carried over
+            cut = _last_boundary(text, begin)
+            if cut >= begin:
+                ctx.count_feed_fasta(view[begin:cut + 1])
+                carry = text[cut + 1:]
+            else:
+                carry = text[begin:]
+        if carry:
+            ctx.count_feed_fasta(carry)
         return cls(ctx.count_finish(), name=name)
 
     @classmethod
@@ -132,18 +178,22 @@ class Profile(object):
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         ctx = _native.context()
         ctx.count_begin(length)
+        it = iter(sequences)
         pending = []
         size = 0
-        for sequence in sequences:
-            data = _encode(sequence)
+        while True:
+            block = list(itertools.islice(it, _JOIN_BLOCK))
+            if not block:
+                break
+            data = _join_block(block)
             pending.append(data)
             size += len(data) + 1
             if size >= _FEED_BYTES:
                 # feeds are independent: a window never spans two feeds, nor two sequences
-                ctx.count_feed(b'\n'.join(pending))
+                ctx.count_feed(pending[0] if len(pending) == 1 else b'\n'.join(pending))
                 pending, size = [], 0
         if pending:
-            ctx.count_feed(b'\n'.join(pending))
+            ctx.count_feed(pending[0] if len(pending) == 1 else b'\n'.join(pending))
         return cls(ctx.count_finish(), name=name)
 
     # ---- properties ------------------------------------------------------------------------
