@@ -51,10 +51,10 @@ extern "C" {
 
 /* counting strategies (kpal_count_set_strategy) */
 #define KPAL_STRATEGY_AUTO 0
-#define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k */
+#define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k (reference implementation, never AUTO) */
 #define KPAL_STRATEGY_LDS_DIRECT 2    /* whole 4^k table privatised in LDS; k <= 7 */
 #define KPAL_STRATEGY_PARTITION 3     /* radix-partition keys, histogram buckets in LDS; 8 <= k <= 12 */
-#define KPAL_STRATEGY_PARTITION2 4    /* two-level radix partition; 13 <= k <= 15 */
+#define KPAL_STRATEGY_PARTITION2 4    /* two-level radix partition; 13 <= k <= 16 */
 
 typedef struct kpal_ctx kpal_ctx;
 

@@ -90,6 +90,32 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so /
+    libhsa-runtime64.so; if libkpal_hip.so pulled in /opt/rocm's copy first, a later ``import torch``
+    would start a second runtime that finds no GPU.  When PyTorch is installed (it is only needed
+    for the multi-GPU reduce), load its copies first -- libkpal_hip.so then binds to them by soname,
+    whichever of the two packages the caller imports first.  Does not import torch."""
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libkpal_hip.so (once).  Raises NativeLibraryMissing if it has not been built."""
     global _lib
@@ -99,6 +125,7 @@ def load():
                 raise NativeLibraryMissing(
                     '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                     '(hipcc --offload-arch=gfx950).  kpal_amd has no CPU fallback.' % LIB_PATH)
+            _share_hip_runtime_with_torch()
             L = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 if 'KPAL_HIP_LIBRARY' in os.environ and not hasattr(L, name):

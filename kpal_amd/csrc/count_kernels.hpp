@@ -6,7 +6,7 @@
 //                       (any k; the k >= 13 path, where the table is 0.5 - 32 GiB).
 //   * LDS direct      : k <= 7, the whole table is privatised per workgroup in LDS as u32
 //                       (bank-replicated for tiny k), merged with one atomic per non-zero bin.
-//   * partition       : 8 <= k <= 15: partition_kernels.hpp.
+//   * partition       : 8 <= k <= 16: partition_kernels.hpp.
 #pragma once
 #include "kpal_device.hpp"
 

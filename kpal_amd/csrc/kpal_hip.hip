@@ -216,11 +216,11 @@ static int prof_collect(kpal_ctx *ctx)
         return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);                   \
     }
 
-#define DISPATCH_K_13_15(k, ...)                                                                   \
+#define DISPATCH_K_13_16(k, ...)                                                                   \
     switch (k) {                                                                                   \
-        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__)                    \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__) \
     default:                                                                                       \
-        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 15 (k=%d)", k); \
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k); \
     }
 
 #define DISPATCH_K_8_12(k, ...)                                                                   \
@@ -373,12 +373,12 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     int s = ctx->strategy;
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
-        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : (k <= 15 ? KPAL_STRATEGY_PARTITION2 : KPAL_STRATEGY_GLOBAL_ATOMIC));
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : KPAL_STRATEGY_PARTITION2);
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
     if (s == KPAL_STRATEGY_PARTITION && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
-    if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 15))
-        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 15 (k=%d)", k);
+    if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 16))
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
     *out = s;
     return KPAL_OK;
 }
@@ -483,7 +483,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     uint16_t *keys = (uint16_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     const uint64_t *no_base = nullptr;
-    DISPATCH_K_13_15(ctx->k, {
+    DISPATCH_K_13_16(ctx->k, {
         LAUNCH(ctx, "coarse_count", (coarse_count_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb, cnt1);
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(NB1), dim3(256), (const uint32_t *)cnt1, G1, offs1, total1);
         LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)total1,

@@ -475,22 +475,24 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
 }
 
 // ==========================================================================================
-// Two-level path, k = 13..15.
+// Two-level path, k = 13..16.
 // ==========================================================================================
 constexpr int kResidualBits = 24;        // residual = a k=12 k-mer
 constexpr int kResKeyBits = kResidualBits - kPartBits;  // 15
-constexpr int kCoarseRows = 64;          // virtual rows of the coarse staging (bucket x replica)
-constexpr int kCoarseCap = 256;          // u32 slots per virtual row (64 rows x 256 x 4 B = 64 KiB)
+constexpr int kCoarseSlots = 16384;      // u32 staging slots per workgroup (64 KiB)
 constexpr int kCoarseThreads = 512;      // 8 waves, one step per wave per tile (8 KiB of input)
 
 template <int K>
 struct CoarseCfg {
-    static constexpr int kBits = 2 * K - kResidualBits;  // 2, 4, 6
-    static constexpr int kBuckets = 1 << kBits;          // 4, 16, 64
-    // replicas per coarse bucket: spreads the LDS slot counters of a few buckets over more
-    // addresses; a wave's 8 virtual rows always hold whole buckets
-    static constexpr int kRep = (kCoarseRows / kBuckets) > 8 ? 8 : (kCoarseRows / kBuckets);
-    static constexpr int kRows = kBuckets * kRep;        // 32, 64, 64
+    static constexpr int kBits = 2 * K - kResidualBits;  // 2, 4, 6, 8
+    static constexpr int kBuckets = 1 << kBits;          // 4, 16, 64, 256
+    // virtual rows of the staging = bucket x replica.  Replicas spread the LDS slot counters of
+    // a few buckets over more addresses; a wave's rows always hold whole buckets.
+    static constexpr int kRowsAlloc = kBuckets > 64 ? kBuckets : 64;   // 64, 64, 64, 256
+    static constexpr int kRep = (kRowsAlloc / kBuckets) > 8 ? 8 : (kRowsAlloc / kBuckets);   // 8, 4, 1, 1
+    static constexpr int kRows = kBuckets * kRep;        // 32, 64, 64, 256
+    static constexpr int kCap = kCoarseSlots / kRowsAlloc;   // u32 slots per row: 256, 256, 256, 64
+    static constexpr int kRowsPerWave = kRowsAlloc / (kCoarseThreads / 64);   // 8, 8, 8, 32
 };
 
 // C1: per-(coarse bucket, block) counts; cnt1[c * G + blk].  One step range per wave like A1.
@@ -539,15 +541,17 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
                                                                         const uint64_t *__restrict__ start1,
                                                                         uint32_t *__restrict__ res_out)
 {
-    constexpr int NB = CoarseCfg<K>::kBuckets, REP = CoarseCfg<K>::kRep, ROWS = CoarseCfg<K>::kRows;
-    __shared__ __attribute__((aligned(16))) uint32_t rows[kCoarseRows * kCoarseCap + 4];  // 64 KiB + dummy
-    __shared__ uint32_t pos[kCoarseRows];
-    __shared__ uint64_t rowbase[kCoarseRows];  // global position of each virtual row's run in this tile
-    __shared__ uint64_t gcur[kCoarseRows];     // per coarse bucket (first NB entries)
+    using CFG = CoarseCfg<K>;
+    constexpr int NB = CFG::kBuckets, REP = CFG::kRep, ROWS = CFG::kRows, RALLOC = CFG::kRowsAlloc, CAP = CFG::kCap;
+    constexpr int RPW = CFG::kRowsPerWave;
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kCoarseSlots + 4];  // 64 KiB + dummy
+    __shared__ uint32_t pos[RALLOC];
+    __shared__ uint64_t rowbase[RALLOC];  // global position of each virtual row's run in this tile
+    __shared__ uint64_t gcur[RALLOC];     // per coarse bucket (first NB entries)
     __shared__ uint32_t overflowed;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < NB) gcur[threadIdx.x] = start1[threadIdx.x] + offs1[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x];
-    if (threadIdx.x < kCoarseRows) pos[threadIdx.x] = 0;
+    if (threadIdx.x < RALLOC) pos[threadIdx.x] = 0;
     if (threadIdx.x == 0) overflowed = 0;
     __syncthreads();
     const uint64_t total_steps = (s.nchunks + 63) / 64;
@@ -572,17 +576,17 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
         for (int j = 0; j < 16; ++j) {
             const uint32_t kmer = kmer_at<K>(window, j);
             const uint32_t vrow = (kmer >> kResidualBits) * REP + myrep;
-            const bool staged = ((mask >> (15 - j)) & 1u) && slot[j] < (uint32_t)kCoarseCap;
-            const uint32_t at = staged ? vrow * kCoarseCap + ((slot[j] + vrow) & (kCoarseCap - 1)) : (uint32_t)(kCoarseRows * kCoarseCap);
+            const bool staged = ((mask >> (15 - j)) & 1u) && slot[j] < (uint32_t)CAP;
+            const uint32_t at = staged ? vrow * CAP + ((slot[j] + vrow) & (CAP - 1)) : (uint32_t)kCoarseSlots;
             rows[at] = kmer & ((1u << kResidualBits) - 1u);
             smax = max(smax, slot[j]);
         }
-        if (smax >= (uint32_t)kCoarseCap) overflowed = 1;   // benign race: every writer stores 1
+        if (smax >= (uint32_t)CAP) overflowed = 1;   // benign race: every writer stores 1
         __syncthreads();
         const uint32_t any_overflow = overflowed;            // stable until the barrier below
-        // wave w owns virtual rows [8w, 8w+8) = whole buckets; lanes 0..7 turn counts into positions
+        // wave w owns virtual rows [RPW*w, RPW*w + RPW) = whole buckets; lanes 0..RPW-1 turn counts into positions
         {
-            const int myrow = wave * 8 + (lane & 7);
+            const int myrow = wave * RPW + (lane & (RPW - 1));
             const uint32_t n = (myrow < ROWS) ? pos[myrow] : 0u;
             uint32_t incl = n;                               // inclusive scan inside each group of REP lanes
 #pragma unroll
@@ -592,26 +596,26 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
             }
             const int bucket = myrow / REP;
             const uint64_t g = (myrow < ROWS) ? gcur[bucket] + (incl - n) : 0ULL;
-            if (lane < 8 && myrow < ROWS) {
+            if (lane < RPW && myrow < ROWS) {
                 rowbase[myrow] = g;
                 if ((lane & (REP - 1)) == REP - 1) gcur[bucket] += incl;   // last replica advances the bucket cursor
                 pos[myrow] = 0;
             }
             const uint64_t addr = (uint64_t)res_out + 4ULL * g;
             const uint32_t a_lo = (uint32_t)addr, a_hi = (uint32_t)(addr >> 32);
-            const uint32_t nbytes = 4u * min(n, (uint32_t)kCoarseCap);
+            const uint32_t nbytes = 4u * min(n, (uint32_t)CAP);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RPW; ++i) {
                 const uint32_t lo = __builtin_amdgcn_readlane(a_lo, i);
                 const uint32_t hi = __builtin_amdgcn_readlane(a_hi, i);
                 const uint32_t nb = __builtin_amdgcn_readlane(nbytes, i);
                 __amdgpu_buffer_rsrc_t rsrc =
                     __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
-                const uint32_t vrow = wave * 8 + i;
+                const uint32_t vrow = wave * RPW + i;
 #pragma unroll
-                for (int q = 0; q < kCoarseCap / 64; ++q) {
+                for (int q = 0; q < CAP / 64; ++q) {
                     const uint32_t sl = q * 64 + lane;
-                    const uint32_t val = rows[vrow * kCoarseCap + ((sl + vrow) & (kCoarseCap - 1))];
+                    const uint32_t val = rows[vrow * CAP + ((sl + vrow) & (CAP - 1))];
                     __builtin_amdgcn_raw_buffer_store_b32((int)val, rsrc, 4 * (int)sl, 0, 0);
                 }
             }
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
         if (any_overflow) {   // block-uniform; skewed input only
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                if (((mask >> (15 - j)) & 1u) && slot[j] >= (uint32_t)kCoarseCap) {
+                if (((mask >> (15 - j)) & 1u) && slot[j] >= (uint32_t)CAP) {
                     const uint32_t kmer = kmer_at<K>(window, j);
                     const uint32_t vrow = (kmer >> kResidualBits) * REP + myrep;
                     res_out[rowbase[vrow] + slot[j]] = kmer & ((1u << kResidualBits) - 1u);

@@ -23,7 +23,7 @@ def strategies(k):
         s.append('lds_direct')
     if 8 <= k <= 12:
         s.append('partition')
-    if 13 <= k <= 15:
+    if 13 <= k <= 16:
         s.append('partition2')
     return s
 
@@ -284,3 +284,55 @@ def test_full_size_k15(ctx):
         assert np.array_equal(a, full)
     finally:
         ctx.free(d)
+
+
+def _kmers_numpy(buf, k, read_len=150):
+    """All valid k-mer indices of '\\n'-terminated fixed-length reads, vectorised on the host."""
+    lut = np.full(256, 255, dtype=np.uint8)
+    for ch, v in zip(b'ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
+        lut[ch] = v
+    codes = lut[buf.reshape(-1, read_len + 1)[:, :read_len]]
+    n_win = read_len - k + 1
+    idx = np.zeros((codes.shape[0], n_win), dtype=np.uint64)
+    bad = np.zeros((codes.shape[0], n_win), dtype=bool)
+    for i in range(k):
+        c = codes[:, i:i + n_win]
+        bad |= c == 255
+        idx = (idx << np.uint64(2)) | (c & 3).astype(np.uint64)
+    return idx[~bad]
+
+
+def test_k16_two_level_on_device(ctx):
+    """k = 16 (32 GiB table, never copied to the host): the two-level partition path against the
+    k-mers enumerated with NumPy and against the global-atomic kernel, compared on the device."""
+    torch = pytest.importorskip('torch')
+    from kpal_amd import _native, dist
+    k, n_reads = 16, 150_000
+    buf = oracle.synth_reads(16, 0, n_reads, 150, noisy=True)
+    want_idx, want_cnt = np.unique(_kmers_numpy(buf, k), return_counts=True)
+    d = ctx.alloc(buf.size)
+    other = _native.Context(ctx.device)
+    try:
+        ctx.h2d(d, buf)
+        ctx.count_begin(k)                       # auto -> partition2
+        ctx.count_feed_device(d, buf.size)
+        ctx.count_feed(b'GATTACAGATTACACATGCATGCAAACCCGGGTTT')   # + a short host feed
+        ctx.count_finish(to_host=False)
+        ctx.sync()
+        t = dist.table_as_tensor(ctx)
+        assert t.numel() == 4 ** k
+        extra = np.array([_enc(b'GATTACAGATTACACATGCATGCAAACCCGGGTTT'[i:i + k]) for i in range(35 - k + 1)], dtype=np.uint64)
+        all_idx, all_cnt = np.unique(np.concatenate([np.repeat(want_idx, want_cnt), extra]), return_counts=True)
+        assert int(t.sum()) == int(all_cnt.sum())
+        assert int(torch.count_nonzero(t)) == all_idx.size
+        got = t[torch.as_tensor(all_idx.astype(np.int64), device=t.device)].cpu().numpy()
+        np.testing.assert_array_equal(got, all_cnt)
+        other.count_begin(k, 'global_atomic')
+        other.count_feed(buf)
+        other.count_feed(b'GATTACAGATTACACATGCATGCAAACCCGGGTTT')
+        other.count_finish(to_host=False)
+        other.sync()
+        assert torch.equal(t, dist.table_as_tensor(other))
+    finally:
+        ctx.free(d)
+        other.close()
