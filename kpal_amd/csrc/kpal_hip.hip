@@ -80,6 +80,7 @@ struct kpal_ctx {
     DevBuf table;  // int64[4^k]
     uint64_t bins = 0;
     size_t batch_bytes = (size_t)1 << 30;
+    uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
@@ -266,6 +267,10 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
     if (const char *e = getenv("KPAL_BATCH_BYTES")) {
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= (1ULL << 20)) ctx->batch_bytes = (size_t)v;
+    }
+    if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
+        unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 1024) ctx->split_above = v;
     }
     *out = ctx;
     return KPAL_OK;
@@ -458,7 +463,9 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
-// Two-level partition, k = 13..15: coarse count/scan/scatter into 24-bit residuals, then the
+constexpr int kSplitBatch = 1;   // launch_partition2: a coarse bucket would overflow its 32-bit offsets
+
+// Two-level partition, k = 13..16: coarse count/scan/scatter into 24-bit residuals, then the
 // one-level pipeline on every coarse bucket's residual stream (2-D launches over coarse buckets).
 static int launch_partition2(kpal_ctx *ctx, const Span &s)
 {
@@ -470,8 +477,11 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     spb = (spb + 7) / 8 * 8;   // 8 waves, one step per wave per tile
     const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
     const uint64_t max_keys = s.nchunks * 16;
-    CHK(ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64));
-    CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
+    if (ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64) != KPAL_OK ||
+        ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK) {
+        if (max_keys <= ((uint64_t)1 << 30)) return KPAL_E_NOMEM;
+        return kSplitBatch;   // not enough HBM for a batch of this size: retry with half
+    }
     CHK(ensure(ctx, ctx->cnt1, (size_t)NB1 * G1 * sizeof(uint32_t)));
     CHK(ensure(ctx, ctx->offs1, (size_t)NB1 * G1 * sizeof(uint32_t)));
     CHK(ensure(ctx, ctx->start1, (size_t)(2 * NB1 + 2) * sizeof(uint64_t)));
@@ -488,16 +498,20 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(NB1), dim3(256), (const uint32_t *)cnt1, G1, offs1, total1);
         LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)total1,
                (uint32_t)NB1, no_base, start1);
-        LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
-               (const uint32_t *)offs1, (const uint64_t *)start1, res);
     });
-    // coarse bucket sizes size the level-2 launches (one small D2H + sync per batch)
+    // coarse bucket sizes: they size the level-2 launches and guard the 32-bit in-bucket offsets
+    // (one small D2H + sync per batch)
     std::vector<uint64_t> h1((size_t)NB1 + 1);
     HIPCHK(hipMemcpyAsync(h1.data(), start1, h1.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     uint64_t maxn = 0;
     for (int c = 0; c < NB1; ++c) maxn = std::max(maxn, h1[c + 1] - h1[c]);
     if (maxn == 0) return KPAL_OK;
+    if (maxn > ctx->split_above && s.nchunks > 64) return kSplitBatch;   // skewed batch: the caller halves it
+    DISPATCH_K_13_16(ctx->k, {
+        LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
+               (const uint32_t *)offs1, (const uint64_t *)start1, res);
+    });
     const uint64_t g2_target = std::max<uint64_t>(8, (uint64_t)ctx->num_cu * 8 / NB1);
     uint64_t kpb = (maxn + g2_target - 1) / g2_target;
     kpb = (kpb + kKeysPerBlockQuantum - 1) / kKeysPerBlockQuantum * kKeysPerBlockQuantum;
@@ -533,7 +547,13 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
-    else if (strat == KPAL_STRATEGY_PARTITION2) piece = std::min<size_t>(ctx->batch_bytes * 4, (size_t)0xF0000000u);  // few table merges; < 2^32 keys
+    else if (strat == KPAL_STRATEGY_PARTITION2) {
+        // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
+        // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
+        // only four coarse buckets); larger batches are checked per coarse bucket and halved if needed.
+        piece = ctx->k == 13 ? std::min<size_t>(ctx->batch_bytes * 4, (size_t)0xF0000000u)
+                             : std::min<size_t>(ctx->batch_bytes * 16, (size_t)16 << 30);
+    }
     else if (strat == KPAL_STRATEGY_LDS_DIRECT) piece = (size_t)1 << 31;
     piece &= ~(size_t)15;
     if (piece == 0) piece = 16;
@@ -544,7 +564,20 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
-        else CHK(launch_partition2(ctx, s));
+        else {
+            const int rc = launch_partition2(ctx, s);
+            if (rc == kSplitBatch) {   // rare: process this piece as two halves
+                const size_t half = (len / 2 + 15) & ~(size_t)15;
+                const size_t saved = ctx->batch_bytes;
+                ctx->batch_bytes = std::max<size_t>(half / (ctx->k == 13 ? 4 : 16), 16);
+                int r2 = count_device_range(ctx, addr + off, half, halo + off);
+                if (r2 == KPAL_OK && len > half) r2 = count_device_range(ctx, addr + off + half, len - half, halo + off + half);
+                ctx->batch_bytes = saved;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
     }
     return KPAL_OK;
 }

@@ -184,6 +184,24 @@ def test_host_feed_larger_than_staging(ctx):
     np.testing.assert_array_equal(ctx.count_bytes(12, seq), oracle.count_flat(seq, 12, threads=8))
 
 
+def test_two_level_batch_halving():
+    """Two-level path when a coarse bucket would overflow its 32-bit offsets: the batch is halved
+    recursively (forced here by lowering the limit); halo across the seams of the halves."""
+    from kpal_amd import _native
+    os.environ['KPAL_SPLIT_ABOVE'] = '20000'
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_SPLIT_ABOVE']
+    buf = oracle.synth_reads(47, 0, 6000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    homo = np.frombuffer(b'A' * 300000 + b'C' * 17 + b'N' + b'ACGT' * 5000, dtype=np.uint8)
+    for k in (13, 14):
+        for data in (buf, seq, homo):
+            np.testing.assert_array_equal(c2.count_bytes(k, data), oracle.count_flat(data, k, threads=4))
+    c2.close()
+
+
 def test_small_partition_batches():
     """Partition path with 1 MiB batches: halo across batch seams inside one device feed."""
     from kpal_amd import _native
