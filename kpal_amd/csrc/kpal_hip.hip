@@ -82,7 +82,7 @@ struct kpal_ctx {
     size_t batch_bytes = (size_t)1 << 30;
     uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
     // partition workspace
-    DevBuf keys, cntmat, offs, bucket_start;
+    DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
     DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
@@ -281,7 +281,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
@@ -442,23 +442,26 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
     CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
     CHK(ensure(ctx, ctx->offs, (size_t)kNumBuckets * G * sizeof(uint32_t)));
     CHK(ensure(ctx, ctx->bucket_start, (size_t)(2 * kNumBuckets + 2) * sizeof(uint64_t)));
+    CHK(ensure(ctx, ctx->slice_start, (size_t)(kNumBuckets + 1) * sizeof(uint32_t)));
     uint32_t *cntmat = (uint32_t *)ctx->cntmat.p;
     uint32_t *offs = (uint32_t *)ctx->offs.p;
     uint64_t *bstart = (uint64_t *)ctx->bucket_start.p;
     uint64_t *btotal = bstart + kNumBuckets + 1;
+    uint32_t *sstart = (uint32_t *)ctx->slice_start.p;
     uint16_t *keys = (uint16_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
-    const uint32_t slices = 1;   // one workgroup per bucket: exclusive table slice -> plain RMW merge (measured fastest)
     const uint64_t *no_base = nullptr;
     DISPATCH_K_8_12(ctx->k, {
         LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, cntmat);
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
         LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal,
-               (uint32_t)kNumBuckets, no_base, bstart);
+               (uint32_t)kNumBuckets, no_base, bstart, sstart);
         LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb,
                (const uint32_t *)offs, (const uint64_t *)bstart, keys);
-        LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kNumBuckets * slices), dim3(1024),
-               (const uint16_t *)keys, (const uint64_t *)bstart, slices, table);
+        // one workgroup per bucket (exclusive table slice -> plain read-modify-write merge, measured
+        // fastest); oversized buckets of skewed input are cut into slices by the bucket scan
+        LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kHistGridX), dim3(1024),
+               (const uint16_t *)keys, (const uint64_t *)bstart, (const uint32_t *)sstart, table);
     });
     return KPAL_OK;
 }
@@ -497,7 +500,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         LAUNCH(ctx, "coarse_count", (coarse_count_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb, cnt1);
         LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(NB1), dim3(256), (const uint32_t *)cnt1, G1, offs1, total1);
         LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)total1,
-               (uint32_t)NB1, no_base, start1);
+               (uint32_t)NB1, no_base, start1, (uint32_t *)nullptr);
     });
     // coarse bucket sizes: they size the level-2 launches and guard the 32-bit in-bucket offsets
     // (one small D2H + sync per batch)
@@ -525,16 +528,17 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     uint32_t *offs2 = (uint32_t *)ctx->offs.p;
     uint64_t *bstart2 = (uint64_t *)ctx->bucket_start.p;
     uint64_t *total2 = bstart2 + (size_t)NB1 * (kNumBuckets + 1);
-    const uint32_t slices = 1;   // 512 x NB1 >= 2048 workgroups; exclusive table slices -> plain RMW merge
+    CHK(ensure(ctx, ctx->slice_start, (size_t)NB1 * (kNumBuckets + 1) * sizeof(uint32_t)));
+    uint32_t *sstart2 = (uint32_t *)ctx->slice_start.p;
     LAUNCH(ctx, "key_count", key_count_kernel, dim3(G2, NB1), dim3(kScatterThreads), (const uint32_t *)res,
            (const uint64_t *)start1, (uint32_t)kpb, cntmat2);
     LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets, NB1), dim3(256), (const uint32_t *)cntmat2, G2, offs2, total2);
     LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(NB1), dim3(kNumBuckets), (const uint64_t *)total2,
-           (uint32_t)kNumBuckets, (const uint64_t *)start1, bstart2);
+           (uint32_t)kNumBuckets, (const uint64_t *)start1, bstart2, sstart2);
     LAUNCH(ctx, "key_scatter", key_scatter_kernel, dim3(G2, NB1), dim3(kLineThreads), (const uint32_t *)res,
            (const uint64_t *)start1, (uint32_t)kpb, (const uint32_t *)offs2, (const uint64_t *)bstart2, keys);
-    LAUNCH(ctx, "part_hist", (part_hist_kernel<kResKeyBits>), dim3(kNumBuckets * slices, NB1), dim3(1024),
-           (const uint16_t *)keys, (const uint64_t *)bstart2, slices, table);
+    LAUNCH(ctx, "part_hist", (part_hist_kernel<kResKeyBits>), dim3(kHistGridX, NB1), dim3(1024),
+           (const uint16_t *)keys, (const uint64_t *)bstart2, (const uint32_t *)sstart2, table);
     return KPAL_OK;
 }
 

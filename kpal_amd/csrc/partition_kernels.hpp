@@ -209,11 +209,20 @@ __global__ __launch_bounds__(256) void part_rowscan_kernel(const uint32_t *__res
 // A2b: exclusive scan of n <= 512 row totals -> start[0..n] (start[n] = grand total), offset by
 // base[blockIdx.x] when given.  With a 1-D grid of NB blocks this scans NB independent groups of
 // n rows (the 512 fine buckets of every coarse bucket).
+// It also plans the histogram launch (B): bucket b is cut into slices[b] = ceil(size / T) slices,
+// T = max(2 x mean bucket size, kMinSliceKeys) -- one slice per bucket for unskewed input, up to
+// n/2 extra slices spread over the oversized buckets of skewed input (a homopolymer puts every key
+// into ONE bucket).  slice_start[0..n] is the exclusive scan of slices; sum <= n + n/2.
+constexpr uint32_t kMinSliceKeys = 1u << 16;
+constexpr uint32_t kHistGridX = kNumBuckets + kNumBuckets / 2;   // upper bound of the slice count
+
 __global__ __launch_bounds__(kNumBuckets) void part_bucketscan_kernel(const uint64_t *__restrict__ row_total, uint32_t n,
                                                                       const uint64_t *__restrict__ base,
-                                                                      uint64_t *__restrict__ start)
+                                                                      uint64_t *__restrict__ start,
+                                                                      uint32_t *__restrict__ slice_start)
 {
     __shared__ uint64_t wsum[kNumBuckets / 64];
+    __shared__ uint32_t ssum[kNumBuckets / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t v = threadIdx.x < n ? row_total[(uint64_t)blockIdx.x * n + threadIdx.x] : 0ULL;
     uint64_t incl = v;
@@ -225,11 +234,33 @@ __global__ __launch_bounds__(kNumBuckets) void part_bucketscan_kernel(const uint
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint64_t off = base ? base[blockIdx.x] : 0ULL;
+    uint64_t total = 0;
 #pragma unroll
-    for (int w = 0; w < kNumBuckets / 64; ++w) off += (w < wave) ? wsum[w] : 0ULL;
+    for (int w = 0; w < kNumBuckets / 64; ++w) {
+        off += (w < wave) ? wsum[w] : 0ULL;
+        total += wsum[w];
+    }
     uint64_t *out = start + (uint64_t)blockIdx.x * (n + 1);
     if (threadIdx.x < n) out[threadIdx.x] = off + incl - v;
     if (threadIdx.x == n - 1) out[n] = off + incl;
+    if (!slice_start) return;
+    // slices per bucket and their exclusive scan
+    const uint64_t target = max((uint64_t)kMinSliceKeys, 2 * ((total + n - 1) / n));
+    const uint32_t slices = threadIdx.x < n ? (uint32_t)max((uint64_t)1, (v + target - 1) / target) : 0u;
+    uint32_t sincl = slices;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(sincl, d);
+        if (lane >= d) sincl += o;
+    }
+    if (lane == 63) ssum[wave] = sincl;
+    __syncthreads();
+    uint32_t soff = 0;
+#pragma unroll
+    for (int w = 0; w < kNumBuckets / 64; ++w) soff += (w < wave) ? ssum[w] : 0u;
+    uint32_t *sout = slice_start + (uint64_t)blockIdx.x * (n + 1);
+    if (threadIdx.x < n) sout[threadIdx.x] = soff + sincl - slices;
+    if (threadIdx.x == n - 1) sout[n] = soff + sincl;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -411,17 +442,29 @@ __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, u
 }
 
 // B: histogram one slice of one bucket in LDS, merge into the table.
-// grid = (512 buckets x slices, coarse buckets); block 1024 threads.  bucket_start has 513
-// entries per coarse bucket; the table slice of coarse bucket c starts at c << (9 + KB).
+// grid = (kHistGridX, coarse buckets); block 1024 threads.  bucket_start has 513 entries per coarse
+// bucket, slice_start (from the bucket scan) maps workgroup w to (bucket, slice); the table slice of
+// coarse bucket c starts at c << (9 + KB).
+// Skew: low-complexity sequence sends long runs of ONE key to a bucket, and 64 lanes adding to one
+// LDS address serialise 64-fold.  Per 16-byte vector the wave takes lane 0's first key as the "hot"
+// key, counts its occurrences with ballots in a scalar register and adds 0 for those lanes; one
+// lane adds the scalar count.  Unskewed input pays two extra VALU per key (B is memory-bound).
 template <int KB>
 __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restrict__ keys,
                                                          const uint64_t *__restrict__ bucket_start,
-                                                         uint32_t slices, unsigned long long *__restrict__ table)
+                                                         const uint32_t *__restrict__ slice_start,
+                                                         unsigned long long *__restrict__ table)
 {
     constexpr int BINS = 1 << KB;
     __shared__ __attribute__((aligned(16))) uint32_t hist[BINS];  // 128 KiB at KB = 15
-    const uint32_t b = blockIdx.x / slices;
-    const uint32_t sl = blockIdx.x % slices;
+    const uint32_t *ss = slice_start + (uint64_t)blockIdx.y * (kNumBuckets + 1);
+    if (blockIdx.x >= ss[kNumBuckets]) return;
+    uint32_t b = 0;   // largest b with ss[b] <= blockIdx.x (block-uniform binary search)
+#pragma unroll
+    for (int step = kNumBuckets / 2; step >= 1; step >>= 1)
+        if (ss[b + step] <= blockIdx.x) b += step;
+    const uint32_t sl = blockIdx.x - ss[b];
+    const uint32_t slices = ss[b + 1] - ss[b];
     for (int i = threadIdx.x; i < BINS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint64_t *bstart = bucket_start + (uint64_t)blockIdx.y * (kNumBuckets + 1);
@@ -435,15 +478,20 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
     const uint64_t a1 = a0 + ((e1 - a0) & ~7ULL);
     const uint4 *kv = reinterpret_cast<const uint4 *>(keys + a0);
     const uint64_t nvec = (a1 - a0) >> 3;
+    const int lane = threadIdx.x & 63;
     auto add8 = [&](const uint4 q) {
-        atomicAdd(&hist[q.x & 0xFFFFu], 1u);
-        atomicAdd(&hist[q.x >> 16], 1u);
-        atomicAdd(&hist[q.y & 0xFFFFu], 1u);
-        atomicAdd(&hist[q.y >> 16], 1u);
-        atomicAdd(&hist[q.z & 0xFFFFu], 1u);
-        atomicAdd(&hist[q.z >> 16], 1u);
-        atomicAdd(&hist[q.w & 0xFFFFu], 1u);
-        atomicAdd(&hist[q.w >> 16], 1u);
+        const uint32_t k[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
+                               q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+        const uint32_t hot = __builtin_amdgcn_readfirstlane(k[0]);
+        uint32_t same = 0;   // wave-uniform: stays in a scalar register
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool eq = k[j] == hot;
+            same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
+            atomicAdd(&hist[k[j]], eq ? 0u : 1u);
+        }
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+        if (lane == __ffsll((long long)active) - 1) atomicAdd(&hist[hot], same);
     };
     // four 16-byte loads in flight per lane (64 KiB per workgroup) to cover HBM latency
     uint64_t v = threadIdx.x;
