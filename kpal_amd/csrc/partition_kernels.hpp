@@ -446,9 +446,10 @@ __global__ __launch_bounds__(kScatterThreads) void part_scatter_kernel(Span s, u
 // bucket, slice_start (from the bucket scan) maps workgroup w to (bucket, slice); the table slice of
 // coarse bucket c starts at c << (9 + KB).
 // Skew: low-complexity sequence sends long runs of ONE key to a bucket, and 64 lanes adding to one
-// LDS address serialise 64-fold.  Per 16-byte vector the wave takes lane 0's first key as the "hot"
-// key, counts its occurrences with ballots in a scalar register and adds 0 for those lanes; one
-// lane adds the scalar count.  Unskewed input pays two extra VALU per key (B is memory-bound).
+// LDS address serialise (~2 clk per lane).  Per 16-byte vector the wave picks a "hot" key (lane
+// 0's first key, or the first dissenting lane's if that one is more frequent), counts its
+// occurrences with ballots in a scalar register and diverts those lanes to private dummy words; one lane adds the
+// scalar count.  Unskewed input pays two extra VALU per key (B is memory-bound).
 template <int KB>
 __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restrict__ keys,
                                                          const uint64_t *__restrict__ bucket_start,
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
                                                          unsigned long long *__restrict__ table)
 {
     constexpr int BINS = 1 << KB;
-    __shared__ __attribute__((aligned(16))) uint32_t hist[BINS];  // 128 KiB at KB = 15
+    __shared__ __attribute__((aligned(16))) uint32_t hist[BINS + 64];  // 128 KiB at KB = 15, + one dummy word per lane
     const uint32_t *ss = slice_start + (uint64_t)blockIdx.y * (kNumBuckets + 1);
     if (blockIdx.x >= ss[kNumBuckets]) return;
     uint32_t b = 0;   // largest b with ss[b] <= blockIdx.x (block-uniform binary search)
@@ -482,15 +483,22 @@ __global__ __launch_bounds__(1024) void part_hist_kernel(const uint16_t *__restr
     auto add8 = [&](const uint4 q) {
         const uint32_t k[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
                                q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
-        const uint32_t hot = __builtin_amdgcn_readfirstlane(k[0]);
+        // hot key: the first lane's first key, or -- if fewer than half of the lanes agree with it --
+        // the first dissenting lane's, whichever is more frequent (all wave-uniform, scalar)
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+        uint32_t hot = __builtin_amdgcn_readfirstlane(k[0]);
+        const unsigned long long agree = __builtin_amdgcn_ballot_w64(k[0] == hot);
+        if (__popcll(agree) < 32 && (active & ~agree)) {
+            const uint32_t other = __builtin_amdgcn_readlane(k[0], __ffsll((long long)(active & ~agree)) - 1);
+            if (__popcll(__builtin_amdgcn_ballot_w64(k[0] == other)) > __popcll(agree)) hot = other;
+        }
         uint32_t same = 0;   // wave-uniform: stays in a scalar register
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool eq = k[j] == hot;
             same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
-            atomicAdd(&hist[k[j]], eq ? 0u : 1u);
+            atomicAdd(&hist[eq ? (uint32_t)(BINS + lane) : k[j]], 1u);   // hot lanes: a private dummy word (no conflict)
         }
-        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
         if (lane == __ffsll((long long)active) - 1) atomicAdd(&hist[hot], same);
     };
     // four 16-byte loads in flight per lane (64 KiB per workgroup) to cover HBM latency
