@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Summarise two rocprofv3 counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs of the
+same command) into per-kernel HBM bytes per dispatch.
+
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <input_bytes_per_launch> "<note>" > out.json
+
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md, HBM section), so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def collect(root, counter):
+    per = collections.defaultdict(lambda: [0.0, set()])
+    for d, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith('counter_collection.csv'):
+                continue
+            with open(os.path.join(d, f)) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get('Counter_Name') != counter:
+                        continue
+                    name = row['Kernel_Name'].split('(')[0].replace('void ', '')
+                    per[name][0] += float(row['Counter_Value'])
+                    per[name][1].add(row['Dispatch_Id'])
+    return {k: (v[0], len(v[1])) for k, v in per.items()}
+
+
+def main():
+    fetch_dir, write_dir, in_bytes, note = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+    fetch = collect(fetch_dir, 'FETCH_SIZE')
+    write = collect(write_dir, 'WRITE_SIZE')
+    out = {'note': note, 'input_bytes_per_launch_avg': in_bytes, 'kernels': {}}
+    for name in fetch:
+        f, n = fetch[name]
+        w, nw = write.get(name, (0.0, n))
+        rec = {'FETCH_SIZE': f / n, 'dispatches': n, 'WRITE_SIZE': w / max(nw, 1)}
+        rec['hbm_bytes_per_dispatch_corrected'] = (2 * rec['FETCH_SIZE'] + rec['WRITE_SIZE']) * 1024
+        out['kernels'][name] = rec
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main()
