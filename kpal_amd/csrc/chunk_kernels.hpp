@@ -1,0 +1,460 @@
+// chunk_kernels.hpp -- one-pass radix partition into CHUNKED bucket lists (k = 8..12, gfx950).
+//
+// The exact-offset pipeline of partition_kernels.hpp reads the input twice: a counting pass (A1)
+// exists only to give every (bucket, workgroup) run its final position.  Here the scatter kernel
+// needs no positions: a bucket's keys go into 8 KiB chunks.  Workgroup g owns the chunk ids
+// [g*R, (g+1)*R), R = steps per workgroup / 4 + 1024 + margin -- enough in EVERY case: at most
+// steps/4 full chunks (a step is 1024 k-mers, a chunk 4096 keys), one partly filled and one
+// pre-assigned next chunk per bucket -- so allocation is an LDS counter, never a global atomic.  A retired chunk is recorded
+// as one word (chunk id | fill-1 << 22) in the table row of its (bucket, workgroup); rows hold four
+// entries, further ones (skewed input only) go to an overflow list that is grouped by bucket.
+// The histogram kernel walks its bucket's table rows and overflow entries.  Still exact, still
+// deterministic in its result (integer adds commute), no capacity estimates, and skew needs no
+// special layout: a bucket that receives everything simply owns more chunks.
+//
+//   C3  chunk_scatter_kernel<K>   ASCII -> 16-bit keys in chunks (LDS staging as in A3)
+//   C4a chunk_plan_kernel         scan of the overflow counts per bucket, slice plan for C5
+//   C4b chunk_list_kernel         overflow entries grouped by bucket (empty for unskewed input)
+//   C5  chunk_hist_kernel<KB>     LDS histogram over a bucket's chunks, merge into the table
+#pragma once
+#include "partition_kernels.hpp"
+
+namespace kpal {
+
+constexpr uint32_t kChunkShift = 12;
+constexpr uint32_t kChunkKeys = 1u << kChunkShift;   // 4096 keys = 8 KiB
+constexpr uint32_t kChunkRow = 4;                    // table entries per (bucket, workgroup)
+constexpr uint32_t kChunkEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kChunkDeferCap = 1024;            // abandoned tiles a workgroup can remember (16384 steps per wave)
+constexpr uint32_t kChunkIdBits = 20;                // chunk ids < 2^20: key indices fit 32 bits; entry = id | (fill-1) << 20
+
+struct ChunkPool {
+    uint16_t *keys;        // G * per_block chunks of kChunkKeys keys
+    uint32_t per_block;    // R: chunk ids of workgroup g are [g*R, (g+1)*R)
+    uint32_t *table;       // [512][G][kChunkRow] entries (chunk id | (fill-1) << 20), kChunkEmpty = none
+    uint32_t *nlist;       // [512] retired chunks per bucket (slice plan)
+    uint32_t *ovf_n;       // [512] overflow entries per bucket
+    uint32_t *ovf_count;   // total overflow entries
+    uint2 *ovf;            // overflow entries (bucket, entry), capacity G * per_block
+    uint32_t *error;       // set if a workgroup ran out of chunks (cannot happen: R is a worst-case bound)
+};
+// The scatter kernel gets the pool by pointer (device memory): its rarely used fields must not sit
+// in scalar registers for the whole kernel.
+
+__device__ __forceinline__ uint32_t chunk_entry(uint32_t cid, uint32_t fill) { return cid | ((fill - 1u) << kChunkIdBits); }
+
+// Workgroup-local allocation of n contiguous chunks.
+__device__ __forceinline__ uint32_t chunk_alloc(const ChunkPool *p, uint32_t per_block, uint32_t *alloc_next, uint32_t n)
+{
+    uint32_t id = atomicAdd(alloc_next, n);
+    const uint32_t end = (blockIdx.x + 1u) * per_block;
+    if (id + n > end) {   // keep every write inside the workgroup's range, report
+        *p->error = 1u;
+        id = end - n;
+    }
+    return id;
+}
+
+// Record a finished chunk of bucket b; `nret` counts this (bucket, workgroup)'s chunks so far.
+__device__ __forceinline__ void chunk_retire(const ChunkPool *p, uint32_t cid, uint32_t b, uint32_t fill, uint32_t &nret)
+{
+    const uint32_t e = chunk_entry(cid, fill);
+    if (nret < kChunkRow) {
+        p->table[((uint64_t)b * gridDim.x + blockIdx.x) * kChunkRow + nret] = e;
+    } else {   // skewed input only
+        const uint32_t at = atomicAdd(p->ovf_count, 1u);
+        p->ovf[at] = make_uint2(b, e);
+        atomicAdd(&p->ovf_n[b], 1u);
+    }
+    ++nret;
+    atomicAdd(&p->nlist[b], 1u);
+}
+
+// Placement of 16 values into the per-tile rows (layout of place16).  A counted value whose row is
+// full (slot >= 64: a few per tile even for uniform input) is stored directly at its final place:
+// slot s of bucket b lies at gcur[b] + s while that is inside the bucket's current chunk, else in
+// its pre-assigned next chunk.  Slots >= kChunkKeys cannot be placed (the bucket would need a third
+// chunk in this tile): the caller abandons such a tile.  Returns the largest counted slot.
+template <int KB>
+__device__ __forceinline__ uint32_t place16_chunked(unsigned char *rows, uint32_t *pos, const uint32_t *gcur,
+                                                    const uint32_t *nextc, uint16_t *__restrict__ keys,
+                                                    const uint32_t (&v)[16], uint32_t valid
+                                                    )
+{
+    constexpr uint32_t kKeyMask = (1u << KB) - 1u;
+    uint32_t slot[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;  // 4 * bucket
+        slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (valid >> (15 - j)) & 1u);
+    }
+    uint32_t smax = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;
+        const uint32_t counted = (valid >> (15 - j)) & 1u;
+        const uint32_t x = slot[j] | ((counted ^ 1u) << 16);                 // >= 64: not counted, or row full
+        const uint32_t at = ((2u * slot[j] + b4) & 126u) | (b4 << 5);        // byte offset of the rotated slot
+        *(uint16_t *)(rows + (x < (uint32_t)kSlotCap ? at : kRowsBytes)) = (uint16_t)(v[j] & kKeyMask);
+        smax = max(smax, counted ? slot[j] : 0u);
+    }
+    if (smax >= (uint32_t)kSlotCap) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (((valid >> (15 - j)) & 1u) && slot[j] >= (uint32_t)kSlotCap && slot[j] < kChunkKeys) {
+                const uint32_t b = v[j] >> KB;
+                const uint32_t g = gcur[b];
+                const uint32_t room = kChunkKeys - (g & (kChunkKeys - 1));
+                const uint32_t at = slot[j] < room ? g + slot[j] : (nextc[b] << kChunkShift) + (slot[j] - room);
+                keys[at] = (uint16_t)(v[j] & kKeyMask);
+            }
+        }
+    }
+    return smax;
+}
+
+// Copy-out of the staged rows of one tile.  Thread t owns bucket t
+// (wave w: buckets [64w, 64w+64)).  n keys of the bucket go to key index g, g+1, ... of its current
+// chunk; those beyond the chunk's end (`room`) go to key index second, second+1, ...  Only the
+// staged part [0, min(n, 64)) is written here, as one range-checked buffer_store_short per bucket
+// plus a second one for the rare bucket whose staged run crosses the chunk end.
+__device__ __forceinline__ void chunk_store_rows(const unsigned char *rows, uint16_t *__restrict__ keys, uint32_t n,
+                                                 uint32_t g, uint32_t second)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = wave * kBucketsPerWave;
+    const uint32_t r0 = 2u * lane + 4u * first;
+    const unsigned char *wrows = rows + (uint32_t)first * 128u;
+    unsigned long long cross;
+    {
+        const uint32_t staged = min(n, (uint32_t)kSlotCap);
+        const uint32_t room = kChunkKeys - (g & (kChunkKeys - 1));
+        const uint64_t addr = (uint64_t)keys + 2ULL * g;
+        const uint32_t my_lo = (uint32_t)addr, my_hi = (uint32_t)(addr >> 32);
+        const uint32_t my_bytes = 2u * min(staged, room);
+        cross = __builtin_amdgcn_ballot_w64(staged > room);
+#pragma unroll
+        for (int i0 = 0; i0 < kBucketsPerWave; i0 += 8) {
+            uint16_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)   // unconditional LDS reads first (8 in flight)
+                v[u] = *(const uint16_t *)(wrows + (i0 + u) * 128 + ((r0 + 4u * (i0 + u)) & 126u));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t lo = __builtin_amdgcn_readlane(my_lo, i0 + u);
+                const uint32_t hi = __builtin_amdgcn_readlane(my_hi, i0 + u);
+                const uint32_t nb = __builtin_amdgcn_readlane(my_bytes, i0 + u);
+                __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0, (int)nb, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b16((short)v[u], rsrc, 2 * lane, 0, 0);
+            }
+        }
+    }
+    // staged runs that cross the end of their chunk: slots [room, staged) continue at `second`
+    while (cross) {   // wave-uniform; everything below is scalar
+        const int i = __ffsll((long long)cross) - 1;
+        cross &= cross - 1;
+        const uint32_t gi = __builtin_amdgcn_readlane(g, i);
+        const uint32_t rm = kChunkKeys - (gi & (kChunkKeys - 1));
+        const uint32_t st = min(__builtin_amdgcn_readlane(n, i), (uint32_t)kSlotCap);
+        // slot s lands at second + (s - room)
+        const uint32_t sec = (uint32_t)__builtin_amdgcn_readlane(second, i);   // (the builtin returns int: no sign extension)
+        const uint64_t addr2 = (uint64_t)keys + 2ULL * sec - 2ULL * rm;
+        const uint16_t v = *(const uint16_t *)(wrows + i * 128 + ((r0 + 4u * i) & 126u));
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)addr2, (short)0, (int)(2u * st), 0x00020000);
+        // lanes below `room` were written by the first store: send them out of range
+        __builtin_amdgcn_raw_buffer_store_b16((short)v, rsrc, (uint32_t)lane >= rm ? 2 * lane : 0x7FFFFFF0, 0, 0);
+    }
+}
+
+// Abandoned tile (a bucket would have needed a third chunk: more than 4096 of the tile's 24576
+// k-mers in one bucket, i.e. homopolymer-like input under several waves at once): its k-mers are
+// counted straight into the table.  Per step the wave counts the occurrences of its first k-mer with
+// ballots (one global atomic), everything else takes one global atomic per k-mer.
+template <int K>
+__device__ __forceinline__ void chunk_count_tile_direct(const Span &s, uint64_t first_step,
+                                                        unsigned long long *__restrict__ table)
+{
+    const int lane = threadIdx.x & 63;
+    Chunk carry = load_chunk(s, (int64_t)(first_step * 64) - 1);
+    for (int st = 0; st < kScatterSteps; ++st) {
+        uint64_t window;
+        uint32_t mask;
+        part_step<K>(s, first_step + st, carry, window, mask);
+        // hot k-mer: the first counted one of the lowest lane that has any
+        const unsigned long long have = __builtin_amdgcn_ballot_w64(mask != 0);
+        if (!have) continue;   // wave-uniform
+        const int src = __ffsll((long long)have) - 1;
+        const uint32_t m0 = __builtin_amdgcn_readlane(mask, src);
+        const uint32_t w0_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(window >> 32), src);   // (returns int)
+        const uint32_t w0_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)window, src);
+        const uint64_t w0 = ((uint64_t)w0_hi << 32) | w0_lo;
+        const uint32_t hot = kmer_at<K>(w0, 15 - (31 - __clz(m0)));   // highest set bit of m0 = smallest j
+        uint32_t same = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t v = kmer_at<K>(window, j);
+            const bool counted = (mask >> (15 - j)) & 1u;
+            const bool eq = counted && v == hot;
+            same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
+            if (counted && !eq) atomicAdd(&table[v], 1ULL);
+        }
+        if (lane == src) atomicAdd(&table[hot], (unsigned long long)same);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span s, uint64_t steps_per_block,
+                                                                           const ChunkPool *__restrict__ p,
+                                                                           uint16_t *__restrict__ keys, uint32_t per_block,
+                                                                           unsigned long long *__restrict__ table)
+{
+    constexpr int KB = PartCfg<K>::kKeyBits;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kRowsBytes + 16];
+    __shared__ uint32_t pos[kNumBuckets];
+    __shared__ uint32_t gcur[kNumBuckets];    // key index (chunk id << 12 | offset) of every bucket's cursor
+    __shared__ uint32_t nextc[kNumBuckets];   // every bucket's pre-assigned next chunk
+    __shared__ uint32_t tile_over, alloc_next, defer_n;
+    __shared__ uint16_t defer_t[kChunkDeferCap];   // abandoned tiles, counted directly after the main loop
+    static_assert(kScatterThreads == kNumBuckets && kSlotCap == 64, "one lane per slot, one thread per bucket");
+    const int wave = threadIdx.x >> 6;
+    const uint32_t mine = threadIdx.x;        // the bucket this thread owns in the copy-out phase
+    const uint32_t first_chunk = blockIdx.x * per_block;
+    if (threadIdx.x == 0) {
+        alloc_next = first_chunk + 2 * kNumBuckets;   // a current and a next chunk per bucket are pre-assigned
+        tile_over = 0;
+        defer_n = 0;
+    }
+    gcur[mine] = (first_chunk + mine) << kChunkShift;
+    nextc[mine] = first_chunk + kNumBuckets + mine;
+    uint32_t nret = 0;                        // chunks of (mine, this workgroup) retired so far
+    pos[mine] = 0;
+    __syncthreads();
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
+    const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
+    const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
+    Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
+    for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
+        if (block_step0 + t >= total_steps) break;  // block-uniform: wave 0 owns the lowest addresses
+        uint64_t window[kScatterSteps];
+        uint32_t mask[kScatterSteps];
+#pragma unroll
+        for (int st = 0; st < kScatterSteps; ++st) part_step<K>(s, step0 + t + st, carry, window[st], mask[st]);
+        uint32_t smax = 0;
+#pragma unroll
+        for (int st = 0; st < kScatterSteps; ++st) {
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window[st], j);
+            smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, mask[st]
+                                                    ));
+        }
+        if (smax >= kChunkKeys) tile_over = 1;   // benign race: every writer stores 1
+        __syncthreads();
+        if (tile_over) {   // block-uniform, pathological input only: forget the tile, count it after the loop
+            pos[mine] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                tile_over = 0;
+                if (defer_n < kChunkDeferCap) defer_t[defer_n] = (uint16_t)(t / kScatterSteps);
+                else *p->error = 1u;
+                ++defer_n;
+            }
+            __syncthreads();
+            continue;
+        }
+        const uint32_t n = pos[mine], g = gcur[mine], nx = nextc[mine];
+        chunk_store_rows(rows, keys, n, g, nx << kChunkShift);
+        const uint32_t room = kChunkKeys - (g & (kChunkKeys - 1));
+        uint32_t g2 = g + n;
+        if (n >= room) {   // the current chunk is full: retire it, continue in the next, take another
+            chunk_retire(p, g >> kChunkShift, mine, kChunkKeys, nret);
+            g2 = (nx << kChunkShift) + (n - room);
+            nextc[mine] = chunk_alloc(p, per_block, &alloc_next, 1);
+        }
+        gcur[mine] = g2;
+        pos[mine] = 0;
+        __syncthreads();
+    }
+    // the partly filled current chunks, then the unused row entries
+    __syncthreads();
+    const uint32_t g = gcur[mine];
+    if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
+    for (uint32_t e = nret; e < kChunkRow; ++e) p->table[((uint64_t)mine * gridDim.x + blockIdx.x) * kChunkRow + e] = kChunkEmpty;
+    const uint32_t nd = min(defer_n, kChunkDeferCap);
+    for (uint32_t i = 0; i < nd; ++i)
+        chunk_count_tile_direct<K>(s, step0 + (uint64_t)defer_t[i] * kScatterSteps, table);
+}
+
+// C4a: exclusive scan of the overflow counts -> ostart[0..512], cursors reset; slice plan of the
+// histogram launch as in part_bucketscan_kernel, in units of chunks.
+__global__ __launch_bounds__(kNumBuckets) void chunk_plan_kernel(const uint32_t *__restrict__ nlist,
+                                                                 const uint32_t *__restrict__ ovf_n,
+                                                                 uint32_t *__restrict__ ostart, uint32_t *__restrict__ ocur,
+                                                                 uint32_t *__restrict__ slice_start)
+{
+    __shared__ uint32_t wsum[kNumBuckets / 64], ssum[kNumBuckets / 64], tsum[kNumBuckets / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v = ovf_n[threadIdx.x];
+    const uint32_t c = nlist[threadIdx.x];
+    uint32_t incl = v, cincl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d), oc = __shfl_up(cincl, d);
+        if (lane >= d) {
+            incl += o;
+            cincl += oc;
+        }
+    }
+    if (lane == 63) {
+        wsum[wave] = incl;
+        tsum[wave] = cincl;
+    }
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kNumBuckets / 64; ++w) {
+        off += (w < wave) ? wsum[w] : 0u;
+        total += tsum[w];
+    }
+    ostart[threadIdx.x] = off + incl - v;
+    if (threadIdx.x == kNumBuckets - 1) ostart[kNumBuckets] = off + incl;
+    ocur[threadIdx.x] = 0;
+    const uint32_t target = max(64u, 2u * ((total + kNumBuckets - 1) / kNumBuckets));
+    const uint32_t slices = max(1u, (c + target - 1) / target);
+    uint32_t sincl = slices;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(sincl, d);
+        if (lane >= d) sincl += o;
+    }
+    if (lane == 63) ssum[wave] = sincl;
+    __syncthreads();
+    uint32_t soff = 0;
+#pragma unroll
+    for (int w = 0; w < kNumBuckets / 64; ++w) soff += (w < wave) ? ssum[w] : 0u;
+    slice_start[threadIdx.x] = soff + sincl - slices;
+    if (threadIdx.x == kNumBuckets - 1) slice_start[kNumBuckets] = soff + sincl;
+}
+
+// C4b: overflow entries grouped by bucket (order inside a bucket is irrelevant).
+__global__ __launch_bounds__(256) void chunk_list_kernel(ChunkPool p, const uint32_t *__restrict__ ostart,
+                                                         uint32_t *__restrict__ ocur, uint32_t *__restrict__ osorted)
+{
+    const uint32_t n = *p.ovf_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = p.ovf[i];
+        osorted[ostart[e.x] + atomicAdd(&ocur[e.x], 1u)] = e.y;
+    }
+}
+
+// C5: LDS histogram of one slice of one bucket's chunks, merged into the table (see
+// part_hist_kernel for the slice plan and the hot-key counting).  The bucket's entries are its
+// table row (G * 4 words, mostly two or three chunks per workgroup) followed by its overflow
+// entries; a slice takes an equal share of both.  A wave reads 64 entries at a time and works
+// through the non-empty ones chunk by chunk, four 16-byte loads per lane in flight.
+template <int KB>
+__global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t G, const uint32_t *__restrict__ ostart,
+                                                          const uint32_t *__restrict__ osorted,
+                                                          const uint32_t *__restrict__ slice_start,
+                                                          unsigned long long *__restrict__ table)
+{
+    constexpr int BINS = 1 << KB;
+    __shared__ __attribute__((aligned(16))) uint32_t hist[BINS + 64];
+    if (blockIdx.x >= slice_start[kNumBuckets]) return;
+    uint32_t b = 0;
+#pragma unroll
+    for (int step = kNumBuckets / 2; step >= 1; step >>= 1)
+        if (slice_start[b + step] <= blockIdx.x) b += step;
+    const uint32_t sl = blockIdx.x - slice_start[b];
+    const uint32_t slices = slice_start[b + 1] - slice_start[b];
+    for (int i = threadIdx.x; i < BINS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto add8 = [&](const uint4 q, uint32_t live) {   // live: how many of the 8 keys exist (tail of a chunk)
+        const uint32_t k[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
+                               q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+        uint32_t hot = __builtin_amdgcn_readfirstlane(k[0]);
+        const unsigned long long agree = __builtin_amdgcn_ballot_w64(k[0] == hot);
+        if (__popcll(agree) < 32 && (active & ~agree)) {
+            const uint32_t other = __builtin_amdgcn_readlane(k[0], __ffsll((long long)(active & ~agree)) - 1);
+            if (__popcll(__builtin_amdgcn_ballot_w64(k[0] == other)) > __popcll(agree)) hot = other;
+        }
+        uint32_t same = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool exists = (uint32_t)j < live;
+            const bool eq = exists && k[j] == hot;
+            same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
+            atomicAdd(&hist[(eq || !exists) ? (uint32_t)(BINS + lane) : (k[j] & (uint32_t)(BINS - 1))], 1u);
+        }
+        if (lane == __ffsll((long long)active) - 1) atomicAdd(&hist[hot & (uint32_t)(BINS - 1)], same);
+    };
+    // A unit is half a chunk: vectors [256h, 256h + 256) (a vector = 8 keys), four per lane.  The
+    // loads of the next unit are issued before the current one is histogrammed.
+    uint4 qa[4];
+    uint32_t la[4];
+    bool have = false;
+    auto consume = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (la[u]) add8(qa[u], la[u]);
+    };
+    auto feed = [&](uint32_t e, uint32_t half) {   // wave-uniform arguments
+        const uint32_t fill = (e >> kChunkIdBits) + 1u;
+        const uint32_t nvec = (fill + 7u) >> 3;
+        const uint4 *kv = reinterpret_cast<const uint4 *>(p.keys + ((uint64_t)(e & ((1u << kChunkIdBits) - 1u)) << kChunkShift));
+        uint4 qb[4];
+        uint32_t lb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t v = 256u * half + 64u * u + lane;
+            lb[u] = v < nvec ? min(8u, fill - 8u * v) : 0u;
+            qb[u] = make_uint4(0, 0, 0, 0);
+            if (lb[u]) qb[u] = kv[v];
+        }
+        if (have) consume();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qa[u] = qb[u];
+            la[u] = lb[u];
+        }
+        have = true;
+    };
+    auto walk = [&](const uint32_t *list, uint32_t n_entries) {
+        const uint32_t per = (n_entries + slices - 1) / slices;
+        const uint32_t e0 = min(sl * per, n_entries), e1 = min((sl + 1) * per, n_entries);
+        for (uint32_t base = e0 + wave * 64; base < e1; base += 16 * 64) {
+            const uint32_t idx = base + lane;
+            const uint32_t e = idx < e1 ? list[idx] : kChunkEmpty;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(e != kChunkEmpty);
+            while (m) {   // wave-uniform
+                const int i = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t ei = __builtin_amdgcn_readlane(e, i);
+                feed(ei, 0);
+                if ((ei >> kChunkIdBits) + 1u > 256u * 8u) feed(ei, 1);
+            }
+        }
+    };
+    walk(p.table + (uint64_t)b * G * kChunkRow, G * kChunkRow);
+    walk(osorted + ostart[b], ostart[b + 1] - ostart[b]);
+    if (have) consume();
+    __syncthreads();
+    unsigned long long *dst = table + ((uint64_t)b << KB);
+    if (slices == 1) {
+        for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
+            const uint32_t c = hist[i];
+            if (c) dst[i] += (unsigned long long)c;
+        }
+    } else {
+        for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
+            const uint32_t c = hist[i];
+            if (c) atomicAdd(&dst[i], (unsigned long long)c);
+        }
+    }
+}
+
+}  // namespace kpal

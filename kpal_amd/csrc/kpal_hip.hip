@@ -16,6 +16,7 @@
 
 #include "count_kernels.hpp"
 #include "partition_kernels.hpp"
+#include "chunk_kernels.hpp"
 #include "fasta_kernels.hpp"
 #include "vec_kernels.hpp"
 #include "option_kernels.hpp"
@@ -83,6 +84,10 @@ struct kpal_ctx {
     uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
+    DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
+    bool chunk_error_armed = false;
+    ChunkPool chunk_pool_sent = {};          // what the device copy of the pool descriptor holds
+    ChunkPool *chunk_pool_dev = nullptr;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
     DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
@@ -281,7 +286,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
@@ -360,6 +365,8 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     ctx->bins = 1ULL << (2 * k);
     CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+    if (ctx->chunk_meta.p) HIPCHK(hipMemsetAsync((uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, 0, sizeof(uint32_t), ctx->stream));
+    ctx->chunk_error_armed = false;
     ctx->counting = true;
     return KPAL_OK;
 }
@@ -367,7 +374,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_CHUNKED)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -378,9 +385,9 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     int s = ctx->strategy;
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
-        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION : KPAL_STRATEGY_PARTITION2);
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_CHUNKED : KPAL_STRATEGY_PARTITION2);
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
-    if (s == KPAL_STRATEGY_PARTITION && (k < 8 || k > 12))
+    if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED) && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
     if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 16))
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
@@ -462,6 +469,75 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
         // fastest); oversized buckets of skewed input are cut into slices by the bucket scan
         LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kHistGridX), dim3(1024),
                (const uint16_t *)keys, (const uint64_t *)bstart, (const uint32_t *)sstart, table);
+    });
+    return KPAL_OK;
+}
+
+// Chunked one-level partition, k = 8..12 (chunk_kernels.hpp): scatter into per-workgroup 2 KiB
+// chunks, record them in (bucket, workgroup) table rows, histogram every bucket's chunks.
+static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    // one round of two resident workgroups per CU: every workgroup leaves a partly filled and an
+    // unused chunk per bucket behind, so fewer, longer workgroups than the exact-offset path
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 2;
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + kStepsPerBlockQuantum - 1) / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+    const uint32_t G = (uint32_t)((total_steps + spb - 1) / spb);
+    // chunks per workgroup, worst case: spb*1024/4096 full ones + a partly filled and a
+    // pre-assigned next one per bucket (+ slack)
+    const uint64_t R = spb * 1024 / kChunkKeys + 2 * kNumBuckets + 64;
+    const uint64_t cap = (uint64_t)G * R;
+    if (cap >= (1ull << kChunkIdBits)) return set_err(KPAL_E_INVALID, "chunked partition: batch too large");
+    CHK(ensure(ctx, ctx->keys, cap * kChunkKeys * sizeof(uint16_t)));
+    CHK(ensure(ctx, ctx->chunk_table, (size_t)kNumBuckets * G * kChunkRow * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->chunk_ovf, cap * sizeof(uint2)));
+    CHK(ensure(ctx, ctx->chunk_sorted, cap * sizeof(uint32_t)));
+    // meta words: nlist[512] ovf_n[512] ovf_count error | ostart[513] ocur[512] slice_start[513] | ChunkPool
+    const size_t pool_words = (sizeof(ChunkPool) + 3) / 4 + 4;
+    const size_t meta_words = 2 * kNumBuckets + 2 + (kNumBuckets + 1) + kNumBuckets + (kNumBuckets + 1) + 3 + pool_words;
+    const bool fresh = ctx->chunk_meta.p == nullptr;
+    CHK(ensure(ctx, ctx->chunk_meta, meta_words * sizeof(uint32_t)));
+    uint32_t *meta = (uint32_t *)ctx->chunk_meta.p;
+    if (fresh) HIPCHK(hipMemsetAsync(meta, 0, meta_words * sizeof(uint32_t), ctx->stream));
+    ChunkPool p;
+    memset(&p, 0, sizeof(p));   // padding too: the descriptor is compared bytewise below
+    p.keys = (uint16_t *)ctx->keys.p;
+    p.per_block = (uint32_t)R;
+    p.table = (uint32_t *)ctx->chunk_table.p;
+    p.nlist = meta;
+    p.ovf_n = meta + kNumBuckets;
+    p.ovf_count = meta + 2 * kNumBuckets;
+    p.error = meta + 2 * kNumBuckets + 1;
+    p.ovf = (uint2 *)ctx->chunk_ovf.p;
+    uint32_t *ostart = meta + 2 * kNumBuckets + 2;
+    uint32_t *ocur = ostart + kNumBuckets + 1;
+    uint32_t *sstart = ocur + kNumBuckets;
+    ChunkPool *dpool = (ChunkPool *)(((uintptr_t)(sstart + kNumBuckets + 1) + 15) & ~(uintptr_t)15);
+    // the device copy changes only when a buffer was reallocated (per_block travels by value): a
+    // synchronous copy then -- an asynchronous one would read this stack frame after it is gone
+    ChunkPool cmp = p;
+    cmp.per_block = 0;
+    if (memcmp(&cmp, &ctx->chunk_pool_sent, sizeof(ChunkPool)) != 0 || dpool != ctx->chunk_pool_dev) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(dpool, &cmp, sizeof(ChunkPool), hipMemcpyHostToDevice));
+        ctx->chunk_pool_sent = cmp;
+        ctx->chunk_pool_dev = dpool;
+    }
+    ctx->chunk_error_armed = true;
+    // per batch: counts restart at 0; the error word is sticky until count_finish
+    HIPCHK(hipMemsetAsync(meta, 0, (2 * kNumBuckets + 1) * sizeof(uint32_t), ctx->stream));
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_8_12(ctx->k, {
+        LAUNCH(ctx, "chunk_scatter", (chunk_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, (const ChunkPool *)dpool,
+               p.keys, p.per_block, table);
+        LAUNCH(ctx, "chunk_plan", chunk_plan_kernel, dim3(1), dim3(kNumBuckets), (const uint32_t *)p.nlist,
+               (const uint32_t *)p.ovf_n, ostart, ocur, sstart);
+        LAUNCH(ctx, "chunk_list", chunk_list_kernel, dim3(256), dim3(256), p, (const uint32_t *)ostart, ocur,
+               (uint32_t *)ctx->chunk_sorted.p);
+        LAUNCH(ctx, "chunk_hist", (chunk_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kHistGridX), dim3(1024), p, G,
+               (const uint32_t *)ostart, (const uint32_t *)ctx->chunk_sorted.p, (const uint32_t *)sstart, table);
     });
     return KPAL_OK;
 }
@@ -550,7 +626,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     CHK(resolve_strategy(ctx, &strat));
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
-    if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
+    if (strat == KPAL_STRATEGY_PARTITION || strat == KPAL_STRATEGY_PARTITION_CHUNKED) piece = ctx->batch_bytes;
     else if (strat == KPAL_STRATEGY_PARTITION2) {
         // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
         // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
@@ -568,6 +644,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
         else {
             const int rc = launch_partition2(ctx, s);
             if (rc == kSplitBatch) {   // rare: process this piece as two halves
@@ -738,9 +815,16 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
+    uint32_t pool_error = 0;
+    if (ctx->chunk_error_armed)
+        HIPCHK(hipMemcpyAsync(&pool_error, (uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, ctx->table.p, ctx->bins * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (pool_error) {
+        HIPCHK(hipMemsetAsync((uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, 0, sizeof(uint32_t), ctx->stream));
+        return set_err(KPAL_E_HIP, "chunked partition: the chunk pool ran out (internal sizing error %u); counts are invalid", pool_error);
+    }
     return KPAL_OK;
 }
 

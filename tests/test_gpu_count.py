@@ -23,6 +23,7 @@ def strategies(k):
         s.append('lds_direct')
     if 8 <= k <= 12:
         s.append('partition')
+        s.append('partition_chunked')
     if 13 <= k <= 16:
         s.append('partition2')
     return s
@@ -215,6 +216,8 @@ def test_small_partition_batches():
     for k in (8, 12):
         np.testing.assert_array_equal(c2.count_bytes(k, buf, 'partition'), oracle.count_flat(buf, k, threads=4))
         np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition'), oracle.count_flat(seq, k, threads=4))
+        np.testing.assert_array_equal(c2.count_bytes(k, buf, 'partition_chunked'), oracle.count_flat(buf, k, threads=4))
+        np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition_chunked'), oracle.count_flat(seq, k, threads=4))
     c2.close()
 
 
@@ -254,6 +257,11 @@ def test_full_size_properties_k12(ctx, k, n_reads):
             ctx.count_feed_device(d + f * 151, n * 151)
             parts.append(ctx.count_finish())
         np.testing.assert_array_equal(parts[0] + parts[1], full)
+        # the two partition pipelines agree bin for bin at full size (key indices beyond 2^31)
+        for strat in ('partition', 'partition_chunked'):
+            ctx.count_begin(k, strat)
+            ctx.count_feed_device(d, nbytes)
+            np.testing.assert_array_equal(ctx.count_finish(), full, err_msg=strat)
         # alternative strategy agrees on a 10 M-read prefix
         ctx.count_begin(k, 'global_atomic')
         ctx.count_feed_device(d, 10_000_000 * 151)

@@ -89,6 +89,14 @@ def test_from_fasta_chunked_reads(ctx, monkeypatch):
         monkeypatch.setattr(klib, '_FASTA_CHUNK', chunk)
         p = klib.Profile.from_fasta(io.StringIO(text), 9)
         np.testing.assert_array_equal(p.counts, want)
+    # CRLF line ends, bytes handle, chunks smaller than most records, junk before the first header
+    text = 'junk line\r\n' + random_fasta(rnd, 60, 6000, eol='\r\n')
+    seqs = [s for _, s in klib._fasta_records(io.StringIO(text, newline=''))]
+    want = oracle.from_sequences(seqs, 7)
+    for chunk in (257, 1 << 12, 1 << 20):
+        monkeypatch.setattr(klib, '_FASTA_CHUNK', chunk)
+        p = klib.Profile.from_fasta(io.BytesIO(text.encode('latin-1')), 7)
+        np.testing.assert_array_equal(p.counts, want)
 
 
 def test_large_single_record(ctx):

@@ -10,6 +10,7 @@ from kpal_amd import _native
 ap = argparse.ArgumentParser()
 ap.add_argument('--k', type=int, default=12)
 ap.add_argument('--mb', type=int, default=1024)
+ap.add_argument('--strategy', default='auto')
 a = ap.parse_args()
 ctx = _native.context()
 rs = np.random.RandomState(5)
@@ -48,7 +49,7 @@ for name, buf in cases.items():
     for it in range(3):
         if it == 1:
             ctx.prof_enable(True); ctx.prof_reset()
-        ctx.count_begin(a.k)
+        ctx.count_begin(a.k, a.strategy)
         ctx.count_feed_device(d, buf.size)
         ctx.count_finish(to_host=False)
     prof = ctx.prof_get()
