@@ -170,10 +170,12 @@ __device__ __forceinline__ void chunk_store_rows(const unsigned char *rows, uint
 // Abandoned tile (a bucket would have needed a third chunk: more than 4096 of the tile's 24576
 // k-mers in one bucket, i.e. homopolymer-like input under several waves at once): its k-mers are
 // counted straight into the table.  Per step the wave counts the occurrences of its first k-mer with
-// ballots (one global atomic), everything else takes one global atomic per k-mer.
+// ballots into a pending (k-mer, count) pair that is flushed with one global atomic only when the
+// hot k-mer changes; everything else takes one global atomic per k-mer.
 template <int K>
 __device__ __forceinline__ void chunk_count_tile_direct(const Span &s, uint64_t first_step,
-                                                        unsigned long long *__restrict__ table)
+                                                        unsigned long long *__restrict__ table, uint32_t &pend_hot,
+                                                        unsigned long long &pend_cnt)
 {
     const int lane = threadIdx.x & 63;
     Chunk carry = load_chunk(s, (int64_t)(first_step * 64) - 1);
@@ -199,7 +201,12 @@ __device__ __forceinline__ void chunk_count_tile_direct(const Span &s, uint64_t 
             same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
             if (counted && !eq) atomicAdd(&table[v], 1ULL);
         }
-        if (lane == src) atomicAdd(&table[hot], (unsigned long long)same);
+        if (hot != pend_hot) {   // wave-uniform
+            if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
+            pend_hot = hot;
+            pend_cnt = 0;
+        }
+        pend_cnt += same;
     }
 }
 
@@ -283,8 +290,11 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
     if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
     for (uint32_t e = nret; e < kChunkRow; ++e) p->table[((uint64_t)mine * gridDim.x + blockIdx.x) * kChunkRow + e] = kChunkEmpty;
     const uint32_t nd = min(defer_n, kChunkDeferCap);
+    uint32_t pend_hot = 0;
+    unsigned long long pend_cnt = 0;
     for (uint32_t i = 0; i < nd; ++i)
-        chunk_count_tile_direct<K>(s, step0 + (uint64_t)defer_t[i] * kScatterSteps, table);
+        chunk_count_tile_direct<K>(s, step0 + (uint64_t)defer_t[i] * kScatterSteps, table, pend_hot, pend_cnt);
+    if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table[pend_hot], pend_cnt);
 }
 
 // C4a: exclusive scan of the overflow counts -> ostart[0..512], cursors reset; slice plan of the
@@ -372,7 +382,9 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
     for (int i = threadIdx.x; i < BINS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto add8 = [&](const uint4 q, uint32_t live) {   // live: how many of the 8 keys exist (tail of a chunk)
+    // FULL: all 8 keys exist; otherwise only the first `live` (tail vector of a partly filled chunk)
+    auto add8 = [&](const uint4 q, uint32_t live, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const uint32_t k[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
                                q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
         const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
         uint32_t same = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bool exists = (uint32_t)j < live;
+            const bool exists = FULL || (uint32_t)j < live;
             const bool eq = exists && k[j] == hot;
             same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
             atomicAdd(&hist[(eq || !exists) ? (uint32_t)(BINS + lane) : (k[j] & (uint32_t)(BINS - 1))], 1u);
@@ -396,11 +408,16 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
     // loads of the next unit are issued before the current one is histogrammed.
     uint4 qa[4];
     uint32_t la[4];
-    bool have = false;
+    bool have = false, all_full = false;   // all_full (wave-uniform): every key of the pending unit exists
     auto consume = [&]() {
+        if (all_full) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (la[u]) add8(qa[u], la[u]);
+            for (int u = 0; u < 4; ++u) add8(qa[u], 8u, std::true_type{});
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (la[u]) add8(qa[u], la[u], std::false_type{});
+        }
     };
     auto feed = [&](uint32_t e, uint32_t half) {   // wave-uniform arguments
         const uint32_t fill = (e >> kChunkIdBits) + 1u;
@@ -422,6 +439,7 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
             la[u] = lb[u];
         }
         have = true;
+        all_full = fill >= 8u * 256u * (half + 1u);
     };
     auto walk = [&](const uint32_t *list, uint32_t n_entries) {
         const uint32_t per = (n_entries + slices - 1) / slices;
