@@ -28,16 +28,20 @@ constexpr uint32_t kChunkEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kChunkDeferCap = 1024;            // abandoned tiles a workgroup can remember (16384 steps per wave)
 constexpr uint32_t kChunkIdBits = 20;                // chunk ids < 2^20: key indices fit 32 bits; entry = id | (fill-1) << 20
 
+// All arrays carry a leading coarse-bucket dimension Y (1 for the one-level path; blockIdx.y
+// selects it), so chunk ids -- relative to the coarse bucket's part of the pool -- stay below 2^20.
 struct ChunkPool {
-    uint16_t *keys;        // G * per_block chunks of kChunkKeys keys
+    uint16_t *keys;        // [Y][G * per_block chunks][kChunkKeys keys]
     uint32_t per_block;    // R: chunk ids of workgroup g are [g*R, (g+1)*R)
-    uint32_t *table;       // [512][G][kChunkRow] entries (chunk id | (fill-1) << 20), kChunkEmpty = none
-    uint32_t *nlist;       // [512] retired chunks per bucket (slice plan)
-    uint32_t *ovf_n;       // [512] overflow entries per bucket
-    uint32_t *ovf_count;   // total overflow entries
-    uint2 *ovf;            // overflow entries (bucket, entry), capacity G * per_block
+    uint32_t groups;       // G: scatter workgroups per coarse bucket
+    uint32_t *table;       // [Y][512][G][kChunkRow] entries (chunk id | (fill-1) << 20), kChunkEmpty = none
+    uint32_t *nlist;       // [Y][512] retired chunks per bucket (slice plan)
+    uint32_t *ovf_n;       // [Y][512] overflow entries per bucket
+    uint32_t *ovf_count;   // [Y] overflow entries
+    uint2 *ovf;            // [Y][G * per_block] overflow entries (bucket, entry)
     uint32_t *error;       // set if a workgroup ran out of chunks (cannot happen: R is a worst-case bound)
 };
+__device__ __forceinline__ uint64_t chunk_pool_chunks(const ChunkPool &p) { return (uint64_t)p.groups * p.per_block; }
 // The scatter kernel gets the pool by pointer (device memory): its rarely used fields must not sit
 // in scalar registers for the whole kernel.
 
@@ -56,18 +60,23 @@ __device__ __forceinline__ uint32_t chunk_alloc(const ChunkPool *p, uint32_t per
 }
 
 // Record a finished chunk of bucket b; `nret` counts this (bucket, workgroup)'s chunks so far.
+__device__ __forceinline__ uint32_t *chunk_table_row(const ChunkPool *p, uint32_t b)
+{
+    return p->table + (((uint64_t)blockIdx.y * kNumBuckets + b) * gridDim.x + blockIdx.x) * kChunkRow;
+}
+
 __device__ __forceinline__ void chunk_retire(const ChunkPool *p, uint32_t cid, uint32_t b, uint32_t fill, uint32_t &nret)
 {
     const uint32_t e = chunk_entry(cid, fill);
     if (nret < kChunkRow) {
-        p->table[((uint64_t)b * gridDim.x + blockIdx.x) * kChunkRow + nret] = e;
+        chunk_table_row(p, b)[nret] = e;
     } else {   // skewed input only
-        const uint32_t at = atomicAdd(p->ovf_count, 1u);
-        p->ovf[at] = make_uint2(b, e);
-        atomicAdd(&p->ovf_n[b], 1u);
+        const uint32_t at = atomicAdd(&p->ovf_count[blockIdx.y], 1u);
+        p->ovf[(uint64_t)blockIdx.y * chunk_pool_chunks(*p) + at] = make_uint2(b, e);
+        atomicAdd(&p->ovf_n[blockIdx.y * kNumBuckets + b], 1u);
     }
     ++nret;
-    atomicAdd(&p->nlist[b], 1u);
+    atomicAdd(&p->nlist[blockIdx.y * kNumBuckets + b], 1u);
 }
 
 // Placement of 16 values into the per-tile rows (layout of place16).  A counted value whose row is
@@ -78,8 +87,7 @@ __device__ __forceinline__ void chunk_retire(const ChunkPool *p, uint32_t cid, u
 template <int KB>
 __device__ __forceinline__ uint32_t place16_chunked(unsigned char *rows, uint32_t *pos, const uint32_t *gcur,
                                                     const uint32_t *nextc, uint16_t *__restrict__ keys,
-                                                    const uint32_t (&v)[16], uint32_t valid
-                                                    )
+                                                    const uint32_t (&v)[16], uint32_t valid)
 {
     constexpr uint32_t kKeyMask = (1u << KB) - 1u;
     uint32_t slot[16];
@@ -165,6 +173,27 @@ __device__ __forceinline__ void chunk_store_rows(const unsigned char *rows, uint
         // lanes below `room` were written by the first store: send them out of range
         __builtin_amdgcn_raw_buffer_store_b16((short)v, rsrc, (uint32_t)lane >= rm ? 2 * lane : 0x7FFFFFF0, 0, 0);
     }
+}
+
+// Copy-out phase of a normal tile: thread t owns bucket t.  Stores the staged keys, advances the
+// cursor, and when the current chunk is full retires it, continues in the pre-assigned next chunk
+// and takes another one from the workgroup's range.
+__device__ __forceinline__ void chunk_finish_tile(const unsigned char *rows, uint32_t *pos, uint32_t *gcur, uint32_t *nextc,
+                                                  uint32_t *alloc_next, const ChunkPool *p, uint32_t per_block,
+                                                  uint16_t *__restrict__ keys, uint32_t &nret)
+{
+    const uint32_t mine = threadIdx.x;
+    const uint32_t n = pos[mine], g = gcur[mine], nx = nextc[mine];
+    chunk_store_rows(rows, keys, n, g, nx << kChunkShift);
+    const uint32_t room = kChunkKeys - (g & (kChunkKeys - 1));
+    uint32_t g2 = g + n;
+    if (n >= room) {
+        chunk_retire(p, g >> kChunkShift, mine, kChunkKeys, nret);
+        g2 = (nx << kChunkShift) + (n - room);
+        nextc[mine] = chunk_alloc(p, per_block, alloc_next, 1);
+    }
+    gcur[mine] = g2;
+    pos[mine] = 0;
 }
 
 // Abandoned tile (a bucket would have needed a third chunk: more than 4096 of the tile's 24576
@@ -254,8 +283,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
             uint32_t v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window[st], j);
-            smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, mask[st]
-                                                    ));
+            smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, mask[st]));
         }
         if (smax >= kChunkKeys) tile_over = 1;   // benign race: every writer stores 1
         __syncthreads();
@@ -271,30 +299,114 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
             __syncthreads();
             continue;
         }
-        const uint32_t n = pos[mine], g = gcur[mine], nx = nextc[mine];
-        chunk_store_rows(rows, keys, n, g, nx << kChunkShift);
-        const uint32_t room = kChunkKeys - (g & (kChunkKeys - 1));
-        uint32_t g2 = g + n;
-        if (n >= room) {   // the current chunk is full: retire it, continue in the next, take another
-            chunk_retire(p, g >> kChunkShift, mine, kChunkKeys, nret);
-            g2 = (nx << kChunkShift) + (n - room);
-            nextc[mine] = chunk_alloc(p, per_block, &alloc_next, 1);
-        }
-        gcur[mine] = g2;
-        pos[mine] = 0;
+        chunk_finish_tile(rows, pos, gcur, nextc, &alloc_next, p, per_block, keys, nret);
         __syncthreads();
     }
     // the partly filled current chunks, then the unused row entries
     __syncthreads();
     const uint32_t g = gcur[mine];
     if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
-    for (uint32_t e = nret; e < kChunkRow; ++e) p->table[((uint64_t)mine * gridDim.x + blockIdx.x) * kChunkRow + e] = kChunkEmpty;
+    for (uint32_t e = nret; e < kChunkRow; ++e) chunk_table_row(p, mine)[e] = kChunkEmpty;
     const uint32_t nd = min(defer_n, kChunkDeferCap);
     uint32_t pend_hot = 0;
     unsigned long long pend_cnt = 0;
     for (uint32_t i = 0; i < nd; ++i)
         chunk_count_tile_direct<K>(s, step0 + (uint64_t)defer_t[i] * kScatterSteps, table, pend_hot, pend_cnt);
     if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table[pend_hot], pend_cnt);
+}
+
+// Level 2 of the two-level path (k = 13..16) as a chunked scatter: blockIdx.y = coarse bucket c, whose
+// 24-bit residuals (9-bit bucket | 15-bit key) are res[start1[c] .. start1[c+1]); workgroup g takes
+// residuals [g*KPB, (g+1)*KPB) of that stream, a wave-step is 1024 residuals (load_macro).  Same
+// staging, chunk logic and table rows as chunk_scatter_kernel -- no counting pass over the residuals.
+template <int KB>
+__device__ __forceinline__ void chunk_count_keys_direct(const uint32_t *__restrict__ res, uint64_t lo, uint64_t n, uint64_t at,
+                                                        unsigned long long *__restrict__ table_c)
+{
+    for (int st = 0; st < kScatterSteps; ++st) {
+        uint32_t v[16], valid;
+        load_macro(res, lo, n, at + (uint64_t)st * kMacroKeys, v, valid);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool counted = (valid >> (15 - j)) & 1u;
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(counted);
+            if (!live) continue;   // wave-uniform
+            const uint32_t hot = (uint32_t)__builtin_amdgcn_readlane(v[j], __ffsll((long long)live) - 1);
+            const bool eq = counted && v[j] == hot;
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(eq);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)live) - 1) atomicAdd(&table_c[hot], (unsigned long long)__popcll(same));
+            if (counted && !eq) atomicAdd(&table_c[v[j]], 1ULL);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScatterThreads, 4) void chunk_key_scatter_kernel(const uint32_t *__restrict__ res,
+                                                                               const uint64_t *__restrict__ start1,
+                                                                               uint32_t keys_per_block,
+                                                                               const ChunkPool *__restrict__ p,
+                                                                               uint16_t *__restrict__ keys_base, uint32_t per_block,
+                                                                               unsigned long long *__restrict__ table)
+{
+    constexpr int KB = kResKeyBits;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kRowsBytes + 16];
+    __shared__ uint32_t pos[kNumBuckets];
+    __shared__ uint32_t gcur[kNumBuckets];
+    __shared__ uint32_t nextc[kNumBuckets];
+    __shared__ uint32_t tile_over, alloc_next, defer_n;
+    __shared__ uint16_t defer_t[kChunkDeferCap];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t mine = threadIdx.x;
+    const uint32_t c = blockIdx.y;
+    const uint64_t lo = start1[c], n = start1[c + 1] - lo;
+    uint16_t *keys = keys_base + (((uint64_t)c * gridDim.x * per_block) << kChunkShift);
+    const uint32_t first_chunk = blockIdx.x * per_block;
+    if (threadIdx.x == 0) {
+        alloc_next = first_chunk + 2 * kNumBuckets;
+        tile_over = 0;
+        defer_n = 0;
+    }
+    gcur[mine] = (first_chunk + mine) << kChunkShift;
+    nextc[mine] = first_chunk + kNumBuckets + mine;
+    uint32_t nret = 0;
+    pos[mine] = 0;
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)blockIdx.x * keys_per_block;
+    const uint64_t per_wave = keys_per_block / kScatterWaves;
+    const uint64_t w0 = b0 + (uint64_t)wave * per_wave;
+    for (uint64_t t = 0; t < per_wave; t += (uint64_t)kScatterSteps * kMacroKeys) {
+        if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest residuals (also skips empty workgroups)
+        uint32_t smax = 0;
+#pragma unroll
+        for (int st = 0; st < kScatterSteps; ++st) {
+            uint32_t v[16], valid;
+            load_macro(res, lo, n, w0 + t + (uint64_t)st * kMacroKeys, v, valid);
+            smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, valid));
+        }
+        if (smax >= kChunkKeys) tile_over = 1;
+        __syncthreads();
+        if (tile_over) {   // block-uniform, pathological input only
+            pos[mine] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                tile_over = 0;
+                if (defer_n < kChunkDeferCap) defer_t[defer_n] = (uint16_t)(t / ((uint64_t)kScatterSteps * kMacroKeys));
+                else *p->error = 1u;
+                ++defer_n;
+            }
+            __syncthreads();
+            continue;
+        }
+        chunk_finish_tile(rows, pos, gcur, nextc, &alloc_next, p, per_block, keys, nret);
+        __syncthreads();
+    }
+    __syncthreads();
+    const uint32_t g = gcur[mine];
+    if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
+    for (uint32_t e = nret; e < kChunkRow; ++e) chunk_table_row(p, mine)[e] = kChunkEmpty;
+    const uint32_t nd = min(defer_n, kChunkDeferCap);
+    for (uint32_t i = 0; i < nd; ++i)
+        chunk_count_keys_direct<KB>(res, lo, n, w0 + (uint64_t)defer_t[i] * kScatterSteps * kMacroKeys,
+                                    table + ((uint64_t)c << kResidualBits));
 }
 
 // C4a: exclusive scan of the overflow counts -> ostart[0..512], cursors reset; slice plan of the
@@ -306,6 +418,11 @@ __global__ __launch_bounds__(kNumBuckets) void chunk_plan_kernel(const uint32_t 
 {
     __shared__ uint32_t wsum[kNumBuckets / 64], ssum[kNumBuckets / 64], tsum[kNumBuckets / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    nlist += blockIdx.x * kNumBuckets;           // one workgroup per coarse bucket
+    ovf_n += blockIdx.x * kNumBuckets;
+    ostart += blockIdx.x * (kNumBuckets + 1);
+    ocur += blockIdx.x * kNumBuckets;
+    slice_start += blockIdx.x * (kNumBuckets + 1);
     const uint32_t v = ovf_n[threadIdx.x];
     const uint32_t c = nlist[threadIdx.x];
     uint32_t incl = v, cincl = c;
@@ -352,26 +469,34 @@ __global__ __launch_bounds__(kNumBuckets) void chunk_plan_kernel(const uint32_t 
 __global__ __launch_bounds__(256) void chunk_list_kernel(ChunkPool p, const uint32_t *__restrict__ ostart,
                                                          uint32_t *__restrict__ ocur, uint32_t *__restrict__ osorted)
 {
-    const uint32_t n = *p.ovf_count;
+    const uint32_t n = p.ovf_count[blockIdx.y];
+    const uint64_t region = (uint64_t)blockIdx.y * chunk_pool_chunks(p);
+    ostart += blockIdx.y * (kNumBuckets + 1);
+    ocur += blockIdx.y * kNumBuckets;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint2 e = p.ovf[i];
-        osorted[ostart[e.x] + atomicAdd(&ocur[e.x], 1u)] = e.y;
+        const uint2 e = p.ovf[region + i];
+        osorted[region + ostart[e.x] + atomicAdd(&ocur[e.x], 1u)] = e.y;
     }
 }
 
 // C5: LDS histogram of one slice of one bucket's chunks, merged into the table (see
 // part_hist_kernel for the slice plan and the hot-key counting).  The bucket's entries are its
 // table row (G * 4 words, mostly two or three chunks per workgroup) followed by its overflow
-// entries; a slice takes an equal share of both.  A wave reads 64 entries at a time and works
-// through the non-empty ones chunk by chunk, four 16-byte loads per lane in flight.
+// entries; a slice takes an equal share of both.  The entries are dealt out to the 16 waves round
+// robin; a wave works through its non-empty ones chunk by chunk, four 16-byte loads per lane in flight.
 template <int KB>
-__global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t G, const uint32_t *__restrict__ ostart,
+__global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, const uint32_t *__restrict__ ostart,
                                                           const uint32_t *__restrict__ osorted,
                                                           const uint32_t *__restrict__ slice_start,
                                                           unsigned long long *__restrict__ table)
 {
     constexpr int BINS = 1 << KB;
     __shared__ __attribute__((aligned(16))) uint32_t hist[BINS + 64];
+    const uint32_t G = p.groups;
+    const uint64_t region = (uint64_t)blockIdx.y * chunk_pool_chunks(p);   // this coarse bucket's part of pool and overflow list
+    const uint16_t *keys = p.keys + (region << kChunkShift);
+    ostart += blockIdx.y * (kNumBuckets + 1);
+    slice_start += blockIdx.y * (kNumBuckets + 1);
     if (blockIdx.x >= slice_start[kNumBuckets]) return;
     uint32_t b = 0;
 #pragma unroll
@@ -422,7 +547,7 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
     auto feed = [&](uint32_t e, uint32_t half) {   // wave-uniform arguments
         const uint32_t fill = (e >> kChunkIdBits) + 1u;
         const uint32_t nvec = (fill + 7u) >> 3;
-        const uint4 *kv = reinterpret_cast<const uint4 *>(p.keys + ((uint64_t)(e & ((1u << kChunkIdBits) - 1u)) << kChunkShift));
+        const uint4 *kv = reinterpret_cast<const uint4 *>(keys + ((uint64_t)(e & ((1u << kChunkIdBits) - 1u)) << kChunkShift));
         uint4 qb[4];
         uint32_t lb[4];
 #pragma unroll
@@ -444,8 +569,12 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
     auto walk = [&](const uint32_t *list, uint32_t n_entries) {
         const uint32_t per = (n_entries + slices - 1) / slices;
         const uint32_t e0 = min(sl * per, n_entries), e1 = min((sl + 1) * per, n_entries);
-        for (uint32_t base = e0 + wave * 64; base < e1; base += 16 * 64) {
-            const uint32_t idx = base + lane;
+        // entries are dealt out in quads (one table row = the chunks of one scatter workgroup): quad q
+        // belongs to wave q % 16, so short lists still keep all waves busy and every wave gets the
+        // same mix of full and partly filled chunks.  Lane l looks at entry l % 4 of the wave's
+        // (16 * round + l / 4)-th quad.
+        for (uint32_t base = e0 + 4u * wave; base < e1; base += 16 * 64) {
+            const uint32_t idx = base + 64u * (lane >> 2) + (lane & 3u);
             const uint32_t e = idx < e1 ? list[idx] : kChunkEmpty;
             unsigned long long m = __builtin_amdgcn_ballot_w64(e != kChunkEmpty);
             while (m) {   // wave-uniform
@@ -457,11 +586,11 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, uint32_t 
             }
         }
     };
-    walk(p.table + (uint64_t)b * G * kChunkRow, G * kChunkRow);
-    walk(osorted + ostart[b], ostart[b + 1] - ostart[b]);
+    walk(p.table + ((uint64_t)blockIdx.y * kNumBuckets + b) * G * kChunkRow, G * kChunkRow);
+    walk(osorted + region + ostart[b], ostart[b + 1] - ostart[b]);
     if (have) consume();
     __syncthreads();
-    unsigned long long *dst = table + ((uint64_t)b << KB);
+    unsigned long long *dst = table + ((uint64_t)blockIdx.y << (kPartBits + KB)) + ((uint64_t)b << KB);
     if (slices == 1) {
         for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
             const uint32_t c = hist[i];

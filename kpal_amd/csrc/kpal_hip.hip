@@ -86,8 +86,11 @@ struct kpal_ctx {
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
     bool chunk_error_armed = false;
+    bool level2_chunked = false;             // two-level path: KPAL_LEVEL2_CHUNKED=1 runs level 2 as a chunked scatter (measured: no gain, the aligned-line key_scatter is faster)
     ChunkPool chunk_pool_sent = {};          // what the device copy of the pool descriptor holds
     ChunkPool *chunk_pool_dev = nullptr;
+    uint32_t chunk_meta_y = 0;               // coarse-bucket count the meta layout was cleared for
+    uint32_t *chunk_error_word = nullptr;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
     DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
@@ -273,6 +276,7 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= (1ULL << 20)) ctx->batch_bytes = (size_t)v;
     }
+    if (const char *e = getenv("KPAL_LEVEL2_CHUNKED")) ctx->level2_chunked = atoi(e) != 0;
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;
@@ -365,7 +369,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     ctx->bins = 1ULL << (2 * k);
     CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
-    if (ctx->chunk_meta.p) HIPCHK(hipMemsetAsync((uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
     ctx->chunk_error_armed = false;
     ctx->counting = true;
     return KPAL_OK;
@@ -473,7 +477,84 @@ static int launch_partition(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
-// Chunked one-level partition, k = 8..12 (chunk_kernels.hpp): scatter into per-workgroup 2 KiB
+// Workspace of one chunked scatter + histogram over Y coarse buckets (Y = 1: one-level path):
+// pool of 8 KiB key chunks, table rows, overflow lists, per-coarse-bucket meta words and the device
+// copy of the pool descriptor.  meta words per coarse bucket y: nlist[512] ovf_n[512] (all y first,
+// so one memset clears them), then ovf_count[Y] error, then ostart[Y][513] ocur[Y][512]
+// slice_start[Y][513], then the descriptor.
+struct ChunkLaunch {
+    ChunkPool p;
+    ChunkPool *dpool;
+    uint32_t *ostart, *ocur, *sstart;
+    uint32_t Y;
+};
+
+static int chunk_prepare(kpal_ctx *ctx, uint32_t Y, uint32_t G, uint64_t R, ChunkLaunch &cl)
+{
+    const uint64_t per_y = (uint64_t)G * R;
+    if (per_y >= (1ull << kChunkIdBits)) return set_err(KPAL_E_INVALID, "chunked partition: batch too large");
+    const uint64_t cap = per_y * Y;
+    CHK(ensure(ctx, ctx->keys, cap * kChunkKeys * sizeof(uint16_t)));
+    CHK(ensure(ctx, ctx->chunk_table, (size_t)Y * kNumBuckets * G * kChunkRow * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->chunk_ovf, cap * sizeof(uint2)));
+    CHK(ensure(ctx, ctx->chunk_sorted, cap * sizeof(uint32_t)));
+    const size_t clear_words = (size_t)Y * 2 * kNumBuckets + Y;   // nlist, ovf_n, ovf_count
+    const size_t pool_words = (sizeof(ChunkPool) + 3) / 4 + 8;
+    const size_t meta_words = clear_words + 1 + (size_t)Y * (2 * (kNumBuckets + 1) + kNumBuckets) + 4 + pool_words;
+    const bool fresh = ctx->chunk_meta.cap < meta_words * sizeof(uint32_t);
+    CHK(ensure(ctx, ctx->chunk_meta, meta_words * sizeof(uint32_t)));
+    uint32_t *meta = (uint32_t *)ctx->chunk_meta.p;
+    if (fresh || Y != ctx->chunk_meta_y) {
+        HIPCHK(hipMemsetAsync(meta, 0, meta_words * sizeof(uint32_t), ctx->stream));
+        ctx->chunk_meta_y = Y;
+        ctx->chunk_pool_dev = nullptr;
+    }
+    ChunkPool &p = cl.p;
+    memset(&p, 0, sizeof(p));   // padding too: the descriptor is compared bytewise below
+    p.keys = (uint16_t *)ctx->keys.p;
+    p.per_block = (uint32_t)R;
+    p.groups = G;
+    p.table = (uint32_t *)ctx->chunk_table.p;
+    p.nlist = meta;
+    p.ovf_n = meta + (size_t)Y * kNumBuckets;
+    p.ovf_count = meta + (size_t)Y * 2 * kNumBuckets;
+    p.error = meta + clear_words;
+    p.ovf = (uint2 *)ctx->chunk_ovf.p;
+    cl.ostart = meta + clear_words + 1;
+    cl.ocur = cl.ostart + (size_t)Y * (kNumBuckets + 1);
+    cl.sstart = cl.ocur + (size_t)Y * kNumBuckets;
+    cl.dpool = (ChunkPool *)(((uintptr_t)(cl.sstart + (size_t)Y * (kNumBuckets + 1)) + 15) & ~(uintptr_t)15);
+    cl.Y = Y;
+    ctx->chunk_error_word = p.error;
+    // the device copy changes only when a buffer was reallocated or the geometry changed: a
+    // synchronous copy then -- an asynchronous one would read this stack frame after it is gone
+    if (memcmp(&p, &ctx->chunk_pool_sent, sizeof(ChunkPool)) != 0 || cl.dpool != ctx->chunk_pool_dev) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(cl.dpool, &p, sizeof(ChunkPool), hipMemcpyHostToDevice));
+        ctx->chunk_pool_sent = p;
+        ctx->chunk_pool_dev = cl.dpool;
+    }
+    ctx->chunk_error_armed = true;
+    // per batch: counts restart at 0; the error word is sticky until count_finish
+    HIPCHK(hipMemsetAsync(meta, 0, clear_words * sizeof(uint32_t), ctx->stream));
+    return KPAL_OK;
+}
+
+// The kernels after the scatter: slice plan, overflow grouping, histogram + merge.
+template <int KB>
+static int chunk_histogram(kpal_ctx *ctx, const ChunkLaunch &cl)
+{
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    LAUNCH(ctx, "chunk_plan", chunk_plan_kernel, dim3(cl.Y), dim3(kNumBuckets), (const uint32_t *)cl.p.nlist,
+           (const uint32_t *)cl.p.ovf_n, cl.ostart, cl.ocur, cl.sstart);
+    LAUNCH(ctx, "chunk_list", chunk_list_kernel, dim3(64, cl.Y), dim3(256), cl.p, (const uint32_t *)cl.ostart, cl.ocur,
+           (uint32_t *)ctx->chunk_sorted.p);
+    LAUNCH(ctx, "chunk_hist", (chunk_hist_kernel<KB>), dim3(kHistGridX, cl.Y), dim3(1024), cl.p, (const uint32_t *)cl.ostart,
+           (const uint32_t *)ctx->chunk_sorted.p, (const uint32_t *)cl.sstart, table);
+    return KPAL_OK;
+}
+
+// Chunked one-level partition, k = 8..12 (chunk_kernels.hpp): scatter into per-workgroup 8 KiB
 // chunks, record them in (bucket, workgroup) table rows, histogram every bucket's chunks.
 static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
 {
@@ -488,56 +569,13 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
     // chunks per workgroup, worst case: spb*1024/4096 full ones + a partly filled and a
     // pre-assigned next one per bucket (+ slack)
     const uint64_t R = spb * 1024 / kChunkKeys + 2 * kNumBuckets + 64;
-    const uint64_t cap = (uint64_t)G * R;
-    if (cap >= (1ull << kChunkIdBits)) return set_err(KPAL_E_INVALID, "chunked partition: batch too large");
-    CHK(ensure(ctx, ctx->keys, cap * kChunkKeys * sizeof(uint16_t)));
-    CHK(ensure(ctx, ctx->chunk_table, (size_t)kNumBuckets * G * kChunkRow * sizeof(uint32_t)));
-    CHK(ensure(ctx, ctx->chunk_ovf, cap * sizeof(uint2)));
-    CHK(ensure(ctx, ctx->chunk_sorted, cap * sizeof(uint32_t)));
-    // meta words: nlist[512] ovf_n[512] ovf_count error | ostart[513] ocur[512] slice_start[513] | ChunkPool
-    const size_t pool_words = (sizeof(ChunkPool) + 3) / 4 + 4;
-    const size_t meta_words = 2 * kNumBuckets + 2 + (kNumBuckets + 1) + kNumBuckets + (kNumBuckets + 1) + 3 + pool_words;
-    const bool fresh = ctx->chunk_meta.p == nullptr;
-    CHK(ensure(ctx, ctx->chunk_meta, meta_words * sizeof(uint32_t)));
-    uint32_t *meta = (uint32_t *)ctx->chunk_meta.p;
-    if (fresh) HIPCHK(hipMemsetAsync(meta, 0, meta_words * sizeof(uint32_t), ctx->stream));
-    ChunkPool p;
-    memset(&p, 0, sizeof(p));   // padding too: the descriptor is compared bytewise below
-    p.keys = (uint16_t *)ctx->keys.p;
-    p.per_block = (uint32_t)R;
-    p.table = (uint32_t *)ctx->chunk_table.p;
-    p.nlist = meta;
-    p.ovf_n = meta + kNumBuckets;
-    p.ovf_count = meta + 2 * kNumBuckets;
-    p.error = meta + 2 * kNumBuckets + 1;
-    p.ovf = (uint2 *)ctx->chunk_ovf.p;
-    uint32_t *ostart = meta + 2 * kNumBuckets + 2;
-    uint32_t *ocur = ostart + kNumBuckets + 1;
-    uint32_t *sstart = ocur + kNumBuckets;
-    ChunkPool *dpool = (ChunkPool *)(((uintptr_t)(sstart + kNumBuckets + 1) + 15) & ~(uintptr_t)15);
-    // the device copy changes only when a buffer was reallocated (per_block travels by value): a
-    // synchronous copy then -- an asynchronous one would read this stack frame after it is gone
-    ChunkPool cmp = p;
-    cmp.per_block = 0;
-    if (memcmp(&cmp, &ctx->chunk_pool_sent, sizeof(ChunkPool)) != 0 || dpool != ctx->chunk_pool_dev) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipMemcpy(dpool, &cmp, sizeof(ChunkPool), hipMemcpyHostToDevice));
-        ctx->chunk_pool_sent = cmp;
-        ctx->chunk_pool_dev = dpool;
-    }
-    ctx->chunk_error_armed = true;
-    // per batch: counts restart at 0; the error word is sticky until count_finish
-    HIPCHK(hipMemsetAsync(meta, 0, (2 * kNumBuckets + 1) * sizeof(uint32_t), ctx->stream));
+    ChunkLaunch cl;
+    CHK(chunk_prepare(ctx, 1, G, R, cl));
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_8_12(ctx->k, {
-        LAUNCH(ctx, "chunk_scatter", (chunk_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, (const ChunkPool *)dpool,
-               p.keys, p.per_block, table);
-        LAUNCH(ctx, "chunk_plan", chunk_plan_kernel, dim3(1), dim3(kNumBuckets), (const uint32_t *)p.nlist,
-               (const uint32_t *)p.ovf_n, ostart, ocur, sstart);
-        LAUNCH(ctx, "chunk_list", chunk_list_kernel, dim3(256), dim3(256), p, (const uint32_t *)ostart, ocur,
-               (uint32_t *)ctx->chunk_sorted.p);
-        LAUNCH(ctx, "chunk_hist", (chunk_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kHistGridX), dim3(1024), p, G,
-               (const uint32_t *)ostart, (const uint32_t *)ctx->chunk_sorted.p, (const uint32_t *)sstart, table);
+        LAUNCH(ctx, "chunk_scatter", (chunk_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, (const ChunkPool *)cl.dpool,
+               cl.p.keys, cl.p.per_block, table);
+        CHK(chunk_histogram<PartCfg<K>::kKeyBits>(ctx, cl));
     });
     return KPAL_OK;
 }
@@ -557,7 +595,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
     const uint64_t max_keys = s.nchunks * 16;
     if (ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64) != KPAL_OK ||
-        ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK) {
+        (!ctx->level2_chunked && ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK)) {
         if (max_keys <= ((uint64_t)1 << 30)) return KPAL_E_NOMEM;
         return kSplitBatch;   // not enough HBM for a batch of this size: retry with half
     }
@@ -591,6 +629,24 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
                (const uint32_t *)offs1, (const uint64_t *)start1, res);
     });
+    if (ctx->level2_chunked) {
+        // level 2 as a chunked scatter (chunk_kernels.hpp): no counting pass over the residuals.
+        // Two resident workgroups per CU in total; every workgroup leaves ~1000 unused 8 KiB chunks.
+        const uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * 2 / NB1);
+        const uint64_t quantum = (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;   // 24576 residuals per tile
+        uint64_t kpb2 = (maxn + g2t - 1) / g2t;
+        kpb2 = (kpb2 + quantum - 1) / quantum * quantum;
+        if (kpb2 > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
+        const uint32_t G2c = (uint32_t)((maxn + kpb2 - 1) / kpb2);
+        const uint64_t R2 = kpb2 / kChunkKeys + 2 * kNumBuckets + 64;
+        ChunkLaunch cl;
+        const int rc = chunk_prepare(ctx, (uint32_t)NB1, G2c, R2, cl);
+        if (rc == KPAL_E_NOMEM && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // retry with half the batch
+        if (rc != KPAL_OK) return rc;
+        LAUNCH(ctx, "chunk_key_scatter", chunk_key_scatter_kernel, dim3(G2c, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+               (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
+        return chunk_histogram<kResKeyBits>(ctx, cl);
+    }
     const uint64_t g2_target = std::max<uint64_t>(8, (uint64_t)ctx->num_cu * 8 / NB1);
     uint64_t kpb = (maxn + g2_target - 1) / g2_target;
     kpb = (kpb + kKeysPerBlockQuantum - 1) / kKeysPerBlockQuantum * kKeysPerBlockQuantum;
@@ -817,12 +873,12 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
     uint32_t pool_error = 0;
     if (ctx->chunk_error_armed)
-        HIPCHK(hipMemcpyAsync(&pool_error, (uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&pool_error, ctx->chunk_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, ctx->table.p, ctx->bins * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (pool_error) {
-        HIPCHK(hipMemsetAsync((uint32_t *)ctx->chunk_meta.p + 2 * kNumBuckets + 1, 0, sizeof(uint32_t), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
         return set_err(KPAL_E_HIP, "chunked partition: the chunk pool ran out (internal sizing error %u); counts are invalid", pool_error);
     }
     return KPAL_OK;
