@@ -682,7 +682,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     CHK(resolve_strategy(ctx, &strat));
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
-    if (strat == KPAL_STRATEGY_PARTITION || strat == KPAL_STRATEGY_PARTITION_CHUNKED) piece = ctx->batch_bytes;
+    if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
+    else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) piece = std::min<size_t>(ctx->batch_bytes, (size_t)1 << 30);   // chunk ids < 2^20
     else if (strat == KPAL_STRATEGY_PARTITION2) {
         // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
         // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
