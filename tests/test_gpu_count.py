@@ -312,6 +312,39 @@ def test_full_size_k15(ctx):
         ctx.free(d)
 
 
+def test_partition_pipelines_on_skewed_inputs(ctx):
+    """Both k = 8..12 pipelines against the oracle on inputs that stress the chunk logic: skewed
+    composition (buckets of very different sizes), long homopolymer / tandem-repeat stretches inside
+    random sequence (rows overflowing into direct stores across chunk ends, abandoned tiles), runs of
+    N, and one bucket receiving almost everything."""
+    rs = np.random.RandomState(77)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    n = 48 << 20
+
+    def rnd(p, size):
+        return acgt[rs.choice(4, size=size, p=p)]
+
+    cases = {}
+    cases['at_rich'] = rnd([.4, .1, .1, .4], n)
+    mixed = rnd([.25, .25, .25, .25], n)
+    at = 0
+    while at < n - (1 << 20):                     # stretches of 2 KB .. 1 MB every ~1 MB
+        length = int(rs.choice([2048, 10000, 70000, 300000, 1 << 20]))
+        unit = [b'A', b'AC', b'AAT', b'ACGTT', b'N'][rs.randint(5)]
+        mixed[at:at + length] = np.resize(np.frombuffer(unit, dtype=np.uint8), length)
+        at += length + rs.randint(1 << 18, 1 << 21)
+    cases['stretches'] = mixed
+    mostly_a = np.full(n, ord('A'), dtype=np.uint8)
+    idx = rs.randint(0, n, n // 50)
+    mostly_a[idx] = rnd([.25, .25, .25, .25], idx.size)
+    cases['mostly_a'] = mostly_a
+    for name, buf in cases.items():
+        for k in (12, 9):
+            want = oracle.count_flat(buf, k, threads=8)
+            for strat in ('partition_chunked', 'partition'):
+                np.testing.assert_array_equal(ctx.count_bytes(k, buf, strat), want, err_msg='%s k=%d %s' % (name, k, strat))
+
+
 def _kmers_numpy(buf, k, read_len=150):
     """All valid k-mer indices of '\\n'-terminated fixed-length reads, vectorised on the host."""
     lut = np.full(256, 255, dtype=np.uint8)
