@@ -680,6 +680,9 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
 {
     int strat = 0;
     CHK(resolve_strategy(ctx, &strat));
+    // tiny feeds (single records, short reads lists): the partition pipelines cost a fixed
+    // 0.1 - 0.5 ms (launches, one merge of the whole table); a quarter million atomics do not
+    if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
