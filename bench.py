@@ -31,7 +31,8 @@ def pmc_traffic(kernel, k, input_bytes_per_launch):
     WRITE_SIZE, gfx950 correction applied), scaled to this run's bytes per launch.  PMC counters
     cannot be read from inside the bench process; None if no profile of this kernel is committed."""
     try:
-        with open(PMC_PROFILE) as fh:
+        path = PMC_PROFILE if k == 12 else PMC_PROFILE.replace('.json', '_k%d.json' % k)
+        with open(path) as fh:
             prof = json.load(fh)
         for name, rec in prof['kernels'].items():
             if ('::%s_kernel' % kernel) in name and ('<%d' % k) in name:
