@@ -25,7 +25,24 @@ constexpr uint32_t kChunkShift = 12;
 constexpr uint32_t kChunkKeys = 1u << kChunkShift;   // 4096 keys = 8 KiB
 constexpr uint32_t kChunkRow = 4;                    // table entries per (bucket, workgroup)
 constexpr uint32_t kChunkEmpty = 0xFFFFFFFFu;
-constexpr uint32_t kChunkDeferCap = 1024;            // abandoned tiles a workgroup can remember (16384 steps per wave)
+constexpr uint32_t kChunkDeferCap = 256;             // runs of consecutive abandoned tiles a workgroup can remember
+
+// Abandoned tiles are remembered as runs (first tile, count): skew comes in stretches.
+struct DeferRun {
+    uint32_t first, count;
+};
+__device__ __forceinline__ void defer_tile(DeferRun *runs, uint32_t &n_runs, uint32_t tile, uint32_t *error)
+{
+    if (n_runs && runs[n_runs - 1].first + runs[n_runs - 1].count == tile) {
+        ++runs[n_runs - 1].count;
+    } else if (n_runs < kChunkDeferCap) {
+        runs[n_runs].first = tile;
+        runs[n_runs].count = 1;
+        ++n_runs;
+    } else {
+        *error = 1u;
+    }
+}
 constexpr uint32_t kChunkIdBits = 20;                // chunk ids < 2^20: key indices fit 32 bits; entry = id | (fill-1) << 20
 
 // All arrays carry a leading coarse-bucket dimension Y (1 for the one-level path; blockIdx.y
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
     __shared__ uint32_t gcur[kNumBuckets];    // key index (chunk id << 12 | offset) of every bucket's cursor
     __shared__ uint32_t nextc[kNumBuckets];   // every bucket's pre-assigned next chunk
     __shared__ uint32_t tile_over, alloc_next, defer_n;
-    __shared__ uint16_t defer_t[kChunkDeferCap];   // abandoned tiles, counted directly after the main loop
+    __shared__ DeferRun defer_t[kChunkDeferCap];   // abandoned tiles, counted directly after the main loop
     static_assert(kScatterThreads == kNumBuckets && kSlotCap == 64, "one lane per slot, one thread per bucket");
     const int wave = threadIdx.x >> 6;
     const uint32_t mine = threadIdx.x;        // the bucket this thread owns in the copy-out phase
@@ -292,9 +309,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
             __syncthreads();
             if (threadIdx.x == 0) {
                 tile_over = 0;
-                if (defer_n < kChunkDeferCap) defer_t[defer_n] = (uint16_t)(t / kScatterSteps);
-                else *p->error = 1u;
-                ++defer_n;
+                defer_tile(defer_t, defer_n, (uint32_t)(t / kScatterSteps), p->error);
             }
             __syncthreads();
             continue;
@@ -307,11 +322,11 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
     const uint32_t g = gcur[mine];
     if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
     for (uint32_t e = nret; e < kChunkRow; ++e) chunk_table_row(p, mine)[e] = kChunkEmpty;
-    const uint32_t nd = min(defer_n, kChunkDeferCap);
     uint32_t pend_hot = 0;
     unsigned long long pend_cnt = 0;
-    for (uint32_t i = 0; i < nd; ++i)
-        chunk_count_tile_direct<K>(s, step0 + (uint64_t)defer_t[i] * kScatterSteps, table, pend_hot, pend_cnt);
+    for (uint32_t i = 0; i < defer_n; ++i)
+        for (uint32_t q = 0; q < defer_t[i].count; ++q)
+            chunk_count_tile_direct<K>(s, step0 + (uint64_t)(defer_t[i].first + q) * kScatterSteps, table, pend_hot, pend_cnt);
     if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table[pend_hot], pend_cnt);
 }
 
@@ -321,21 +336,42 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
 // staging, chunk logic and table rows as chunk_scatter_kernel -- no counting pass over the residuals.
 template <int KB>
 __device__ __forceinline__ void chunk_count_keys_direct(const uint32_t *__restrict__ res, uint64_t lo, uint64_t n, uint64_t at,
-                                                        unsigned long long *__restrict__ table_c)
+                                                        unsigned long long *__restrict__ table_c, int steps, uint32_t &pend_hot,
+                                                        unsigned long long &pend_cnt)
 {
-    for (int st = 0; st < kScatterSteps; ++st) {
+    for (int st = 0; st < steps; ++st) {
         uint32_t v[16], valid;
         load_macro(res, lo, n, at + (uint64_t)st * kMacroKeys, v, valid);
+        // Per position j the wave looks for a frequent residual among the lanes 0, 8, .., 56 (a
+        // low-complexity stretch of >= 128 residuals covers eight consecutive lanes, so it is sampled)
+        // and counts its occurrences with a ballot into the pending (residual, count) pair, which is
+        // flushed with one global atomic when the residual changes; the other lanes add individually.
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const bool counted = (valid >> (15 - j)) & 1u;
-            const unsigned long long live = __builtin_amdgcn_ballot_w64(counted);
-            if (!live) continue;   // wave-uniform
-            const uint32_t hot = (uint32_t)__builtin_amdgcn_readlane(v[j], __ffsll((long long)live) - 1);
+            uint32_t hot = pend_hot;
+            uint32_t best = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counted && v[j] == pend_hot));
+            if (best < 32)   // wave-uniform: the pending residual does not dominate this position
+#pragma unroll
+            for (int l = 0; l < 64; l += 8) {
+                const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane(v[j], l);
+                const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counted && v[j] == cand));
+                if (cnt > best) {   // wave-uniform
+                    best = cnt;
+                    hot = cand;
+                }
+            }
             const bool eq = counted && v[j] == hot;
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(eq);
-            if ((int)(threadIdx.x & 63) == __ffsll((long long)live) - 1) atomicAdd(&table_c[hot], (unsigned long long)__popcll(same));
+            const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
             if (counted && !eq) atomicAdd(&table_c[v[j]], 1ULL);
+            if (same) {
+                if (hot != pend_hot) {
+                    if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table_c[pend_hot], pend_cnt);
+                    pend_hot = hot;
+                    pend_cnt = 0;
+                }
+                pend_cnt += same;
+            }
         }
     }
 }
@@ -353,7 +389,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_key_scatter_kernel(c
     __shared__ uint32_t gcur[kNumBuckets];
     __shared__ uint32_t nextc[kNumBuckets];
     __shared__ uint32_t tile_over, alloc_next, defer_n;
-    __shared__ uint16_t defer_t[kChunkDeferCap];
+    __shared__ DeferRun defer_t[kChunkDeferCap];
     const int wave = threadIdx.x >> 6;
     const uint32_t mine = threadIdx.x;
     const uint32_t c = blockIdx.y;
@@ -389,9 +425,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_key_scatter_kernel(c
             __syncthreads();
             if (threadIdx.x == 0) {
                 tile_over = 0;
-                if (defer_n < kChunkDeferCap) defer_t[defer_n] = (uint16_t)(t / ((uint64_t)kScatterSteps * kMacroKeys));
-                else *p->error = 1u;
-                ++defer_n;
+                defer_tile(defer_t, defer_n, (uint32_t)(t / ((uint64_t)kScatterSteps * kMacroKeys)), p->error);
             }
             __syncthreads();
             continue;
@@ -403,10 +437,237 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_key_scatter_kernel(c
     const uint32_t g = gcur[mine];
     if (g & (kChunkKeys - 1)) chunk_retire(p, g >> kChunkShift, mine, g & (kChunkKeys - 1), nret);
     for (uint32_t e = nret; e < kChunkRow; ++e) chunk_table_row(p, mine)[e] = kChunkEmpty;
-    const uint32_t nd = min(defer_n, kChunkDeferCap);
-    for (uint32_t i = 0; i < nd; ++i)
-        chunk_count_keys_direct<KB>(res, lo, n, w0 + (uint64_t)defer_t[i] * kScatterSteps * kMacroKeys,
-                                    table + ((uint64_t)c << kResidualBits));
+    uint32_t pend_hot = 0;
+    unsigned long long pend_cnt = 0;
+    unsigned long long *table_c = table + ((uint64_t)c << kResidualBits);
+    for (uint32_t i = 0; i < defer_n; ++i)
+        for (uint32_t q = 0; q < defer_t[i].count; ++q)
+            chunk_count_keys_direct<KB>(res, lo, n, w0 + (uint64_t)(defer_t[i].first + q) * kScatterSteps * kMacroKeys, table_c,
+                                        kScatterSteps, pend_hot, pend_cnt);
+    if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table_c[pend_hot], pend_cnt);
+}
+
+// ------------------------------------------------------------------------------------------
+// Level 2 with aligned-line staging AND chunks (default for k = 13..16).  key_scatter_kernel's
+// persistent 128-slot rows, from which only whole aligned 128-byte lines leave the CU, need exact
+// positions only to know where a row's lines go; with chunks a row simply fills its bucket's
+// current 8 KiB chunk line by line (a chunk is 64 lines, so a line never straddles two chunks)
+// and moves to the pre-assigned next chunk when it is full -- the counting pass over the
+// residuals (key_count_kernel, 54 GB of reads at k = 15) disappears, and so do the partial first
+// lines of the exact layout.
+//   gl[b]   : key index of row slot 0 (64-aligned) | lo (slots < lo of the current line are already
+//             in memory: they left directly when the row overflowed)
+//   keep[b] : keys left in the row after the last flush (restored if a tile is abandoned)
+// ------------------------------------------------------------------------------------------
+// key index of row slot `slot` of a row whose slot 0 sits at `base` (64-aligned) in its chunk
+__device__ __forceinline__ uint32_t line_slot_index(uint32_t base, uint32_t next, uint32_t slot)
+{
+    const uint32_t room = kChunkKeys - (base & (kChunkKeys - 1));
+    return slot < room ? base + slot : (next << kChunkShift) + (slot - room);
+}
+
+template <int KB>
+__device__ __forceinline__ uint32_t place16_lines_chunked(unsigned char *rows, uint32_t *pos, const uint32_t *gl,
+                                                          const uint32_t *nextc, uint16_t *__restrict__ keys,
+                                                          const uint32_t (&v)[16], uint32_t valid)
+{
+    constexpr uint32_t kKeyMask = (1u << KB) - 1u;
+    uint32_t slot[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;  // 4 * bucket
+        slot[j] = atomicAdd((uint32_t *)((unsigned char *)pos + b4), (valid >> (15 - j)) & 1u);
+    }
+    uint32_t smax = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b4 = (v[j] >> (KB - 2)) & 0x7FCu;
+        const uint32_t counted = (valid >> (15 - j)) & 1u;
+        const uint32_t x = slot[j] | ((counted ^ 1u) << 16);                  // >= 128: not counted, or row full
+        const uint32_t rot = (b4 << 2) & 0xF0u;                               // 16 * (bucket % 16): bank spread
+        const uint32_t at = ((2u * slot[j] + rot) & 254u) | (b4 << 6);        // row base = bucket * 256
+        *(uint16_t *)(rows + (x < kLineSlots ? at : kLineRowsBytes)) = (uint16_t)(v[j] & kKeyMask);
+        smax = max(smax, counted ? slot[j] : 0u);
+    }
+    if (smax >= kLineSlots) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (((valid >> (15 - j)) & 1u) && slot[j] >= kLineSlots && slot[j] < kChunkKeys) {
+                const uint32_t b = v[j] >> KB;
+                keys[line_slot_index(gl[b] & ~63u, nextc[b], slot[j])] = (uint16_t)(v[j] & kKeyMask);
+            }
+        }
+    }
+    return smax;
+}
+
+// Flush phase of one tile; eight lanes share a row (lane = row_in_group << 3 | piece, a piece is 8
+// slots = 16 bytes).  Common case: exactly one complete line and lo == 0 -> one aligned 128-byte
+// store per row.  Everything else (rows that overflowed, the final partial line) takes the slow
+// path under a wave-uniform test.
+struct LineRowState {
+    uint32_t *pos, *keep, *gl, *nextc, *nret, *alloc_next;
+};
+
+__device__ __forceinline__ void line_row_advance(const LineRowState &st, const ChunkPool *p, uint32_t per_block, uint32_t row,
+                                                 uint32_t base, uint32_t advance, uint32_t new_n, uint32_t new_lo)
+{
+    // the row's slot 0 moves `advance` keys (a multiple of 64) forward; crossing the end of the chunk
+    // retires it and continues in the next one
+    const uint32_t room = kChunkKeys - (base & (kChunkKeys - 1));
+    uint32_t nb = base + advance;
+    if (advance >= room) {
+        uint32_t nr = st.nret[row];
+        chunk_retire(p, base >> kChunkShift, row, kChunkKeys, nr);
+        st.nret[row] = nr;
+        nb = (st.nextc[row] << kChunkShift) + (advance - room);
+        st.nextc[row] = chunk_alloc(p, per_block, st.alloc_next, 1);
+    }
+    st.pos[row] = new_n;
+    st.keep[row] = new_n;
+    st.gl[row] = nb | new_lo;
+}
+
+__device__ __forceinline__ void flush_row_slow_chunked(unsigned char *rb, uint32_t rot, uint32_t piece, uint32_t row, uint32_t n,
+                                                       uint32_t glw, const LineRowState &st, const ChunkPool *p,
+                                                       uint32_t per_block, uint16_t *__restrict__ keys, bool final)
+{
+    const uint32_t l0 = glw & 63u, base = glw & ~63u, next = st.nextc[row];
+    const uint32_t L = n >> 6, r = n & 63u;
+    const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
+    const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
+    if (L >= 1) {
+        const uint16_t *k = (const uint16_t *)&line0;
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e)
+            if (8 * piece + e >= l0) keys[base + 8 * piece + e] = k[e];     // line 0 lies inside the current chunk
+        if (L >= 2) *(uint4 *)(keys + line_slot_index(base, next, 64 + 8 * piece)) = line1;
+        if (L == 1 && 8 * piece < r) *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;   // leftover moves down
+    }
+    uint32_t new_n = n, new_lo = l0, adv = 0;
+    if (L >= 1) {
+        new_n = r;
+        new_lo = L >= 2 ? r : 0u;      // with L >= 2 the remainder went out directly
+        adv = 64u * L;
+    }
+    if (final && new_n > new_lo && L <= 1) {
+        // unfinished last line of this workgroup's share: slots [new_lo, new_n)
+        const uint4 cur = (L == 1) ? line1 : line0;
+        const uint16_t *k = (const uint16_t *)&cur;
+#pragma unroll
+        for (uint32_t e = 0; e < 8; ++e) {
+            const uint32_t sl = 8 * piece + e;
+            if (sl >= new_lo && sl < new_n) keys[line_slot_index(base, next, adv + sl)] = k[e];
+        }
+    }
+    if (piece == 0) {
+        line_row_advance(st, p, per_block, row, base, adv, new_n, new_lo);
+        if (final) {   // the partly filled chunk the row ends in
+            const uint32_t g = (st.gl[row] & ~63u) + new_n;
+            if (g & (kChunkKeys - 1)) {
+                uint32_t nr = st.nret[row];
+                chunk_retire(p, g >> kChunkShift, row, g & (kChunkKeys - 1), nr);
+                st.nret[row] = nr;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void flush_lines_chunked(unsigned char *rows, const LineRowState &st, const ChunkPool *p,
+                                                    uint32_t per_block, uint16_t *__restrict__ keys, bool final)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t piece = lane & 7;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t row = wave * 32 + g * 8 + (lane >> 3);
+        const uint32_t n = st.pos[row];
+        const uint32_t glw = st.gl[row];
+        const uint32_t rot = (row & 15u) << 4;
+        unsigned char *rb = rows + row * kLineRowBytes;
+        const bool fast = (n >> 6) == 1 && (glw & 63u) == 0;
+        const bool slow = !fast && ((n >> 6) >= 1 || final);
+        if (__builtin_expect(__any(slow), 0)) {          // wave-uniform
+            if (slow || fast) flush_row_slow_chunked(rb, rot, piece, row, n, glw, st, p, per_block, keys, final);
+            else if (piece == 0) st.keep[row] = n;
+            continue;
+        }
+        const uint32_t r = n & 63u;
+        if (fast) {   // only the lanes of flushing rows touch LDS (roughly half of them per tile)
+            const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
+            *(uint4 *)(keys + glw + 8 * piece) = line0;                         // one aligned 128-byte line per 8 lanes
+            if (8 * piece < r) {                                                // leftover moves down
+                const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
+                *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;
+            }
+            if (piece == 0) line_row_advance(st, p, per_block, row, glw, 64u, r, 0u);
+        } else if (piece == 0) {
+            st.keep[row] = n;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLineThreads) void chunk_key_lines_kernel(const uint32_t *__restrict__ res,
+                                                                      const uint64_t *__restrict__ start1,
+                                                                      uint32_t keys_per_block, const ChunkPool *__restrict__ p,
+                                                                      uint16_t *__restrict__ keys_base, uint32_t per_block,
+                                                                      unsigned long long *__restrict__ table)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char rows[kLineRowsBytes + 16];
+    __shared__ uint32_t pos[kNumBuckets], keep[kNumBuckets], gl[kNumBuckets], nextc[kNumBuckets], nret[kNumBuckets];
+    __shared__ uint32_t tile_over, alloc_next, defer_n;
+    __shared__ DeferRun defer_t[kChunkDeferCap];
+    const uint32_t c = blockIdx.y;
+    const uint64_t lo = start1[c], n = start1[c + 1] - lo;
+    uint16_t *keys = keys_base + (((uint64_t)c * gridDim.x * per_block) << kChunkShift);
+    const uint32_t first_chunk = blockIdx.x * per_block;
+    if (threadIdx.x == 0) {
+        alloc_next = first_chunk + 2 * kNumBuckets;
+        tile_over = 0;
+        defer_n = 0;
+    }
+    if (threadIdx.x < kNumBuckets) {
+        gl[threadIdx.x] = (first_chunk + threadIdx.x) << kChunkShift;
+        nextc[threadIdx.x] = first_chunk + kNumBuckets + threadIdx.x;
+        pos[threadIdx.x] = 0;
+        keep[threadIdx.x] = 0;
+        nret[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const LineRowState st = {pos, keep, gl, nextc, nret, &alloc_next};
+    const uint64_t b0 = (uint64_t)blockIdx.x * keys_per_block;
+    const uint64_t per_wave = keys_per_block / kLineWaves;
+    const uint64_t w0 = b0 + (uint64_t)(threadIdx.x >> 6) * per_wave;
+    for (uint64_t t = 0; t < per_wave; t += kMacroKeys) {
+        if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest residuals (also skips empty workgroups)
+        uint32_t v[16], valid;
+        load_macro(res, lo, n, w0 + t, v, valid);
+        if (place16_lines_chunked<kResKeyBits>(rows, pos, gl, nextc, keys, v, valid) >= kChunkKeys) tile_over = 1;
+        lds_barrier();
+        if (tile_over) {   // block-uniform, pathological input only: forget the tile, count it after the loop
+            if (threadIdx.x < kNumBuckets) pos[threadIdx.x] = keep[threadIdx.x];
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                tile_over = 0;
+                defer_tile(defer_t, defer_n, (uint32_t)(t / kMacroKeys), p->error);
+            }
+        } else {
+            flush_lines_chunked(rows, st, p, per_block, keys, false);
+        }
+        lds_barrier();
+    }
+    flush_lines_chunked(rows, st, p, per_block, keys, true);
+    __syncthreads();
+    if (threadIdx.x < kNumBuckets)
+        for (uint32_t e = nret[threadIdx.x]; e < kChunkRow; ++e) chunk_table_row(p, threadIdx.x)[e] = kChunkEmpty;
+    uint32_t pend_hot = 0;
+    unsigned long long pend_cnt = 0;
+    unsigned long long *table_c = table + ((uint64_t)c << kResidualBits);
+    for (uint32_t i = 0; i < defer_n; ++i)
+        for (uint32_t q = 0; q < defer_t[i].count; ++q)
+            chunk_count_keys_direct<kResKeyBits>(res, lo, n, w0 + (uint64_t)(defer_t[i].first + q) * kMacroKeys, table_c, 1,
+                                                 pend_hot, pend_cnt);
+    if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table_c[pend_hot], pend_cnt);
 }
 
 // C4a: exclusive scan of the overflow counts -> ostart[0..512], cursors reset; slice plan of the

@@ -86,7 +86,7 @@ struct kpal_ctx {
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
     bool chunk_error_armed = false;
-    bool level2_chunked = false;             // two-level path: KPAL_LEVEL2_CHUNKED=1 runs level 2 as a chunked scatter (measured: no gain, the aligned-line key_scatter is faster)
+    int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     ChunkPool chunk_pool_sent = {};          // what the device copy of the pool descriptor holds
     ChunkPool *chunk_pool_dev = nullptr;
     uint32_t chunk_meta_y = 0;               // coarse-bucket count the meta layout was cleared for
@@ -276,7 +276,7 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= (1ULL << 20)) ctx->batch_bytes = (size_t)v;
     }
-    if (const char *e = getenv("KPAL_LEVEL2_CHUNKED")) ctx->level2_chunked = atoi(e) != 0;
+    if (const char *e = getenv("KPAL_LEVEL2")) ctx->level2_mode = atoi(e);
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;
@@ -595,7 +595,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
     const uint64_t max_keys = s.nchunks * 16;
     if (ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64) != KPAL_OK ||
-        (!ctx->level2_chunked && ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK)) {
+        (ctx->level2_mode == 0 && ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK)) {
         if (max_keys <= ((uint64_t)1 << 30)) return KPAL_E_NOMEM;
         return kSplitBatch;   // not enough HBM for a batch of this size: retry with half
     }
@@ -629,11 +629,12 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
                (const uint32_t *)offs1, (const uint64_t *)start1, res);
     });
-    if (ctx->level2_chunked) {
+    if (ctx->level2_mode != 0) {
         // level 2 as a chunked scatter (chunk_kernels.hpp): no counting pass over the residuals.
         // Two resident workgroups per CU in total; every workgroup leaves ~1000 unused 8 KiB chunks.
-        const uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * 2 / NB1);
-        const uint64_t quantum = (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;   // 24576 residuals per tile
+        const bool lines = ctx->level2_mode == 2;   // aligned-line staging: one 1024-thread workgroup per CU
+        const uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * (lines ? 8 : 2) / NB1);
+        const uint64_t quantum = lines ? (uint64_t)kKeysPerBlockQuantum : (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;
         uint64_t kpb2 = (maxn + g2t - 1) / g2t;
         kpb2 = (kpb2 + quantum - 1) / quantum * quantum;
         if (kpb2 > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
@@ -643,8 +644,12 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         const int rc = chunk_prepare(ctx, (uint32_t)NB1, G2c, R2, cl);
         if (rc == KPAL_E_NOMEM && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // retry with half the batch
         if (rc != KPAL_OK) return rc;
-        LAUNCH(ctx, "chunk_key_scatter", chunk_key_scatter_kernel, dim3(G2c, NB1), dim3(kScatterThreads), (const uint32_t *)res,
-               (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
+        if (lines)
+            LAUNCH(ctx, "chunk_key_lines", chunk_key_lines_kernel, dim3(G2c, NB1), dim3(kLineThreads), (const uint32_t *)res,
+                   (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
+        else
+            LAUNCH(ctx, "chunk_key_scatter", chunk_key_scatter_kernel, dim3(G2c, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+                   (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
         return chunk_histogram<kResKeyBits>(ctx, cl);
     }
     const uint64_t g2_target = std::max<uint64_t>(8, (uint64_t)ctx->num_cu * 8 / NB1);
