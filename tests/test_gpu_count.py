@@ -203,6 +203,27 @@ def test_two_level_batch_halving():
     c2.close()
 
 
+@pytest.mark.parametrize('mode', ['0', '1', '2'])
+def test_two_level_variants_of_level2(mode):
+    """The three level-2 pipelines of the two-level path (KPAL_LEVEL2: 0 count + exact offsets, 1 chunked
+    per-tile runs, 2 chunked aligned lines = default) against the oracle, including skewed input."""
+    from kpal_amd import _native
+    os.environ['KPAL_LEVEL2'] = mode
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_LEVEL2']
+    rs = np.random.RandomState(int(mode) + 3)
+    buf = oracle.synth_reads(53, 0, 30000, 150, noisy=True)
+    skew = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=6 << 20, p=[.4, .1, .1, .4])].copy()
+    skew[1 << 20:(1 << 20) + 700000] = ord('A')                       # a stretch that abandons tiles
+    skew[3 << 20:(3 << 20) + 300000] = np.resize(np.frombuffer(b'AC', dtype=np.uint8), 300000)
+    for k in (13, 14):
+        for data in (buf, skew):
+            np.testing.assert_array_equal(c2.count_bytes(k, data), oracle.count_flat(data, k, threads=8))
+    c2.close()
+
+
 def test_small_partition_batches():
     """Partition path with 1 MiB batches: halo across batch seams inside one device feed."""
     from kpal_amd import _native
