@@ -937,7 +937,8 @@ static int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out)
 {
     const uint64_t n = 1ULL << (2 * k);
     if (k >= 6) {
-        LAUNCH(ctx, "balance_tiled", balance_tiled_kernel, dim3((unsigned)(1u << (2 * (k - 6)))), dim3(1024), in, out, k);
+        const unsigned tiles = 1u << (2 * (k - 6));
+        LAUNCH(ctx, "balance_tiled", balance_tiled_kernel, dim3(std::min<unsigned>(tiles, (unsigned)ctx->num_cu * 2)), dim3(1024), in, out, k);
     } else if (in == out) {
         LAUNCH(ctx, "balance_inplace", balance_inplace_kernel, dim3(stream_grid(ctx, n)), dim3(256), out, k, n);
     } else {

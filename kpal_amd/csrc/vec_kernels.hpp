@@ -100,25 +100,55 @@ __global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, 
     __shared__ unsigned long long A[S][S + 1];
     __shared__ unsigned long long B[S][S + 1];
     const int md = k - 2 * T;
-    const uint64_t M = blockIdx.x;
-    const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
-    if (M > Mr) return;
-    const bool self = M == Mr;
+    const uint64_t nM = 1ULL << (2 * md);
     const uint64_t rowstride = 1ULL << (2 * (k - T));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rl = (int)revcomp((uint64_t)lane, T);
     const unsigned long long *uin = reinterpret_cast<const unsigned long long *>(in);
     unsigned long long *uout = reinterpret_cast<unsigned long long *>(out);
-    for (int h = w; h < S; h += 16) {
-        A[h][lane] = uin[(uint64_t)h * rowstride + M * S + lane];
-        if (!self) B[h][lane] = uin[(uint64_t)h * rowstride + Mr * S + lane];
-    }
-    __syncthreads();
-    const int rl = (int)revcomp((uint64_t)lane, T);
-    for (int h = w; h < S; h += 16) {
-        const int rh = (int)revcomp((uint64_t)h, T);
-        const unsigned long long partner = self ? A[rl][rh] : B[rl][rh];
-        uout[(uint64_t)h * rowstride + M * S + lane] = A[h][lane] + partner;
-        if (!self) uout[(uint64_t)h * rowstride + Mr * S + lane] = B[h][lane] + A[rl][rh];
+    // persistent workgroups over the canonical tile pairs (M <= rc(M)); the next pair's eight values
+    // per thread are loaded before the current pair is exchanged through LDS and written back
+    auto canonical_from = [&](uint64_t m) {
+        while (m < nM && md > 0 && m > revcomp(m, md)) m += gridDim.x;
+        return m;
+    };
+    auto fetch = [&](uint64_t M, unsigned long long (&a)[4], unsigned long long (&b)[4]) {
+        const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t row = (uint64_t)(w + 16 * q) * rowstride;
+            a[q] = uin[row + M * S + lane];
+            b[q] = uin[row + Mr * S + lane];
+        }
+    };
+    unsigned long long a[4], b[4], na[4], nb[4];
+    uint64_t M = canonical_from(blockIdx.x);
+    if (M < nM) fetch(M, a, b);
+    while (M < nM) {
+        const uint64_t Mn = canonical_from(M + gridDim.x);
+        if (Mn < nM) fetch(Mn, na, nb);
+        const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+        const bool self = M == Mr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            A[w + 16 * q][lane] = a[q];
+            B[w + 16 * q][lane] = b[q];   // self: B == A
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rh = (int)revcomp((uint64_t)(w + 16 * q), T);
+            const uint64_t row = (uint64_t)(w + 16 * q) * rowstride;
+            uout[row + M * S + lane] = a[q] + B[rl][rh];
+            if (!self) uout[row + Mr * S + lane] = b[q] + A[rl][rh];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = na[q];
+            b[q] = nb[q];
+        }
+        M = Mn;
     }
 }
 
