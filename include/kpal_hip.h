@@ -88,6 +88,12 @@ int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);  
 int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);
 /* The flattening alone (tests): host_out needs nbytes bytes; records are each preceded by '\n'. */
 int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out);
+/* Profile.from_fasta_by_record, klib.py:114-133, batched: host_flat holds n_records records,
+ * record r = bytes [starts[r], starts[r+1]) (starts ascending, starts[n_records] = nbytes; put a
+ * separator byte such as '\n' between records so that no window spans two of them).  host_out
+ * receives n_records tables of 4^k int64, record-major.  Independent of the begin/feed/finish state. */
+int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
+                       size_t n_records, int64_t *host_out);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
 int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
 

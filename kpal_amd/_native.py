@@ -55,6 +55,7 @@ SIGNATURES = {
     'kpal_count_feed_device': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_fasta': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_fasta_flatten': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
@@ -268,6 +269,18 @@ class Context(object):
     def synth_reads_device(self, seed, first_read, n_reads, read_len, dev_ptr, noisy=False):
         _check(self._L.kpal_synth_reads_device(self._h, int(seed), int(first_read), int(n_reads), int(read_len),
                                                int(bool(noisy)), _vp(dev_ptr)))
+
+    def count_records(self, k, flat, starts):
+        """One table per record of a flat byte stream: record r = flat[starts[r]:starts[r+1]]
+        (separator bytes between records) -> int64[n_records, 4**k]."""
+        a = np.frombuffer(flat, dtype=np.uint8) if not isinstance(flat, np.ndarray) else np.ascontiguousarray(flat, dtype=np.uint8)
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        n = st.size - 1
+        out = np.empty((max(n, 0), 4 ** k), dtype=np.int64)
+        if n > 0:
+            _check(self._L.kpal_count_records(self._h, int(k), a.ctypes.data if a.size else None, a.size, st.ctypes.data, n,
+                                              out.ctypes.data))
+        return out
 
     def count_bytes(self, k, buf, strategy='auto'):
         """Count one flat host byte stream -> int64[4**k]."""

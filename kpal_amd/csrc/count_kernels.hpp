@@ -39,6 +39,56 @@ __global__ __launch_bounds__(256) void count_global_atomic_kernel(Span s, uint64
 }
 
 // ------------------------------------------------------------------------------------------
+// Batched per-record counting (Profile.from_fasta_by_record, kpal/klib.py:114-133): the flat
+// stream holds many records, starts[r] = position of record r's first byte (ascending,
+// starts[R] = stream length; a separator byte lies between records).  Every k-mer is added to the
+// table of the record its LAST byte lies in -- windows never span a separator, so that is the
+// record that contains it.  Records are short (that is what the batch entry point is for): one
+// global atomic per k-mer into out[r * 4^k + kmer].
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void count_records_kernel(Span s, uint64_t steps_per_wave,
+                                                            const uint64_t *__restrict__ starts, uint32_t n_records,
+                                                            unsigned long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t step0 = wave * steps_per_wave;
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (step0 >= total_steps) return;
+    const uint64_t step1 = min(step0 + steps_per_wave, total_steps);
+    Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
+    for (uint64_t st = step0; st < step1; ++st) {
+        uint64_t window;
+        uint32_t mask;
+        if (interior_range(s, st * 64, st * 64 + 64)) wave_step<K, false>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+        else wave_step<K, true>(s, (int64_t)(st * 64 + lane), carry, window, mask);
+        if (mask == 0) continue;
+        // record of the lane's first byte: largest r with starts[r] <= position (positions are relative
+        // to the first fed byte, s.lo)
+        const uint64_t p0 = (st * 64 + lane) * 16;
+        const uint64_t rel0 = p0 >= s.lo ? p0 - s.lo : 0;
+        uint32_t lo = 0, hi = n_records;   // invariant: starts[lo] <= rel0 < starts[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (starts[mid] <= rel0) lo = mid;
+            else hi = mid;
+        }
+        uint32_t r = lo;
+        uint64_t next_start = starts[r + 1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t rel = rel0 + j;
+            while (rel >= next_start && r + 1 < n_records) {   // records shorter than a chunk: may advance more than once
+                ++r;
+                next_start = starts[r + 1];
+            }
+            if (mask & (1u << (15 - j))) atomicAdd(&out[((uint64_t)r << (2 * K)) + kmer_at<K>(window, j)], 1ULL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Strategy 2: LDS-direct histogram for k <= 7 (4^k <= 16384 bins).  R bank-interleaved
 // replicas (R*4^k*4 B = 64 KiB at most) so that for tiny k the 64 lanes of a wave do not
 // serialise on a handful of addresses: replica r = lane % R lives at dword bin*R + r.

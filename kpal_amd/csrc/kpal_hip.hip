@@ -876,6 +876,40 @@ KPAL_API int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t n
     return KPAL_OK;
 }
 
+KPAL_API int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
+                                size_t n_records, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    if (n_records == 0) return KPAL_OK;
+    if (!host_starts || !host_out || (nbytes && !host_flat)) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (n_records >= 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "too many records in one batch");
+    if (host_starts[0] != 0 || host_starts[n_records] != nbytes) return set_err(KPAL_E_INVALID, "starts must run from 0 to nbytes");
+    for (size_t r = 0; r < n_records; ++r)
+        if (host_starts[r] > host_starts[r + 1]) return set_err(KPAL_E_INVALID, "starts must be ascending");
+    const uint64_t bins = 1ULL << (2 * k);
+    const size_t out_bytes = n_records * bins * sizeof(int64_t);
+    CHK(ensure(ctx, ctx->scratch[0], out_bytes));
+    CHK(ensure(ctx, ctx->scratch[1], nbytes + 64));
+    CHK(ensure(ctx, ctx->scratch[2], (n_records + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(ctx->scratch[0].p, 0, out_bytes, ctx->stream));
+    if (nbytes) {
+        HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, host_flat, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, host_starts, (n_records + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        const Span s = make_span((const uint8_t *)ctx->scratch[1].p, nbytes, 0);
+        const uint64_t steps = (s.nchunks + 63) / 64;
+        const uint64_t max_waves = (uint64_t)ctx->num_cu * 8 * 4;
+        const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+        const uint64_t waves = (steps + spw - 1) / spw;
+        const unsigned grid = (unsigned)((waves + 3) / 4);
+        DISPATCH_K_1_16(k, LAUNCH(ctx, "count_records", (count_records_kernel<K>), dim3(grid), dim3(256), s, spw,
+                                  (const uint64_t *)ctx->scratch[2].p, (uint32_t)n_records, (unsigned long long *)ctx->scratch[0].p));
+    }
+    HIPCHK(hipMemcpyAsync(host_out, ctx->scratch[0].p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
 KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);

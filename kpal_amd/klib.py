@@ -27,6 +27,7 @@ from . import _native, metrics
 
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
 _JOIN_BLOCK = 4096       # sequences joined per C-level call
+_RECORD_BATCH_BYTES = 1 << 30   # tables downloaded per from_fasta_by_record batch
 _FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
 _WHITESPACE = {ord(c): None for c in ' \t\n\v\f\r'}
 
@@ -162,10 +163,42 @@ class Profile(object):
 
     @classmethod
     def from_fasta_by_record(cls, handle, length, prefix=None):
-        """One profile per FASTA record, named by record (kpal/klib.py:114-133)."""
+        """One profile per FASTA record, named by record (kpal/klib.py:114-133).
+
+        Records are counted in batches (``kpal_count_records``: one kernel launch and one table
+        download for up to ``_RECORD_BATCH_BYTES`` of tables) instead of one count per record; a
+        record whose table alone exceeds that budget falls back to ``from_sequences``."""
+        length = int(length)
+        if length < 1 or length > _native.KPAL_MAX_K:
+            raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         prefix = prefix + '_' if prefix else ''
+        table_bytes = 8 * 4 ** length
+        per_batch = _RECORD_BATCH_BYTES // table_bytes
+        if per_batch < 2:
+            for i, (record_name, seq) in enumerate(_fasta_records(handle)):
+                yield cls.from_sequences([seq], length, name=prefix + (record_name or str(i + 1)))
+            return
+        ctx = _native.context()
+        names, seqs, size = [], [], 0
+
+        def flush():
+            data = [_encode(s) for s in seqs]
+            starts = np.zeros(len(data) + 1, dtype=np.uint64)
+            starts[1:] = np.cumsum([len(d) + 1 for d in data])       # one separator after every record
+            tables = ctx.count_records(length, b''.join(d + b'\n' for d in data), starts)
+            return [cls(tables[j], name=names[j]) for j in range(len(data))]
+
         for i, (record_name, seq) in enumerate(_fasta_records(handle)):
-            yield cls.from_sequences([seq], length, name=prefix + (record_name or str(i + 1)))
+            names.append(prefix + (record_name or str(i + 1)))
+            seqs.append(seq)
+            size += len(seq) + 1
+            if len(seqs) >= per_batch or size >= _FEED_BYTES:
+                for profile in flush():
+                    yield profile
+                names, seqs, size = [], [], 0
+        if seqs:
+            for profile in flush():
+                yield profile
 
     @classmethod
     def from_sequences(cls, sequences, length, name=None):

@@ -108,3 +108,35 @@ def test_large_single_record(ctx):
     from kpal_amd import klib
     p = klib.Profile.from_fasta(io.BytesIO(text), 12)
     np.testing.assert_array_equal(p.counts, oracle.count_flat(seq, 12, threads=8))
+
+
+def test_from_fasta_by_record_batched(ctx, monkeypatch):
+    """One profile per record through the batched kernel (kpal/klib.py:114-133): counts vs the oracle
+    per record, names (record name, or the 1-based index for an empty title) and prefix; records
+    shorter than k, empty records and many records inside one 16-byte chunk."""
+    from kpal_amd import klib
+    rnd = random.Random(21)
+    text = '>r1 first\nACGTNACGT\n>\nAC\n>r3\n\n>r4\nA\n>r5\nC\n>r6\nGGGTTTAAACCC\n' + random_fasta(rnd, 300, 700)
+    recs = list(klib._fasta_records(io.StringIO(text)))
+    for k in (1, 3, 8, 12):
+        for batch in (1 << 30, 3 * 8 * 4 ** k):          # everything in a few batches / three records per batch
+            monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', batch)
+            profiles = list(klib.Profile.from_fasta_by_record(io.StringIO(text), k, prefix='p'))
+            assert len(profiles) == len(recs)
+            for i, (p, (name, seq)) in enumerate(zip(profiles, recs)):
+                assert p.name == 'p_' + (name or str(i + 1))
+                assert p.length == k
+                if i < 40 or i % 37 == 0:
+                    np.testing.assert_array_equal(p.counts, oracle.from_sequences([seq], k), err_msg='record %d k=%d' % (i, k))
+            total = sum(int(p.counts.sum()) for p in profiles)
+            assert total == sum(int(oracle.from_sequences([seq], k).sum()) for _, seq in recs)
+    # without a prefix, and the C-ABI directly with an empty record in the middle
+    first = next(klib.Profile.from_fasta_by_record(io.StringIO(text), 4))
+    assert first.name == 'r1'
+    flat = b'ACGTACGT\n\nTTTT\n'
+    t = ctx.count_records(2, flat, [0, 9, 10, 15])
+    np.testing.assert_array_equal(t[0], oracle.from_sequences(['ACGTACGT'], 2))
+    assert t[1].sum() == 0
+    np.testing.assert_array_equal(t[2], oracle.from_sequences(['TTTT'], 2))
+    with pytest.raises(ValueError):
+        ctx.count_records(2, flat, [0, 9, 8, 15])
