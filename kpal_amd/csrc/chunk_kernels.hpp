@@ -537,10 +537,14 @@ __device__ __forceinline__ void flush_row_slow_chunked(unsigned char *rb, uint32
     const uint4 line0 = *(const uint4 *)(rb + ((16u * piece + rot) & 255u));
     const uint4 line1 = *(const uint4 *)(rb + ((16u * (piece + 8) + rot) & 255u));
     if (L >= 1) {
-        const uint16_t *k = (const uint16_t *)&line0;
+        if (l0 == 0) {   // whole line 0 (it lies inside the current chunk)
+            *(uint4 *)(keys + base + 8 * piece) = line0;
+        } else {         // slots below lo left directly when the row overflowed
+            const uint16_t *k = (const uint16_t *)&line0;
 #pragma unroll
-        for (uint32_t e = 0; e < 8; ++e)
-            if (8 * piece + e >= l0) keys[base + 8 * piece + e] = k[e];     // line 0 lies inside the current chunk
+            for (uint32_t e = 0; e < 8; ++e)
+                if (8 * piece + e >= l0) keys[base + 8 * piece + e] = k[e];
+        }
         if (L >= 2) *(uint4 *)(keys + line_slot_index(base, next, 64 + 8 * piece)) = line1;
         if (L == 1 && 8 * piece < r) *(uint4 *)(rb + ((16u * piece + rot) & 255u)) = line1;   // leftover moves down
     }
