@@ -47,6 +47,21 @@ constexpr uint32_t kChunkIdBits = 20;                // chunk ids < 2^20: key in
 
 // All arrays carry a leading coarse-bucket dimension Y (1 for the one-level path; blockIdx.y
 // selects it), so chunk ids -- relative to the coarse bucket's part of the pool -- stay below 2^20.
+// Bucket scrambling.  A value v = (bucket : 9 bits | key : KB bits) is scattered into bucket
+// b' = bucket ^ g(top six bits of key): the three bases after the bucket prefix decide which of 64
+// different buckets a prefix maps to, so compositional skew (AT-rich genomes: bucket prefixes differ
+// threefold in frequency) is averaged over 64 buckets, while the bins of a scrambled bucket still
+// come in runs of 2^(KB-6) consecutive table entries (for a fixed key top the map is a bijection of
+// the buckets, so every workgroup of the histogram stage still owns its bins exclusively).
+__device__ __forceinline__ uint32_t chunk_bucket_mask(uint32_t key_top6) { return (key_top6 * 73u) & (uint32_t)(kNumBuckets - 1); }
+
+template <int KB>
+__device__ __forceinline__ uint32_t chunk_scramble(uint32_t v)
+{
+    static_assert(KB >= 6, "needs six key bits");
+    return v ^ (chunk_bucket_mask((v >> (KB - 6)) & 63u) << KB);
+}
+
 struct ChunkPool {
     uint16_t *keys;        // [Y][G * per_block chunks][kChunkKeys keys]
     uint32_t per_block;    // R: chunk ids of workgroup g are [g*R, (g+1)*R)
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
         for (int st = 0; st < kScatterSteps; ++st) {
             uint32_t v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = kmer_at<K>(window[st], j);
+            for (int j = 0; j < 16; ++j) v[j] = chunk_scramble<KB>(kmer_at<K>(window[st], j));
             smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, mask[st]));
         }
         if (smax >= kChunkKeys) tile_over = 1;   // benign race: every writer stores 1
@@ -416,6 +431,8 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_key_scatter_kernel(c
         for (int st = 0; st < kScatterSteps; ++st) {
             uint32_t v[16], valid;
             load_macro(res, lo, n, w0 + t + (uint64_t)st * kMacroKeys, v, valid);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = chunk_scramble<KB>(v[j]);
             smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, valid));
         }
         if (smax >= kChunkKeys) tile_over = 1;
@@ -646,6 +663,8 @@ __global__ __launch_bounds__(kLineThreads) void chunk_key_lines_kernel(const uin
         if (b0 + t >= n) break;  // block-uniform: wave 0 owns the lowest residuals (also skips empty workgroups)
         uint32_t v[16], valid;
         load_macro(res, lo, n, w0 + t, v, valid);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = chunk_scramble<kResKeyBits>(v[j]);
         if (place16_lines_chunked<kResKeyBits>(rows, pos, gl, nextc, keys, v, valid) >= kChunkKeys) tile_over = 1;
         lds_barrier();
         if (tile_over) {   // block-uniform, pathological input only: forget the tile, count it after the loop
@@ -855,16 +874,17 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(ChunkPool p, const uin
     walk(osorted + region + ostart[b], ostart[b + 1] - ostart[b]);
     if (have) consume();
     __syncthreads();
-    unsigned long long *dst = table + ((uint64_t)blockIdx.y << (kPartBits + KB)) + ((uint64_t)b << KB);
+    // bin i of scrambled bucket b is table entry (b ^ g(i's top six bits)) << KB | i: runs of 2^(KB-6) bins
+    unsigned long long *dst = table + ((uint64_t)blockIdx.y << (kPartBits + KB));
     if (slices == 1) {
         for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
             const uint32_t c = hist[i];
-            if (c) dst[i] += (unsigned long long)c;
+            if (c) dst[((uint64_t)(b ^ chunk_bucket_mask((uint32_t)i >> (KB - 6))) << KB) + i] += (unsigned long long)c;
         }
     } else {
         for (int i = threadIdx.x; i < BINS; i += blockDim.x) {
             const uint32_t c = hist[i];
-            if (c) atomicAdd(&dst[i], (unsigned long long)c);
+            if (c) atomicAdd(&dst[((uint64_t)(b ^ chunk_bucket_mask((uint32_t)i >> (KB - 6))) << KB) + i], (unsigned long long)c);
         }
     }
 }
