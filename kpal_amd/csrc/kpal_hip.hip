@@ -91,7 +91,7 @@ struct kpal_ctx {
     ChunkPool *chunk_pool_dev = nullptr;
     uint32_t chunk_meta_y = 0;               // coarse-bucket count the meta layout was cleared for
     uint32_t *chunk_error_word = nullptr;
-    DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..15)
+    DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..16)
     DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;

@@ -2,16 +2,18 @@
 //
 // k = 8..12 (one level).  A k-mer's 2k bits split into a 9-bit BUCKET (top) and a KB = 2k-9 bit
 // KEY.  Keys are scattered bucket-major into a u16 array, then each bucket's <= 2^15 bins are
-// histogrammed in LDS and merged into the int64 table:
+// histogrammed in LDS and merged into the int64 table.  This file holds the EXACT-OFFSET pipeline
+// (KPAL_STRATEGY_PARTITION); the default for these k is the one-pass chunked pipeline of
+// chunk_kernels.hpp, which reuses the staging and the histogram design from here:
 //     A1 part_count      per-(bucket, block) counts          reads the input
 //     A2 rowscan+bucketscan  exact, deterministic offsets
 //     A3 part_scatter    keys -> bucket runs                 reads the input, writes 2 B per k-mer
 //     B  part_hist       LDS histogram per bucket            reads 2 B per k-mer
-// k = 13..15 (two levels).  The top 2k-24 bits select one of 4/16/64 COARSE buckets; the 24-bit
-// residual is exactly a k=12 k-mer, so after a coarse count/scan/scatter into u32 residuals
-// (C1..C3) every coarse bucket runs the one-level pipeline on its residual stream (key_count,
-// scans, key_scatter, part_hist) -- all coarse buckets in one 2-D launch per stage, with
-// device-side sizes, so there is no host synchronisation inside a batch.
+// k = 13..16 (two levels).  The top 2k-24 bits select one of 4/16/64/256 COARSE buckets; the
+// 24-bit residual is exactly a k=12 k-mer, so after a coarse count/scan/scatter into u32 residuals
+// (C1..C3) every coarse bucket runs a one-level pipeline on its residual stream -- by default the
+// chunked aligned-line scatter of chunk_kernels.hpp, optionally (KPAL_LEVEL2=0) key_count, scans,
+// key_scatter, part_hist from this file -- all coarse buckets in one 2-D launch per stage.
 //
 // Everything is integer and order-independent: every k-mer gets a unique slot from a returning
 // atomic, count and scatter kernels share one block->range mapping, so results are bit-exact.
@@ -127,7 +129,7 @@ __device__ __forceinline__ void copy_out_tile(const unsigned char *rows, uint32_
 // ------------------------------------------------------------------------------------------
 // A1: per-(bucket, block) key counts of an ASCII span.  cntmat is bucket-major: cntmat[b*G + blk].
 // Block `blk` owns steps [blk*SPB, (blk+1)*SPB); wave w streams the w-th eighth of it, carrying its
-// left-neighbour chunk in registers.  The 512 counters are kept in 32 bank-interleaved replicas
+// left-neighbour chunk in registers.  The 512 counters are kept in 16 bank-interleaved replicas
 // (replica = lane % 16), so a wave's 64 ds_add_u32 rarely conflict;
 // a k-mer that must not be counted adds 0 (branch-free).
 // ------------------------------------------------------------------------------------------
