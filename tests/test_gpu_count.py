@@ -224,6 +224,31 @@ def test_two_level_variants_of_level2(mode):
     c2.close()
 
 
+def test_mixed_feeds_in_one_count(ctx):
+    """Host, device and FASTA feeds of very different sizes inside one begin/finish (AUTO switches
+    between the atomic kernel for tiny feeds and the partition pipelines): the table is the sum."""
+    buf = oracle.synth_reads(61, 0, 40000, 150, noisy=True)
+    pieces = [buf[:10], buf[10:1000], buf[1000:300000], buf[300000:300001], buf[300001:]]
+    fasta = b'>x\nACGTACGTACGTAAAC\nGGGTTT\n>y\nNNNN\nACGTTGCAACGTTGCA\n'
+    fasta_seqs = ['ACGTACGTACGTAAACGGGTTT', 'NNNNACGTTGCAACGTTGCA']
+    for k in (9, 12, 13):
+        ctx.count_begin(k)
+        want = np.zeros(4 ** k, dtype=np.int64)
+        for i, piece in enumerate(pieces):
+            if i % 2:
+                d = ctx.alloc(max(piece.size, 16))
+                ctx.h2d(d, piece)
+                ctx.count_feed_device(d, piece.size)
+                ctx.sync()
+                ctx.free(d)
+            else:
+                ctx.count_feed(piece)
+            want += oracle.count_flat(piece, k)
+        ctx.count_feed_fasta(fasta)
+        want += oracle.from_sequences(fasta_seqs, k)
+        np.testing.assert_array_equal(ctx.count_finish(), want)
+
+
 def test_small_partition_batches():
     """Partition path with 1 MiB batches: halo across batch seams inside one device feed."""
     from kpal_amd import _native
