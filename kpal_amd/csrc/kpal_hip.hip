@@ -638,13 +638,19 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         // ones empty, so the granularity is doubled (AT-rich 1 GiB: 3.1 -> 2.2 ms)
         const uint64_t total1 = h1[NB1] - h1[0];
         const bool unequal = (double)maxn * NB1 > 1.25 * (double)total1;
-        const uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * (lines ? (unequal ? 16 : 8) : 2) / NB1);
+        uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * (lines ? (unequal ? 16 : 8) : 2) / NB1);
         const uint64_t quantum = lines ? (uint64_t)kKeysPerBlockQuantum : (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;
-        uint64_t kpb2 = (maxn + g2t - 1) / g2t;
-        kpb2 = (kpb2 + quantum - 1) / quantum * quantum;
-        if (kpb2 > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
-        const uint32_t G2c = (uint32_t)((maxn + kpb2 - 1) / kpb2);
-        const uint64_t R2 = kpb2 / kChunkKeys + 2 * kNumBuckets + 64;
+        uint64_t kpb2 = 0, R2 = 0;
+        uint32_t G2c = 0;
+        for (;; g2t = (g2t + 1) / 2) {   // few coarse buckets (k = 13): keep a coarse bucket's chunk ids below 2^20
+            kpb2 = (maxn + g2t - 1) / g2t;
+            kpb2 = (kpb2 + quantum - 1) / quantum * quantum;
+            if (kpb2 > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
+            G2c = (uint32_t)((maxn + kpb2 - 1) / kpb2);
+            R2 = kpb2 / kChunkKeys + 2 * kNumBuckets + 64;
+            if ((uint64_t)G2c * R2 < (1ull << kChunkIdBits) || g2t <= 2) break;
+        }
+        if ((uint64_t)G2c * R2 >= (1ull << kChunkIdBits) && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // one coarse bucket holds (almost) everything
         ChunkLaunch cl;
         const int rc = chunk_prepare(ctx, (uint32_t)NB1, G2c, R2, cl);
         if (rc == KPAL_E_NOMEM && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // retry with half the batch

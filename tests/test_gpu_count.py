@@ -224,6 +224,24 @@ def test_two_level_variants_of_level2(mode):
     c2.close()
 
 
+def test_chunk_overflow_lists(ctx):
+    """A steadily hot bucket (70 % A: one scrambled bucket still receives ~6 % of all k-mers, ~1600 per
+    tile -- no tile is abandoned) makes workgroups retire far more than the four chunks a table row
+    holds: the overflow list, its grouping kernel and the slicing of the histogram stage."""
+    rs = np.random.RandomState(91)
+    n = 384 << 20
+    buf = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=n, p=[.7, .1, .1, .1])]
+    d = ctx.alloc(n)       # one device feed: a workgroup's share must be large enough to fill many chunks
+    try:
+        ctx.h2d(d, buf)
+        for k, strat in ((12, 'auto'), (13, 'auto'), (12, 'partition')):
+            ctx.count_begin(k, strat)
+            ctx.count_feed_device(d, n)
+            np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(buf, k, threads=32), err_msg='k=%d %s' % (k, strat))
+    finally:
+        ctx.free(d)
+
+
 def test_mixed_feeds_in_one_count(ctx):
     """Host, device and FASTA feeds of very different sizes inside one begin/finish (AUTO switches
     between the atomic kernel for tiny feeds and the partition pipelines): the table is the sum."""
