@@ -639,6 +639,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
         const uint64_t total1 = h1[NB1] - h1[0];
         const bool unequal = (double)maxn * NB1 > 1.25 * (double)total1;
         uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * (lines ? (unequal ? 16 : 8) : 2) / NB1);
+        g2t = std::min<uint64_t>(g2t, std::max<uint64_t>(2, 4096 / NB1));   // every workgroup reserves ~1000 chunks (9 MB) of pool address space
         const uint64_t quantum = lines ? (uint64_t)kKeysPerBlockQuantum : (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;
         uint64_t kpb2 = 0, R2 = 0;
         uint32_t G2c = 0;
