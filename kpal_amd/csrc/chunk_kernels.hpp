@@ -48,12 +48,18 @@ constexpr uint32_t kChunkIdBits = 20;                // chunk ids < 2^20: key in
 // All arrays carry a leading coarse-bucket dimension Y (1 for the one-level path; blockIdx.y
 // selects it), so chunk ids -- relative to the coarse bucket's part of the pool -- stay below 2^20.
 // Bucket scrambling.  A value v = (bucket : 9 bits | key : KB bits) is scattered into bucket
-// b' = bucket ^ g(top six bits of key): the three bases after the bucket prefix decide which of 64
+// b' = bucket ^ g(top six bits of key), g(t) = t << 3 | t: the three bases after the bucket prefix decide which of 64
 // different buckets a prefix maps to, so compositional skew (AT-rich genomes: bucket prefixes differ
 // threefold in frequency) is averaged over 64 buckets, while the bins of a scrambled bucket still
 // come in runs of 2^(KB-6) consecutive table entries (for a fixed key top the map is a bijection of
 // the buckets, so every workgroup of the histogram stage still owns its bins exclusively).
-__device__ __forceinline__ uint32_t chunk_bucket_mask(uint32_t key_top6) { return (key_top6 * 73u) & (uint32_t)(kNumBuckets - 1); }
+#if defined(KPAL_NO_SCRAMBLE)   // A/B builds only
+__device__ __forceinline__ uint32_t chunk_bucket_mask(uint32_t) { return 0u; }
+#elif defined(KPAL_SCRAMBLE_MUL)
+__device__ __forceinline__ uint32_t chunk_bucket_mask(uint32_t key_top6) { return (key_top6 * 73u) & 511u; }
+#else
+__device__ __forceinline__ uint32_t chunk_bucket_mask(uint32_t key_top6) { return (key_top6 << 3) | key_top6; }   // 64 distinct 9-bit masks, one v_lshl_or
+#endif
 
 template <int KB>
 __device__ __forceinline__ uint32_t chunk_scramble(uint32_t v)
