@@ -51,7 +51,7 @@ extern "C" {
 
 /* counting strategies (kpal_count_set_strategy) */
 #define KPAL_STRATEGY_AUTO 0
-#define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k (reference implementation, never AUTO) */
+#define KPAL_STRATEGY_GLOBAL_ATOMIC 1 /* one 64-bit global atomic per k-mer; any k (AUTO only for feeds <= 256 KiB; cross-check of the other pipelines) */
 #define KPAL_STRATEGY_LDS_DIRECT 2    /* whole 4^k table privatised in LDS; k <= 7 */
 #define KPAL_STRATEGY_PARTITION 3     /* exact-offset radix partition (count, scan, scatter, histogram); 8 <= k <= 12 */
 #define KPAL_STRATEGY_PARTITION_CHUNKED 5 /* one-pass partition into chunked bucket lists (no counting pass); 8 <= k <= 12; AUTO */
