@@ -589,7 +589,7 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
     const int NB1 = 1 << (2 * ctx->k - kResidualBits);
-    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 8;   // measured: coarse_count 8 % faster than with 4 per CU, coarse_scatter indifferent
     uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
     spb = (spb + 7) / 8 * 8;   // 8 waves, one step per wave per tile
     const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
