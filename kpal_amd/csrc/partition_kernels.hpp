@@ -620,11 +620,12 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
     const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
     Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
     const uint32_t myrep = lane & (REP - 1);
+    uint4 raw = fetch_chunk(s, (int64_t)(step0 * 64 + lane));   // fetched one tile ahead: the load flies during the copy-out
     for (uint64_t t = 0; t < steps_per_wave; ++t) {
         if (block_step0 + t >= total_steps) break;  // block-uniform
         uint64_t window;
         uint32_t mask;
-        part_step<K>(s, step0 + t, carry, window, mask);
+        encode_step<K>(s, step0 + t, raw, carry, window, mask);
         uint32_t slot[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(kCoarseThreads) void coarse_scatter_kernel(Span s, 
         }
         if (smax >= (uint32_t)CAP) overflowed = 1;   // benign race: every writer stores 1
         __syncthreads();
+        if (t + 1 < steps_per_wave) raw = fetch_chunk(s, (int64_t)((step0 + t + 1) * 64 + lane));
         const uint32_t any_overflow = overflowed;            // stable until the barrier below
         // wave w owns virtual rows [RPW*w, RPW*w + RPW) = whole buckets; lanes 0..RPW-1 turn counts into positions
         {
