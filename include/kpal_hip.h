@@ -162,6 +162,39 @@ int kpal_dynamic_smooth(kpal_ctx *ctx, int k, int64_t *host_left_inout, int64_t 
 int kpal_profile_distance_matrix(kpal_ctx *ctx, int P, int k, const int64_t *const *host_profiles,
                                  const kpal_distance_options *opt, double *out_lower);
 
+/* ---- profile summaries, merge, shrink ---- */
+/* Profile.total / non_zero / mean / median / std (kpal/klib.py:193-225) of one int64 vector in two
+ * streaming passes plus a radix select for the median.  total wraps like ndarray.sum(); mean and std
+ * follow NumPy's float64 formulation (an exact 128-bit sum, then sum((x - mean)^2) / n), <= 1e-9
+ * relative; median, min and max are exact. */
+typedef struct kpal_profile_stats {
+    int64_t total;     /* counts.sum(), int64 wrap */
+    int64_t non_zero;  /* np.count_nonzero(counts) */
+    int64_t min, max;
+    double mean;       /* counts.mean() */
+    double median;     /* np.median(counts): mean of the two middle elements for even n */
+    double std;        /* counts.std(), population standard deviation */
+} kpal_profile_stats;
+int kpal_stats(kpal_ctx *ctx, size_t n, const int64_t *host_counts, kpal_profile_stats *out);
+int kpal_stats_device(kpal_ctx *ctx, size_t n, const int64_t *dev_counts, kpal_profile_stats *out);
+
+/* Profile.merge(profile, merger) for the built-in metrics.mergers (kpal/metrics.py:174-179,
+ * kpal/klib.py:269-283): out = merger(left, right); out may be left or right. */
+#define KPAL_MERGE_SUM 0   /* x + y */
+#define KPAL_MERGE_XOR 1   /* (x + y) * logical_xor(x, y) */
+#define KPAL_MERGE_INT 2   /* x * bool(y) */
+#define KPAL_MERGE_NINT 3  /* x * logical_not(y) */
+int kpal_merge(kpal_ctx *ctx, size_t n, const int64_t *host_left, const int64_t *host_right, int merger,
+               int64_t *host_out);
+int kpal_merge_device(kpal_ctx *ctx, size_t n, const int64_t *dev_left, const int64_t *dev_right, int merger,
+                      int64_t *dev_out);
+
+/* Profile.shrink(factor), kpal/klib.py:329-352: out[j] = sum of the 4^factor counts that share the
+ * (k - factor)-mer prefix j; 1 <= factor < k (else KPAL_E_INVALID, the reference's ValueError);
+ * out has 4^(k - factor) entries and must not overlap the input. */
+int kpal_shrink(kpal_ctx *ctx, int k, int factor, const int64_t *host_counts, int64_t *host_out);
+int kpal_shrink_device(kpal_ctx *ctx, int k, int factor, const int64_t *dev_counts, int64_t *dev_out);
+
 /* ---- per-kernel timing with HIP events on the ctx stream (bench.py roofline leg) ---- */
 int kpal_prof_enable(kpal_ctx *ctx, int on);
 int kpal_prof_reset(kpal_ctx *ctx);

@@ -37,6 +37,17 @@ class DistanceOptions(ctypes.Structure):
 
 _optp = ctypes.POINTER(DistanceOptions)
 
+
+class ProfileStats(ctypes.Structure):
+    """``kpal_profile_stats`` of include/kpal_hip.h (kpal/klib.py:193-225)."""
+    _fields_ = [('total', ctypes.c_int64), ('non_zero', ctypes.c_int64), ('min', ctypes.c_int64),
+                ('max', ctypes.c_int64), ('mean', ctypes.c_double), ('median', ctypes.c_double),
+                ('std', ctypes.c_double)]
+
+
+_statp = ctypes.POINTER(ProfileStats)
+MERGE_SUM, MERGE_XOR, MERGE_INT, MERGE_NINT = 0, 1, 2, 3
+
 # name -> (restype, argtypes); one entry per symbol declared in include/kpal_hip.h
 SIGNATURES = {
     'kpal_last_error': (ctypes.c_char_p, []),
@@ -79,6 +90,12 @@ SIGNATURES = {
     'kpal_dynamic_smooth': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_double]),
     'kpal_profile_distance_matrix': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp), _optp,
                                                     _f64p]),
+    'kpal_stats': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _statp]),
+    'kpal_stats_device': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _statp]),
+    'kpal_merge': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, ctypes.c_int, _vp]),
+    'kpal_merge_device': (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, ctypes.c_int, _vp]),
+    'kpal_shrink': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'kpal_shrink_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'kpal_prof_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_prof_reset': (ctypes.c_int, [_vp]),
     'kpal_prof_count': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
@@ -380,6 +397,38 @@ class Context(object):
         """In place on two writable contiguous int64 vectors (kdistlib.py:112-124)."""
         _check(self._L.kpal_dynamic_smooth(self._h, int(k), left.ctypes.data, right.ctypes.data, int(summary),
                                            float(threshold)))
+
+    def stats(self, counts):
+        """total / non_zero / min / max / mean / median / std of an int64 vector (klib.py:193-225)."""
+        c = _as_i64(counts)
+        out = ProfileStats()
+        _check(self._L.kpal_stats(self._h, c.size, c.ctypes.data, ctypes.byref(out)))
+        return out
+
+    def stats_device(self, dev_counts, n):
+        out = ProfileStats()
+        _check(self._L.kpal_stats_device(self._h, int(n), dev_counts, ctypes.byref(out)))
+        return out
+
+    def merge(self, left, right, merger):
+        """metrics.mergers[...](left, right) on int64 vectors (metrics.py:174-179) -> new array."""
+        l, r = _as_i64(left), _as_i64(right)
+        if l.size != r.size:
+            raise ValueError('vectors differ in length: %d != %d' % (l.size, r.size))
+        out = np.empty(l.size, dtype=np.int64)
+        _check(self._L.kpal_merge(self._h, l.size, l.ctypes.data, r.ctypes.data, int(merger), out.ctypes.data))
+        return out
+
+    def shrink(self, counts, k, factor):
+        """Sums of 4**factor consecutive counts (klib.py:329-352) -> new array of 4**(k-factor)."""
+        c = _as_i64(counts)
+        if c.size != 4 ** k:
+            raise ValueError('profile length %d != 4**%d' % (c.size, k))
+        if not 1 <= factor < k:
+            raise ValueError('Reduction factor should be smaller than k-mer size.')
+        out = np.empty(4 ** (k - factor), dtype=np.int64)
+        _check(self._L.kpal_shrink(self._h, int(k), int(factor), c.ctypes.data, out.ctypes.data))
+        return out
 
     def profile_distance_matrix(self, profiles, k, options):
         arrs = [_as_i64(p) for p in profiles]

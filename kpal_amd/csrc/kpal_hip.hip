@@ -20,6 +20,7 @@
 #include "fasta_kernels.hpp"
 #include "vec_kernels.hpp"
 #include "option_kernels.hpp"
+#include "stat_kernels.hpp"
 
 #define KPAL_API extern "C" __attribute__((visibility("default")))
 
@@ -1434,6 +1435,176 @@ KPAL_API int kpal_profile_distance_matrix(kpal_ctx *ctx, int P, int k, const int
         for (int j = 0; j < i; ++j)
             CHK(profile_distance_pair(ctx, k, prof + (uint64_t)i * n, prof + (uint64_t)j * n, opt, true,
                                       &out_lower[(size_t)i * (i - 1) / 2 + j]));
+    return KPAL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// profile summaries, merge, shrink (stat_kernels.hpp)
+// ----------------------------------------------------------------------------------------------
+KPAL_API int kpal_stats_device(kpal_ctx *ctx, size_t n, const int64_t *dev_counts, kpal_profile_stats *out)
+{
+    CTX_ENTER(ctx);
+    if (!dev_counts || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (n == 0) return set_err(KPAL_E_INVALID, "empty vector");
+    const unsigned grid = stream_grid(ctx, n, kStatThreads);
+    CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(StatPartial) + 256 * 8));
+    StatPartial *dp = (StatPartial *)ctx->partials.p;
+    LAUNCH(ctx, "stats", stats_kernel, dim3(grid), dim3(kStatThreads), dev_counts, (uint64_t)n, dp);
+    std::vector<StatPartial> hp(grid);
+    HIPCHK(hipMemcpyAsync(hp.data(), dp, (size_t)grid * sizeof(StatPartial), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    StatPartial t = hp[0];
+    for (unsigned b = 1; b < grid; ++b) {
+        const uint64_t lo = t.sum_lo + hp[b].sum_lo;
+        t.sum_hi += hp[b].sum_hi + (lo < t.sum_lo ? 1 : 0);
+        t.sum_lo = lo;
+        t.non_zero += hp[b].non_zero;
+        t.mn = std::min(t.mn, hp[b].mn);
+        t.mx = std::max(t.mx, hp[b].mx);
+    }
+    out->total = (int64_t)t.sum_lo;
+    out->non_zero = (int64_t)t.non_zero;
+    out->min = t.mn;
+    out->max = t.mx;
+    // the 128-bit sum as a double: magnitude first, so that a small negative sum does not cancel
+    uint64_t mag_lo = t.sum_lo, mag_hi = (uint64_t)t.sum_hi;
+    const bool negative = t.sum_hi < 0;
+    if (negative) {
+        mag_lo = ~mag_lo + 1ULL;
+        mag_hi = ~mag_hi + (mag_lo == 0 ? 1ULL : 0ULL);
+    }
+    const double magnitude = std::ldexp((double)mag_hi, 64) + (double)mag_lo;
+    const double exact_sum = negative ? -magnitude : magnitude;
+    out->mean = exact_sum / (double)n;
+    // std: sum((x - mean)^2) / n, kpal/klib.py:220-225 (ndarray.std)
+    double *dv = (double *)ctx->partials.p;
+    LAUNCH(ctx, "stats_var", stats_var_kernel, dim3(grid), dim3(kStatThreads), dev_counts, (uint64_t)n, out->mean, dv);
+    std::vector<double> hv(grid);
+    HIPCHK(hipMemcpyAsync(hv.data(), dv, (size_t)grid * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ss = 0.0;
+    for (unsigned b = 0; b < grid; ++b) ss += hv[b];
+    out->std = std::sqrt(ss / (double)n);
+    // median: radix select of rank (n-1)/2 over the bytes in which min and max differ
+    const uint64_t r0 = (n - 1) / 2, r1 = n / 2;
+    if (t.mn == t.mx) {
+        out->median = (double)t.mn;
+        return KPAL_OK;
+    }
+    const uint64_t kmin = select_key(t.mn), kmax = select_key(t.mx);
+    int top = 7;
+    while (((kmin >> (8 * top)) & 255u) == ((kmax >> (8 * top)) & 255u)) --top;   // kmin != kmax: terminates at >= 0
+    uint64_t mask = top == 7 ? 0ULL : ~0ULL << (8 * (top + 1));
+    uint64_t prefix = kmin & mask;
+    uint64_t below = 0, equal = 0;      // elements with key < / == the digits chosen so far
+    unsigned long long *dh = (unsigned long long *)ctx->partials.p;
+    unsigned long long hh[256];
+    for (int byte = top; byte >= 0; --byte) {
+        HIPCHK(hipMemsetAsync(dh, 0, 256 * 8, ctx->stream));
+        LAUNCH(ctx, "select_hist", select_hist_kernel, dim3(grid), dim3(kStatThreads), dev_counts, (uint64_t)n, mask, prefix,
+               8 * byte, dh);
+        HIPCHK(hipMemcpyAsync(hh, dh, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        int d = 0;
+        uint64_t acc = below;
+        for (; d < 256; ++d) {
+            if (r0 < acc + hh[d]) break;
+            acc += hh[d];
+        }
+        if (d == 256) return set_err(KPAL_E_HIP, "median: rank %llu not found", (unsigned long long)r0);
+        below = acc;
+        equal = hh[d];
+        prefix |= (uint64_t)d << (8 * byte);
+        mask |= 255ULL << (8 * byte);
+    }
+    const int64_t v0 = (int64_t)(prefix ^ 0x8000000000000000ULL);
+    int64_t v1 = v0;
+    if (r1 >= below + equal) {   // the upper middle element is the next larger value
+        LAUNCH(ctx, "select_next", select_next_kernel, dim3(grid), dim3(kStatThreads), dev_counts, (uint64_t)n, prefix, dh);
+        std::vector<unsigned long long> hm(grid);
+        HIPCHK(hipMemcpyAsync(hm.data(), dh, (size_t)grid * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        unsigned long long m = ~0ULL;
+        for (unsigned b = 0; b < grid; ++b) m = std::min(m, hm[b]);
+        v1 = (int64_t)(m ^ 0x8000000000000000ULL);
+    }
+    out->median = ((double)v0 + (double)v1) / 2.0;   // np.median: mean of the two middle elements
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_stats(kpal_ctx *ctx, size_t n, const int64_t *host_counts, kpal_profile_stats *out)
+{
+    CTX_ENTER(ctx);
+    if (!host_counts || !out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (n == 0) return set_err(KPAL_E_INVALID, "empty vector");
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_counts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    return kpal_stats_device(ctx, n, (const int64_t *)ctx->scratch[0].p, out);
+}
+
+KPAL_API int kpal_merge_device(kpal_ctx *ctx, size_t n, const int64_t *dev_left, const int64_t *dev_right, int merger,
+                               int64_t *dev_out)
+{
+    CTX_ENTER(ctx);
+    if (!dev_left || !dev_right || !dev_out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (merger < KPAL_MERGE_SUM || merger > KPAL_MERGE_NINT) return set_err(KPAL_E_INVALID, "unknown merger %d", merger);
+    if (n == 0) return KPAL_OK;
+    const unsigned grid = stream_grid(ctx, n);
+    switch (merger) {
+    case KPAL_MERGE_SUM: LAUNCH(ctx, "merge", (merge_kernel<0>), dim3(grid), dim3(256), dev_left, dev_right, (uint64_t)n, dev_out); break;
+    case KPAL_MERGE_XOR: LAUNCH(ctx, "merge", (merge_kernel<1>), dim3(grid), dim3(256), dev_left, dev_right, (uint64_t)n, dev_out); break;
+    case KPAL_MERGE_INT: LAUNCH(ctx, "merge", (merge_kernel<2>), dim3(grid), dim3(256), dev_left, dev_right, (uint64_t)n, dev_out); break;
+    default: LAUNCH(ctx, "merge", (merge_kernel<3>), dim3(grid), dim3(256), dev_left, dev_right, (uint64_t)n, dev_out); break;
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_merge(kpal_ctx *ctx, size_t n, const int64_t *host_left, const int64_t *host_right, int merger,
+                        int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (!host_left || !host_right || !host_out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (merger < KPAL_MERGE_SUM || merger > KPAL_MERGE_NINT) return set_err(KPAL_E_INVALID, "unknown merger %d", merger);
+    if (n == 0) return KPAL_OK;
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], n * 8));
+    int64_t *dl = (int64_t *)ctx->scratch[0].p, *dr = (int64_t *)ctx->scratch[1].p;
+    HIPCHK(hipMemcpyAsync(dl, host_left, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dr, host_right, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CHK(kpal_merge_device(ctx, n, dl, dr, merger, dl));
+    HIPCHK(hipMemcpyAsync(host_out, dl, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_shrink_device(kpal_ctx *ctx, int k, int factor, const int64_t *dev_counts, int64_t *dev_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (factor < 1 || factor >= k) return set_err(KPAL_E_INVALID, "Reduction factor should be smaller than k-mer size.");
+    if (!dev_counts || !dev_out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const uint64_t n = 1ULL << (2 * k), m = 1ULL << (2 * factor), n_out = n / m;
+    if (m <= 64) {
+        LAUNCH(ctx, "shrink", shrink_small_kernel, dim3(stream_grid(ctx, n / 2)), dim3(256), dev_counts, n / 2, (int)(m / 2), dev_out);
+    } else {
+        LAUNCH(ctx, "shrink", shrink_large_kernel, dim3(stream_grid(ctx, n_out * 64)), dim3(256), dev_counts, n_out, m, dev_out);
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_shrink(kpal_ctx *ctx, int k, int factor, const int64_t *host_counts, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
+    if (factor < 1 || factor >= k) return set_err(KPAL_E_INVALID, "Reduction factor should be smaller than k-mer size.");
+    if (!host_counts || !host_out) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const uint64_t n = 1ULL << (2 * k), n_out = n >> (2 * factor);
+    CHK(ensure(ctx, ctx->scratch[0], n * 8));
+    CHK(ensure(ctx, ctx->scratch[1], n_out * 8));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[0].p, host_counts, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    CHK(kpal_shrink_device(ctx, k, factor, (const int64_t *)ctx->scratch[0].p, (int64_t *)ctx->scratch[1].p));
+    HIPCHK(hipMemcpyAsync(host_out, ctx->scratch[1].p, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return KPAL_OK;
 }
 

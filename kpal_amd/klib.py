@@ -253,17 +253,31 @@ class Profile(object):
     def total(self):
         return self.counts.sum()
 
+    def _device_stats(self):
+        """``kpal_stats`` over integer counts (one upload, two streaming passes and a radix select),
+        or None when the counts are not integers (scaled profiles keep NumPy's float formulation)."""
+        c = np.asanyarray(self.counts)
+        if c.dtype.kind not in 'iub' or c.ndim != 1 or c.size == 0:
+            return None
+        return _native.context().stats(c)
+
     @property
     def mean(self):
-        return self.counts.mean()
+        """Mean count (kpal/klib.py:206-211)."""
+        s = self._device_stats()
+        return self.counts.mean() if s is None else np.float64(s.mean)
 
     @property
     def median(self):
-        return np.median(self.counts)
+        """Median count (kpal/klib.py:213-218), exact: radix select on the device."""
+        s = self._device_stats()
+        return np.median(self.counts) if s is None else np.float64(s.median)
 
     @property
     def std(self):
-        return self.counts.std()
+        """Population standard deviation of the counts (kpal/klib.py:220-225)."""
+        s = self._device_stats()
+        return self.counts.std() if s is None else np.float64(s.std)
 
     # ---- I/O -------------------------------------------------------------------------------
     def save(self, handle, name=None):
@@ -273,8 +287,15 @@ class Profile(object):
             raise ValueError('Profile name may not contain / or . characters.')
         name = name or self.name or next(str(n) for n in itertools.count(1) if str(n) not in handle['profiles'])
         dataset = handle.create_dataset('profiles/' + name, data=self.counts, dtype='int64', compression='gzip')
-        for key in ('length', 'total', 'non_zero', 'mean', 'median', 'std'):
-            dataset.attrs[key] = getattr(self, key)
+        s = self._device_stats()      # all five summaries from one pass over the counts
+        if s is None:
+            attrs = dict((key, getattr(self, key)) for key in ('total', 'non_zero', 'mean', 'median', 'std'))
+        else:
+            attrs = {'total': np.int64(s.total), 'non_zero': int(s.non_zero), 'mean': np.float64(s.mean),
+                     'median': np.float64(s.median), 'std': np.float64(s.std)}
+        dataset.attrs['length'] = self.length
+        for key in ('total', 'non_zero', 'mean', 'median', 'std'):
+            dataset.attrs[key] = attrs[key]
         handle.flush()
         return name
 
@@ -284,7 +305,12 @@ class Profile(object):
 
     def merge(self, profile, merger=metrics.mergers['sum']):
         """Merge another profile into this one with a vectorised merger (kpal/klib.py:269-283)."""
-        self.counts = merger(self.counts, profile.counts)
+        code = metrics.merger_code(merger)
+        l, r = np.asanyarray(self.counts), np.asanyarray(profile.counts)
+        if code is not None and l.dtype.kind in 'iub' and r.dtype.kind in 'iub' and l.shape == r.shape and l.ndim == 1:
+            self.counts = _native.context().merge(l, r, code)     # built-in merger: one HIP kernel
+        else:
+            self.counts = merger(self.counts, profile.counts)     # user callable / float profiles: as the reference
 
     # ---- hot path: balance / split ------------------------------------------------------------
     def _int64_counts(self):
@@ -309,13 +335,21 @@ class Profile(object):
         (kpal/klib.py:300-327) -- ``kpal_split``."""
         return _native.context().split(self._int64_counts(), self.length)
 
-    # ---- container helpers (NumPy; not on the hot path) ------------------------------------------
+    # ---- container helpers ----------------------------------------------------------------------
     def shrink(self, factor=1):
         """Reduce k by ``factor`` by summing groups of ``4**factor`` bins (kpal/klib.py:329-352)."""
         if self.length <= factor:
             raise ValueError('Reduction factor should be smaller than k-mer size.')
-        group = 4 ** factor
-        self.counts = np.asarray(self.counts).reshape(-1, group).sum(axis=1, dtype='int64')
+        if factor < 0:    # the reference fails in range() with a float step (4 ** factor)
+            raise TypeError("'float' object cannot be interpreted as an integer")
+        c = np.asanyarray(self.counts)
+        if factor == 0:   # groups of one: a fresh int64 copy
+            self.counts = np.array(c, dtype='int64')
+            return
+        if c.dtype.kind in 'iub':
+            self.counts = _native.context().shrink(c, self.length, factor)
+        else:   # the reference builds int64 counts from whatever it holds (np.fromiter(..., dtype='int64'))
+            self.counts = c.reshape(-1, 4 ** factor).sum(axis=1).astype('int64')
         self.length -= factor
 
     def shuffle(self):

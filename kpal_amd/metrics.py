@@ -7,8 +7,8 @@ API parity: function names, argument order and the keys of the ``pairwise``,
 Routing rule: ``multiset`` with the built-in ``pairwise['prod']`` /
 ``pairwise['sum']`` objects (recognised by identity) and ``euclidean`` on integer vectors run
 as fused HIP reductions; a user-supplied pairwise callable cannot enter a kernel and keeps the
-reference's NumPy formulation.  The small helpers (scale factors, summaries, mergers) are not on
-the hot path and stay NumPy.
+reference's NumPy formulation.  The built-in mergers run as one HIP kernel through ``Profile.merge``
+(``merger_code``); the scale-factor helpers are scalar arithmetic and stay NumPy.
 """
 from collections import Counter
 
@@ -129,6 +129,15 @@ mergers = {
     'int': lambda x, y: x * np.asanyarray(y, dtype=bool),
     'nint': lambda x, y: x * np.logical_not(y),
 }
+
+
+def merger_code(function):
+    """-> native code of a built-in merge function (a value of :data:`mergers`), else None."""
+    for code, name in ((_native.MERGE_SUM, 'sum'), (_native.MERGE_XOR, 'xor'), (_native.MERGE_INT, 'int'),
+                       (_native.MERGE_NINT, 'nint')):
+        if function is mergers[name]:
+            return code
+    return None
 
 
 def summary_code(function):

@@ -432,6 +432,83 @@ ORACLE_API double kpal_oracle_strand_balance(const int64_t *counts, int k, int p
 }
 
 /* ------------------------------------------------------------------------------------ *
+ * Profile summaries.  kpal/klib.py:193-225: non_zero = np.count_nonzero(counts),
+ * total = counts.sum() (int64, wraps), mean = counts.mean(), median = np.median(counts),
+ * std = counts.std().  NumPy (third party, see np_pairwise_sum above) computes
+ *   mean : add.reduce(counts, dtype=float64) / n -- the int64 -> float64 cast runs through the
+ *          ufunc buffer, 8192 elements at a time, each buffer summed pairwise and the buffer
+ *          sums accumulated in order;
+ *   std  : sqrt(add.reduce(((double)counts - mean)**2) / n), one pairwise sum (no cast);
+ *   median: for even n the mean of the two middle elements of the sorted vector, in float64.
+ * out[0..6] = total, non_zero, min, max (as int64 bit patterns in doubles is lossy, so:)
+ * integers go to iout[0..3] = total, non_zero, min, max; dout[0..2] = mean, median, std.
+ * ------------------------------------------------------------------------------------ */
+ORACLE_API void kpal_oracle_stats(const int64_t *c, size_t n, int64_t *iout, double *dout)
+{
+    uint64_t total = 0;
+    int64_t nz = 0, mn = INT64_MAX, mx = INT64_MIN;
+    for (size_t i = 0; i < n; i++) {
+        total += (uint64_t)c[i];
+        nz += c[i] != 0;
+        if (c[i] < mn) mn = c[i];
+        if (c[i] > mx) mx = c[i];
+    }
+    iout[0] = (int64_t)total;
+    iout[1] = nz;
+    iout[2] = mn;
+    iout[3] = mx;
+    double *d = (double *)malloc((n ? n : 1) * sizeof(double));
+    double sum = 0.0;
+    for (size_t b = 0; b < n; b += 8192) {
+        const size_t len = n - b < 8192 ? n - b : 8192;
+        for (size_t i = 0; i < len; i++) d[i] = (double)c[b + i];
+        sum += np_pairwise_sum(d, len);
+    }
+    const double mean = sum / (double)n;
+    for (size_t i = 0; i < n; i++) {
+        const double x = (double)c[i] - mean;
+        d[i] = x * x;
+    }
+    dout[0] = mean;
+    dout[2] = sqrt(np_pairwise_sum(d, n) / (double)n);
+    free(d);
+    int64_t *sorted = (int64_t *)malloc((n ? n : 1) * sizeof(int64_t));
+    memcpy(sorted, c, n * sizeof(int64_t));
+    qsort(sorted, n, sizeof(int64_t), cmp_i64);
+    dout[1] = (n % 2) ? (double)sorted[n / 2] : ((double)sorted[n / 2 - 1] + (double)sorted[n / 2]) / 2.0;
+    free(sorted);
+}
+
+/* metrics.mergers, kpal/metrics.py:174-179, as used by Profile.merge (klib.py:269-283):
+ *   0 sum : x + y        1 xor : (x + y) * logical_xor(x, y)
+ *   2 int : x * bool(y)  3 nint: x * logical_not(y)            (int64, wrapping) */
+ORACLE_API void kpal_oracle_merge(const int64_t *x, const int64_t *y, size_t n, int merger, int64_t *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t a = (uint64_t)x[i], b = (uint64_t)y[i];
+        uint64_t r;
+        switch (merger) {
+        case 0: r = a + b; break;
+        case 1: r = (a + b) * (uint64_t)((a != 0) != (b != 0)); break;
+        case 2: r = a * (uint64_t)(b != 0); break;
+        default: r = a * (uint64_t)(b == 0); break;
+        }
+        out[i] = (int64_t)r;
+    }
+}
+
+/* Profile.shrink(factor), kpal/klib.py:329-352: new_counts[j] = sum(counts[j*4^f : (j+1)*4^f]). */
+ORACLE_API void kpal_oracle_shrink(const int64_t *c, int k, int factor, int64_t *out)
+{
+    const size_t n = (size_t)1 << (2 * k), m = (size_t)1 << (2 * factor);
+    for (size_t j = 0; j < n / m; j++) {
+        uint64_t s = 0;
+        for (size_t i = 0; i < m; i++) s += (uint64_t)c[j * m + i];
+        out[j] = (int64_t)s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ *
  * Synthetic read generator (OURS, not the reference's: SURVEY.md section 8d).  Shared spec
  * for bench/test inputs; the HIP generator kernel must reproduce these bytes exactly.
  *   mix = splitmix64 finaliser; g = read*read_len + pos;

@@ -63,6 +63,12 @@ def lib():
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int]
         L.kpal_oracle_profile_distance.restype = ctypes.c_double
+        L.kpal_oracle_stats.argtypes = [_c_i64p, ctypes.c_size_t, _c_i64p, _c_f64p]
+        L.kpal_oracle_stats.restype = None
+        L.kpal_oracle_merge.argtypes = [_c_i64p, _c_i64p, ctypes.c_size_t, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_merge.restype = None
+        L.kpal_oracle_shrink.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_shrink.restype = None
         L.kpal_oracle_strand_balance.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int]
         L.kpal_oracle_strand_balance.restype = ctypes.c_double
         L.kpal_oracle_synth_reads.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
@@ -213,6 +219,36 @@ def distance_matrix_text(names, values, precision):
         lines.append(' '.join('{{0:.{0}f}}'.format(precision).format(values[o + j]) for j in range(i)))
         o += i
     return '\n'.join(lines) + '\n'
+
+
+MERGER = {'sum': 0, 'xor': 1, 'int': 2, 'nint': 3}
+
+
+def stats(counts):
+    """Restates Profile.total/non_zero/mean/median/std (klib.py:193-225) -> dict (plus min, max)."""
+    c, cp = _i64(counts)
+    iout = np.empty(4, dtype=np.int64)
+    dout = np.empty(3, dtype=np.float64)
+    lib().kpal_oracle_stats(cp, c.size, iout.ctypes.data_as(_c_i64p), dout.ctypes.data_as(_c_f64p))
+    return {'total': int(iout[0]), 'non_zero': int(iout[1]), 'min': int(iout[2]), 'max': int(iout[3]),
+            'mean': float(dout[0]), 'median': float(dout[1]), 'std': float(dout[2])}
+
+
+def merge(left, right, merger='sum'):
+    """Restates metrics.mergers[merger](left, right) on int64 vectors (metrics.py:174-179)."""
+    l, lp = _i64(left)
+    r, rp = _i64(right)
+    out = np.empty(l.size, dtype=np.int64)
+    lib().kpal_oracle_merge(lp, rp, l.size, MERGER[merger], out.ctypes.data_as(_c_i64p))
+    return out
+
+
+def shrink(counts, length, factor=1):
+    """Restates Profile.shrink (klib.py:329-352) -> the 4^(length-factor) new counts."""
+    c, cp = _i64(counts)
+    out = np.empty(4 ** (length - factor), dtype=np.int64)
+    lib().kpal_oracle_shrink(cp, length, factor, out.ctypes.data_as(_c_i64p))
+    return out
 
 
 def strand_balance(counts, length, pairwise='prod'):

@@ -74,12 +74,10 @@ def test_fasta_tokeniser_and_profile_surface():
     q = p.copy()
     q.counts[0] = 99
     assert p.counts[0] == 0
-    p.merge(q)
-    assert p.counts[0] == 99 and p.counts[1] == 2
-    p.shrink()
-    assert p.length == 1 and list(p.counts) == [111, 44, 76, 108]
     with pytest.raises(ValueError):
-        p.shrink(1)
+        klib.Profile(np.arange(4, dtype=np.int64)).shrink(1)       # factor must be smaller than k
+    p.merge(q, merger=lambda x, y: x + 2 * y)                       # user callable: NumPy, as the reference
+    assert p.counts[0] == 198 and p.counts[1] == 3
 
 
 def test_metrics_numpy_helpers():

@@ -179,3 +179,24 @@ def test_g9_profile_distance_options(golden_options):
             np.testing.assert_array_equal(b, z['g9_%d_%s_r' % (pi, name)])
             checked += 1
     assert checked >= 20
+
+
+def test_g10_summaries_merge_shrink(golden_summaries):
+    """Profile.total/non_zero/mean/median/std, merge with every built-in merger and shrink
+    (kpal/klib.py:193-225,269-283,329-352): oracle vs the reference's outputs."""
+    g, z = golden_summaries
+    assert g['n'] == len(g['cases']) >= 15
+    for i, c in enumerate(g['cases']):
+        v = z['g10_%d' % i]
+        s = oracle.stats(v)
+        assert (s['total'], s['non_zero']) == (c['total'], c['non_zero']), i
+        assert s['median'] == c['median'], i
+        for key in ('mean', 'std'):
+            assert abs(s[key] - c[key]) <= 1e-12 * abs(c[key]) + 1e-300, (i, key, s[key], c[key])
+        assert c['shrink'] == list(range(1, c['k']))
+        for factor in c['shrink']:
+            np.testing.assert_array_equal(oracle.shrink(v, c['k'], factor), z['g10_%d_shrink%d' % (i, factor)])
+    assert len(g['merges']) >= 20
+    for m in g['merges']:
+        l, r = z['g10_%d' % m['left']], z['g10_%d' % m['right_reversed']][::-1]
+        np.testing.assert_array_equal(oracle.merge(l, r, m['merger']), z[m['key']], err_msg=m['key'])

@@ -11,7 +11,8 @@ reference's own code: kpal.klib.Profile, kpal.metrics, kpal.kdistlib, kpal.kmer.
 
 Fixture groups follow SURVEY.md section 8c (G1..G8); G9 pins every ProfileDistance option
 (balance, positive, dynamic smoothing with each summary function, scaling, every metric:
-kpal/kdistlib.py:126-161).  Only DATA is written: inputs and the reference's outputs.
+kpal/kdistlib.py:126-161); G10 pins the profile summaries, Profile.merge with every built-in
+merger and Profile.shrink (kpal/klib.py:193-225,269-283,329-352).  Only DATA is written: inputs and the reference's outputs.
 """
 from __future__ import print_function
 
@@ -384,6 +385,56 @@ def g9(arrays):
             'cases': cases}
 
 
+def g10(arrays):
+    """Profile.total/non_zero/mean/median/std, merge with each metrics.mergers entry, shrink."""
+    rs = np.random.RandomState(10)
+    vecs = []
+    for k, lam in ((1, 2.0), (2, 0.5), (3, 4.0), (4, 0.3), (4, 30.0), (5, 1.0), (6, 0.05), (6, 900.0), (7, 2.5)):
+        vecs.append((k, rs.poisson(lam, 4 ** k).astype('int64')))
+    v = rs.poisson(3.0, 4 ** 5).astype('int64')
+    v[rs.rand(v.size) < 0.5] = 0                      # median 0 / 0.5 territory
+    vecs.append((5, v))
+    vecs.append((4, np.full(4 ** 4, 7, dtype='int64')))                                   # constant
+    vecs.append((5, rs.randint(1 << 40, 1 << 61, size=4 ** 5).astype('int64')))           # sum wraps int64
+    vecs.append((4, rs.randint(-1000, 1000, size=4 ** 4).astype('int64')))                # negative entries
+    vecs.append((6, (rs.randint(0, 3, size=4 ** 6) * (1 << 33)).astype('int64')))         # few distinct, > 2^32
+    v = np.zeros(4 ** 3, dtype='int64')
+    v[:31] = 5
+    v[31] = 9
+    v[32:] = 11                                         # the two middle elements differ: 9 and 11
+    vecs.append((3, v))
+    cases = []
+    for i, (k, c) in enumerate(vecs):
+        arrays['g10_%d' % i] = c
+        p = klib.Profile(c.copy())
+        with np.errstate(all='ignore'):
+            case = {'k': k, 'total': int(p.total), 'non_zero': int(p.non_zero), 'mean': float(p.mean),
+                    'median': float(p.median), 'std': float(p.std), 'shrink': []}
+        for factor in range(1, k):
+            q = klib.Profile(c.copy())
+            with np.errstate(all='ignore'), __import__('warnings').catch_warnings():
+                __import__('warnings').simplefilter('ignore')
+                q.shrink(factor)
+            assert q.length == k - factor
+            arrays['g10_%d_shrink%d' % (i, factor)] = q.counts
+            case['shrink'].append(factor)
+        cases.append(case)
+    merges = []
+    pairs = [(0, 0), (2, 2), (3, 4), (5, 9), (6, 7), (11, 9), (12, 3)]
+    for a, b in pairs:
+        if vecs[a][1].size != vecs[b][1].size:
+            continue
+        for name in ('sum', 'xor', 'int', 'nint'):
+            p = klib.Profile(vecs[a][1].copy())
+            q = klib.Profile(vecs[b][1][::-1].copy())
+            with np.errstate(all='ignore'):
+                p.merge(q, merger=metrics.mergers[name])
+            key = 'g10_merge_%d_%d_%s' % (a, b, name)
+            arrays[key] = np.asarray(p.counts, dtype='int64')
+            merges.append({'left': a, 'right_reversed': b, 'merger': name, 'key': key})
+    return {'n': len(vecs), 'cases': cases, 'merges': merges}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     arrays = {}
@@ -401,6 +452,10 @@ def main():
     with open(os.path.join(OUT, 'options.json'), 'w') as fh:
         json.dump({'meta': meta, 'G9': g9(opt_arrays)}, fh, indent=0)
     np.savez_compressed(os.path.join(OUT, 'options.npz'), **opt_arrays)
+    sum_arrays = {}
+    with open(os.path.join(OUT, 'summaries.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G10': g10(sum_arrays)}, fh, indent=0)
+    np.savez_compressed(os.path.join(OUT, 'summaries.npz'), **sum_arrays)
     print('wrote', sorted(os.listdir(OUT)))
 
 
