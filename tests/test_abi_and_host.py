@@ -139,3 +139,35 @@ def test_world_size_2_gloo_reduce(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GLOO_OK %d' % (1001 * 145) in outs[0]
+
+
+def test_kmer_caller_host_logic():
+    """kpal_amd.kmer (kpal/kmer.py:41-48,112-146,541-700): handle names, custom functions, and the argument
+    errors that are raised before any profile is touched."""
+    import memh5
+    from kpal_amd import kmer
+
+    class Named(io.StringIO):
+        name = '/data/run7/sample_A.fasta'
+
+    class Stdin(io.StringIO):
+        name = '<stdin>'
+
+    assert kmer._name_from_handle(Named()) == 'sample_A'
+    assert kmer._name_from_handle(Stdin()) is None and kmer._name_from_handle(io.StringIO()) is None
+    f = kmer._custom_function('np.maximum(left, right) + 1', 'left, right')
+    assert list(f(np.array([1, 5]), np.array([3, 2]))) == [4, 6]
+    assert kmer._custom_function('numpy.minimum', 'left, right') is np.minimum
+    with pytest.raises(ValueError, match='number of profile names does not match'):
+        kmer.count([io.StringIO('>a\nAC\n')], memh5.File(), 2, names=['a', 'b'])
+    empty = memh5.File()
+    with pytest.raises(ValueError, match='at least two'):
+        kmer.distance_matrix(empty, io.StringIO())
+    one = memh5.File()
+    one.create_dataset('profiles/x', data=np.zeros(16), dtype='int64', compression='gzip')
+    with pytest.raises(ValueError, match='left and right profile names do not match'):
+        kmer.distance(one, empty, io.StringIO())
+    with pytest.raises(ValueError, match='left and right profile names do not match'):
+        kmer.merge(one, empty, memh5.File())
+    with pytest.raises(KeyError):
+        kmer.balance(one, memh5.File(), names=['missing'])

@@ -12,7 +12,9 @@ reference's own code: kpal.klib.Profile, kpal.metrics, kpal.kdistlib, kpal.kmer.
 Fixture groups follow SURVEY.md section 8c (G1..G8); G9 pins every ProfileDistance option
 (balance, positive, dynamic smoothing with each summary function, scaling, every metric:
 kpal/kdistlib.py:126-161); G10 pins the profile summaries, Profile.merge with every built-in
-merger and Profile.shrink (kpal/klib.py:193-225,269-283,329-352).  Only DATA is written: inputs and the reference's outputs.
+merger and Profile.shrink (kpal/klib.py:193-225,269-283,329-352); G11 pins the callers of section 8
+row a14 (kmer.count/merge/balance/get_balance/get_stats/distance/distance_matrix) through real HDF5
+files.  Only DATA is written: inputs and the reference's outputs.
 """
 from __future__ import print_function
 
@@ -435,6 +437,103 @@ def g10(arrays):
     return {'n': len(vecs), 'cases': cases, 'merges': merges}
 
 
+def g11():
+    """The callers of SURVEY.md 8 row a14 -- kmer.count / merge / balance / get_balance / get_stats /
+    distance / distance_matrix (kpal/kmer.py:112-271,541-700) -- on the tutorial FASTA files through
+    real HDF5 files (h5py): dataset attributes, sha256 of the stored counts, and the text outputs."""
+    import tempfile
+    import h5py
+    tdir = os.path.join(OUT, 'tutorial')
+    tmp = tempfile.mkdtemp()
+
+    def h5(name):
+        f = h5py.File(os.path.join(tmp, name), 'w')
+        f.create_group('profiles')
+        return f
+
+    def describe(f):
+        out = {}
+        for name in sorted(f['profiles']):
+            ds = f['profiles/' + name]
+            out[name] = {'attrs': dict((k, float(v) if isinstance(v, (float, np.floating)) else int(v))
+                                       for k, v in ds.attrs.items()),
+                         'sha256': hashlib.sha256(ds[:].astype('<i8').tobytes()).hexdigest()}
+        return out
+
+    def text(fn, *args, **kw):
+        buf = io.StringIO()
+        fn(*args, **kw)
+        return buf
+
+    out = {}
+    files = ['a_1', 'a_2', 'b_1', 'b_2', 'c_1', 'c_2']
+    handles = [open(os.path.join(tdir, n + '.fa')) for n in files]
+    counted = h5('count.k8')
+    kmer.count(handles, counted, 8)                         # names from the file names
+    out['count_k8'] = describe(counted)
+    for h in handles:
+        h.seek(0)
+    named = h5('named.k5')
+    kmer.count(handles[:2], named, 5, names=['x', 'y'])
+    out['count_k5_named'] = describe(named)
+    for h in handles:
+        h.seek(0)
+    rec1 = h5('rec1.k4')
+    one = '>first some title\nACGTTGCAACGT\nACG\n>second\nNNACGTN\n>third\nAC\n'
+    kmer.count([io.StringIO(one)], rec1, 4, by_record=True)  # one file: no prefix
+    out['by_record_one_file'] = {'input': one, 'profiles': describe(rec1)}
+    rec2 = h5('rec2.k4')
+    small = [io.StringIO('>r1 x\nACGTACGTAA\n>r2\nTTTTT\nGGGNAC\n'), io.StringIO('>r1\nCCCCCCC\n')]
+    kmer.count(small, rec2, 3, names=['p', 'q'], by_record=True)
+    out['by_record_two_files'] = {'inputs': ['>r1 x\nACGTACGTAA\n>r2\nTTTTT\nGGGNAC\n', '>r1\nCCCCCCC\n'],
+                                  'profiles': describe(rec2)}
+    # merge: left a_1, b_1 with right a_2, b_2 (names differ -> concatenated), every built-in merger
+    out['merge'] = {}
+    for merger in ('sum', 'xor', 'int', 'nint'):
+        m = h5('merge_%s.k8' % merger)
+        kmer.merge(counted, counted, m, names_left=['a_1', 'b_1'], names_right=['a_2', 'b_2'], merger=merger)
+        out['merge'][merger] = describe(m)
+    m = h5('merge_same.k8')
+    kmer.merge(counted, counted, m, names_left=['c_1'], names_right=['c_1'])
+    out['merge_same_name'] = describe(m)
+    m = h5('merge_custom.k8')
+    kmer.merge(counted, counted, m, names_left=['c_1'], names_right=['c_2'], custom_merger='np.maximum(left, right)')
+    out['merge_custom'] = describe(m)
+    bal = h5('balanced.k8')
+    kmer.balance(counted, bal, names=['a_1', 'c_2'])
+    out['balance'] = describe(bal)
+    for key, fn, kw in (('get_balance_p10', kmer.get_balance, {}), ('get_balance_p3', kmer.get_balance, {'precision': 3}),
+                        ('get_stats_p10', kmer.get_stats, {}), ('get_stats_p4', kmer.get_stats, {'precision': 4, 'names': ['b_2', 'a_1']})):
+        buf = io.StringIO()
+        fn(counted, buf, **kw)
+        out[key] = buf.getvalue()
+    left, right = h5('left.k8'), h5('right.k8')
+    for n in ('a', 'b', 'c'):
+        klib.Profile.from_file(counted, n + '_1').save(left, name=n)
+        klib.Profile.from_file(counted, n + '_2').save(right, name=n)
+    out['distance'] = []
+    for kw in ({}, {'precision': 3}, {'do_balance': True, 'precision': 8}, {'pairwise': 'sum', 'precision': 8},
+               {'distance_function': 'euclidean', 'precision': 6}, {'distance_function': 'cosine', 'precision': 8},
+               {'do_smooth': True, 'summary': 'average', 'threshold': 2, 'precision': 8},
+               {'do_smooth': True, 'summary': 'median', 'threshold': 1, 'do_scale': True, 'down': True, 'precision': 8},
+               {'do_positive': True, 'do_scale': True, 'precision': 8},
+               {'custom_pairwise': 'abs(left - right) / (left + right + 2)', 'precision': 8},
+               {'do_smooth': True, 'custom_summary': 'np.max(values)', 'threshold': 3, 'precision': 8},
+               {'names_left': ['c', 'a'], 'names_right': ['b', 'b'], 'precision': 8}):
+        buf = io.StringIO()
+        kmer.distance(left, right, buf, **kw)
+        out['distance'].append({'kwargs': kw, 'text': buf.getvalue()})
+    out['matrix'] = []
+    for kw in ({'precision': 3}, {'precision': 8, 'do_balance': True}, {'precision': 8, 'pairwise': 'sum', 'names': ['c_2', 'a_1', 'b_1']},
+               {'precision': 6, 'distance_function': 'euclidean'},
+               {'precision': 8, 'do_smooth': True, 'summary': 'min', 'threshold': 1, 'do_scale': True}):
+        buf = io.StringIO()
+        kmer.distance_matrix(counted, buf, **kw)
+        out['matrix'].append({'kwargs': kw, 'text': buf.getvalue()})
+    out['files'] = files
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     arrays = {}
@@ -456,6 +555,8 @@ def main():
     with open(os.path.join(OUT, 'summaries.json'), 'w') as fh:
         json.dump({'meta': meta, 'G10': g10(sum_arrays)}, fh, indent=0)
     np.savez_compressed(os.path.join(OUT, 'summaries.npz'), **sum_arrays)
+    with open(os.path.join(OUT, 'callers.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G11': g11()}, fh, indent=0)
     print('wrote', sorted(os.listdir(OUT)))
 
 
