@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity stress of the vector side (developer tool, GPU box): balance, split, strand
-balance, every ProfileDistance option combination and the distance matrix against the oracle.
+balance, summaries / merge / shrink, every ProfileDistance option combination and the distance matrix
+against the oracle.
     python tools/stress_vec.py [--seconds 90] [--seed 1]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,6 +57,17 @@ while time.time() < t_end:
     assert np.array_equal(f, fo) and np.array_equal(rv, ro), ('split', k)
     for pw in ('prod', 'sum'):
         assert close(ctx.strand_balance(l, k, metric[pw]), oracle.strand_balance(l, k, pw)), ('strand', k, pw)
+    # summaries, merge, shrink (stat_kernels.hpp)
+    sv = l if rs.rand() < 0.7 else (l - rs.randint(0, 1 << 20)).astype(np.int64)      # sometimes negative entries
+    got, want = ctx.stats(sv), oracle.stats(sv)
+    assert (got.total, got.non_zero, got.min, got.max, got.median) == (want['total'], want['non_zero'], want['min'], want['max'], want['median']), ('stats', k)
+    scale = float(np.abs(sv.astype(np.float64)).mean())
+    assert abs(got.mean - want['mean']) <= 1e-9 * scale + 1e-300 and abs(got.std - want['std']) <= 1e-9 * abs(want['std']) + 1e-300, ('stats fp', k, got.mean, want['mean'], got.std, want['std'])
+    mname = ('sum', 'xor', 'int', 'nint')[rs.randint(4)]
+    assert np.array_equal(ctx.merge(l, r, ('sum', 'xor', 'int', 'nint').index(mname)), oracle.merge(l, r, mname)), ('merge', k, mname)
+    if k > 1:
+        f_ = int(rs.randint(1, k))
+        assert np.array_equal(ctx.shrink(l, k, f_), oracle.shrink(l, k, f_)), ('shrink', k, f_)
     for _ in range(6):
         o = dict(do_balance=bool(rs.rand() < 0.5), do_positive=bool(rs.rand() < 0.3), do_smooth=bool(rs.rand() < 0.5),
                  summary=['min', 'average', 'median'][rs.randint(3)], threshold=[0, 1, 2.5, 100][rs.randint(4)],
