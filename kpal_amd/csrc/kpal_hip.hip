@@ -1239,15 +1239,38 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
     for (int ti = 0; ti < side; ++ti)
         for (int tj = 0; tj <= ti; ++tj) tiles.push_back(make_int2(ti, tj));
     const uint32_t ntiles = (uint32_t)tiles.size();
-    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 16 / ntiles)));
-    CHK(ensure(ctx, ctx->scratch[3], (size_t)ntiles * sizeof(int2)));
-    HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, tiles.data(), (size_t)ntiles * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
-    Partial *pp = (Partial *)ctx->partials.p;
-    const int2 *dt = (const int2 *)ctx->scratch[3].p;
-    if (metric == 0) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<0, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
-    else if (metric == 1) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<1, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
-    else LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<2, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+    // LDS-staged 16 x 16 super-tiles when there are enough profiles and bins to share; KPAL_MATRIX_SUPER=0 forces
+    // the register-tile kernel (A/B timing, cross-check)
+    static const bool allow_super = [] { const char *e = getenv("KPAL_MATRIX_SUPER"); return !e || atoi(e) != 0; }();
+    const bool super = allow_super && P > 8 && k >= 6;
+    unsigned gx;
+    if (super) {
+        const int sside = (P + 15) / 16;
+        std::vector<int2> supers;
+        for (int si = 0; si < sside; ++si)
+            for (int sj = 0; sj <= si; ++sj) supers.push_back(make_int2(si, sj));
+        const uint32_t nsuper = (uint32_t)supers.size();
+        gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / kSuperBins, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 8 / nsuper)));
+        CHK(ensure(ctx, ctx->scratch[3], (size_t)nsuper * sizeof(int2)));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, supers.data(), (size_t)nsuper * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+        CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
+        Partial *pp = (Partial *)ctx->partials.p;
+        const int2 *dt = (const int2 *)ctx->scratch[3].p;
+        if (metric == 0) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<0>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
+        else if (metric == 1) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<1>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
+        else LAUNCH(ctx, "matrix_super", (matrix_super_kernel<2>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // `supers` is read by the asynchronous copy above
+    } else {
+        gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 16 / ntiles)));
+        CHK(ensure(ctx, ctx->scratch[3], (size_t)ntiles * sizeof(int2)));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, tiles.data(), (size_t)ntiles * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+        CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
+        Partial *pp = (Partial *)ctx->partials.p;
+        const int2 *dt = (const int2 *)ctx->scratch[3].p;
+        if (metric == 0) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<0, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+        else if (metric == 1) LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<1, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+        else LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<2, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
+    }
     std::vector<Partial> res;
     CHK(finish_partials(ctx, ntiles * TILE * TILE, gx, res));
     for (int i = 1; i < P; ++i)

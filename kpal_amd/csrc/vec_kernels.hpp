@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const Partial *__r
 // the product, and one residual correction of the quotient -- the correction multiplies the error of the
 // quotient by the error of the reciprocal, so the result is within 1 ulp of the correctly rounded quotient
 // whenever v_rcp_f64 is good to 14 bits.  6 full-rate instructions instead of the ~13 of the IEEE
-// division sequence (v_div_scale x2, two Newton steps, v_div_fmas, v_div_fixup), 29.0 -> 21 ms for the
-// 64-profile k=12 matrix.  The parity contract for fp64 results is 1e-9 relative.
+// division sequence (v_div_scale x2, two Newton steps, v_div_fmas, v_div_fixup), 29.0 -> 21.4 ms for the
+// 64-profile k=12 matrix with register tiles.  The parity contract for fp64 results is 1e-9 relative.
 // KPAL_MATRIX_DIV: 0 = IEEE division, 1 = two Newton steps without the correction, 2 = two steps with it.
 #ifndef KPAL_MATRIX_DIV
 #define KPAL_MATRIX_DIV 3
@@ -451,7 +451,7 @@ __device__ __forceinline__ double div_counts(double num, double den)
 #if KPAL_MATRIX_DIV == 0
     return num / den;
 #else
-    double r = __builtin_amdgcn_rcp(den);
+    double r = __builtin_amdgcn_rcp(den);   // (an fp32 v_rcp_f32 seed is as exact and not faster: the reciprocal is not the limit)
     r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
 #if KPAL_MATRIX_DIV != 3
     r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
@@ -470,6 +470,84 @@ __device__ __forceinline__ double div_counts(double num, double den)
 // blockIdx.x strides over bins.  Each thread streams one bin at a time for the TILE row
 // profiles and TILE column profiles (coalesced 512-B wave loads per profile), accumulating
 // TILE^2 (sum, m) pairs in registers.  partial layout: [tile][entry a*TILE+b][blockIdx.x].
+// The TILE x TILE terms of one bin: row values x[], column values y[]; s = fp64 sums, mf = number of
+// multiset terms, m = exact int64 dots (euclidean).
+// Term counts of the float path: per row a one word of four byte counters (column b in byte b) of the bins in
+// which x[a] or y[b] is non-zero -- 19 instead of 48 instructions per bin for the 16 counts; the bytes are
+// added to the 32-bit totals every 255 bins.
+template <int TILE>
+struct TermBytes {
+    uint32_t packed[TILE];
+    uint32_t bins;
+};
+
+template <int TILE>
+__device__ __forceinline__ void term_bytes_flush(TermBytes<TILE> &tb, uint32_t (&mf)[TILE][TILE])
+{
+    static_assert(TILE == 4, "four byte counters per word");
+#pragma unroll
+    for (int a = 0; a < TILE; ++a) {
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) mf[a][b] += (tb.packed[a] >> (8 * b)) & 255u;
+        tb.packed[a] = 0u;
+    }
+    tb.bins = 0u;
+}
+
+template <int METRIC, int TILE>
+__device__ __forceinline__ void matrix_accumulate(const int64_t (&x)[TILE], const int64_t (&y)[TILE], double (&s)[TILE][TILE],
+                                                  unsigned long long (&m)[TILE][TILE], uint32_t (&mf)[TILE][TILE],
+                                                  TermBytes<TILE> &tb)
+{
+    if constexpr (METRIC != 2) {
+        // Counts below 2^31 (any real profile): |x-y|, (x+1)(y+1) and x+y+1 are exact in float64 or
+        // round exactly like the int64 value NumPy converts, so the terms are bit-identical to the
+        // int64 formulation -- with 8 cheap 32-bit conversions per bin instead of 32 64-bit ones.
+        uint64_t any = 0;
+#pragma unroll
+        for (int a = 0; a < TILE; ++a) any |= (uint64_t)x[a] | (uint64_t)y[a];
+        if (__all((any >> 31) == 0)) {   // wave-uniform
+            double xd[TILE], yd[TILE];
+#pragma unroll
+            for (int a = 0; a < TILE; ++a) {
+                xd[a] = (double)(uint32_t)x[a];
+                yd[a] = (double)(uint32_t)y[a];
+            }
+            // branch-free: a pair of zeros contributes |0 - 0| / 1 = +0.0 to the sum and nothing to the count, so
+            // the 16 division chains of a bin are independent straight-line code that the scheduler interleaves
+#pragma unroll
+            for (int a = 0; a < TILE; ++a)
+#pragma unroll
+                for (int b = 0; b < TILE; ++b) {
+                    const double num = fabs(xd[a] - yd[b]);
+                    const double den = METRIC == 0 ? (xd[a] + 1.0) * (yd[b] + 1.0) : xd[a] + yd[b] + 1.0;
+                    s[a][b] += div_counts(num, den);
+                }
+            uint32_t ynz = 0u;   // byte b = 1 iff y[b] != 0
+#pragma unroll
+            for (int b = 0; b < TILE; ++b) ynz |= min((uint32_t)y[b], 1u) << (8 * b);
+#pragma unroll
+            for (int a = 0; a < TILE; ++a) tb.packed[a] += (uint32_t)x[a] != 0u ? 0x01010101u : ynz;
+            if (++tb.bins == 255u) term_bytes_flush(tb, mf);   // wave-uniform
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            if constexpr (METRIC == 2) {
+                const uint64_t d = (uint64_t)x[a] - (uint64_t)y[b];
+                m[a][b] += d * d;
+            } else {
+                if (x[a] != 0 || y[b] != 0) {
+                    s[a][b] += METRIC == 0 ? pw_prod(x[a], y[b]) : pw_sum(x[a], y[b]);
+                    mf[a][b] += 1u;
+                }
+            }
+        }
+}
+
 template <int METRIC, int TILE>
 __global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
                                                           const int2 *__restrict__ tiles,
@@ -478,18 +556,16 @@ __global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restr
     const int ti = tiles[blockIdx.y].x, tj = tiles[blockIdx.y].y;
     double s[TILE][TILE];
     unsigned long long m[TILE][TILE];
+    uint32_t mf[TILE][TILE];   // multiset: number of terms (a thread sees fewer than 2^32 bins); m holds the euclidean dots
 #pragma unroll
     for (int a = 0; a < TILE; ++a)
 #pragma unroll
         for (int b = 0; b < TILE; ++b) {
             s[a][b] = 0.0;
             m[a][b] = 0ULL;
+            mf[a][b] = 0u;
         }
-    uint32_t mf[TILE][TILE];   // multiset: number of terms (a thread sees fewer than 2^32 bins); m holds the euclidean dots
-#pragma unroll
-    for (int a = 0; a < TILE; ++a)
-#pragma unroll
-        for (int b = 0; b < TILE; ++b) mf[a][b] = 0u;
+    TermBytes<TILE> tb = {{0u, 0u, 0u, 0u}, 0u};
     const int64_t *rowp[TILE];
     const int64_t *colp[TILE];
 #pragma unroll
@@ -504,50 +580,9 @@ __global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restr
             x[a] = rowp[a][i];
             y[a] = colp[a][i];
         }
-        if constexpr (METRIC != 2) {
-            // Counts below 2^31 (any real profile): |x-y|, (x+1)(y+1) and x+y+1 are exact in float64 or
-            // round exactly like the int64 value NumPy converts, so the terms are bit-identical to the
-            // int64 formulation -- with 8 cheap 32-bit conversions per bin instead of 32 64-bit ones.
-            uint64_t any = 0;
-#pragma unroll
-            for (int a = 0; a < TILE; ++a) any |= (uint64_t)x[a] | (uint64_t)y[a];
-            if (__all((any >> 31) == 0)) {   // wave-uniform
-                double xd[TILE], yd[TILE];
-#pragma unroll
-                for (int a = 0; a < TILE; ++a) {
-                    xd[a] = (double)(uint32_t)x[a];
-                    yd[a] = (double)(uint32_t)y[a];
-                }
-                // branch-free: a pair of zeros contributes |0 - 0| / 1 = +0.0 to the sum and nothing to m, so
-                // the 16 division chains of a bin are independent straight-line code that the scheduler interleaves
-                // (with a branch per term every chain ran alone, exposed to the full fp64 latency)
-#pragma unroll
-                for (int a = 0; a < TILE; ++a)
-#pragma unroll
-                    for (int b = 0; b < TILE; ++b) {
-                        const double num = fabs(xd[a] - yd[b]);
-                        const double den = METRIC == 0 ? (xd[a] + 1.0) * (yd[b] + 1.0) : xd[a] + yd[b] + 1.0;
-                        s[a][b] += div_counts(num, den);
-                        mf[a][b] += (((uint32_t)x[a] | (uint32_t)y[b]) != 0u) ? 1u : 0u;
-                    }
-                continue;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < TILE; ++a)
-#pragma unroll
-            for (int b = 0; b < TILE; ++b) {
-                if constexpr (METRIC == 2) {
-                    const uint64_t d = (uint64_t)x[a] - (uint64_t)y[b];
-                    m[a][b] += d * d;
-                } else {
-                    if (x[a] != 0 || y[b] != 0) {
-                        s[a][b] += METRIC == 0 ? pw_prod(x[a], y[b]) : pw_sum(x[a], y[b]);
-                        mf[a][b] += 1u;
-                    }
-                }
-            }
+        matrix_accumulate<METRIC, TILE>(x, y, s, m, mf, tb);
     }
+    term_bytes_flush(tb, mf);
 #pragma unroll
     for (int a = 0; a < TILE; ++a)
 #pragma unroll
@@ -556,6 +591,102 @@ __global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restr
             p = block_reduce(p);
             if (threadIdx.x == 0)
                 partials[((uint64_t)blockIdx.y * TILE * TILE + a * TILE + b) * gridDim.x + blockIdx.x] = p;
+        }
+}
+
+// The same lower triangle in 16 x 16 SUPER-tiles staged through LDS (k >= 6, P > 8): a workgroup loads 64 bins
+// of its 16 row and 16 column profiles once (512-byte runs, the next stage's loads in flight during the
+// arithmetic) and its 16 groups of 16 lanes compute the sixteen 4 x 4 register tiles from LDS -- a quarter of
+// the global loads per term of matrix_tile_kernel, whose 146 GB of (cached) loads bound the euclidean matrix
+// and nearly bound the multiset one.  Group g owns tile (4 si + g/4, 4 sj + g%4); tiles above the diagonal
+// idle.  Rows are padded to 68 bins so that the column rows of the two groups of a half-wave (4 rows apart)
+// sit 32 banks apart for ds_read_b64.  Partials: the layout of matrix_tile_kernel, tile index ti(ti+1)/2 + tj.
+constexpr int kSuperBins = 64;
+constexpr int kSuperRow = 68;
+template <int METRIC>
+__global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                           const int2 *__restrict__ supers,
+                                                           Partial *__restrict__ partials)
+{
+    constexpr int TILE = 4;
+    __shared__ int64_t stage[2][32][kSuperRow];
+    const int si = supers[blockIdx.y].x, sj = supers[blockIdx.y].y;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int ti = si * 4 + (g >> 2), tj = sj * 4 + (g & 3);
+    const int side = (P + TILE - 1) / TILE;
+    const bool mine = ti < side && tj <= ti;           // this group's 4 x 4 tile is part of the lower triangle
+    double s[TILE][TILE];
+    unsigned long long m[TILE][TILE];
+    uint32_t mf[TILE][TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            s[a][b] = 0.0;
+            m[a][b] = 0ULL;
+            mf[a][b] = 0u;
+        }
+    TermBytes<TILE> tb = {{0u, 0u, 0u, 0u}, 0u};
+    // loader: value q of thread t is bin (t & 63) of staged row 4 q + (t >> 6): a wave reads one 512-byte run
+    const int lrow = threadIdx.x >> 6, lcol = threadIdx.x & 63;
+    const int64_t *src[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 4 * q + lrow;                    // 0..15 rows of the super-tile, 16..31 its columns
+        const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
+        src[q] = prof + (uint64_t)min(profile, P - 1) * n + lcol;
+    }
+    const uint64_t chunks = n / kSuperBins;
+    int64_t next[8];
+    uint64_t c = blockIdx.x;
+    if (c < chunks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stage[0][4 * q + lrow][lcol] = src[q][c * kSuperBins];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; c < chunks; c += gridDim.x) {
+        const bool more = c + gridDim.x < chunks;      // block-uniform
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) next[q] = src[q][(c + gridDim.x) * kSuperBins];
+        }
+        if (mine) {
+#pragma unroll 1   // (unrolled 2 / 4 times: 21.3 / 20.4 ms against 19.9)
+            for (int u = 0; u < kSuperBins / 16; ++u) {
+                int64_t x[TILE], y[TILE];
+#pragma unroll
+                for (int a = 0; a < TILE; ++a) {
+                    x[a] = stage[cur][4 * (g >> 2) + a][16 * u + l];
+                    y[a] = stage[cur][16 + 4 * (g & 3) + a][16 * u + l];
+                }
+                matrix_accumulate<METRIC, TILE>(x, y, s, m, mf, tb);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stage[cur ^ 1][4 * q + lrow][lcol] = next[q];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    term_bytes_flush(tb, mf);
+    // per-group reduction over its 16 lanes (fixed order), lane 0 of the group writes
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            double ps = s[a][b];
+            unsigned long long pm = METRIC != 2 ? (unsigned long long)mf[a][b] : m[a][b];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {
+                ps += __shfl_down(ps, d, 16);
+                pm += __shfl_down(pm, d, 16);
+            }
+            if (mine && l == 0) {
+                const uint64_t t = (uint64_t)ti * (ti + 1) / 2 + tj;
+                partials[(t * TILE * TILE + a * TILE + b) * gridDim.x + blockIdx.x] = Partial{ps, pm};
+            }
         }
 }
 

@@ -189,6 +189,41 @@ def test_matrix_vs_pairs_and_oracle(ctx):
                     np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
 
 
+def test_matrix_super_tiles(ctx):
+    """The LDS-staged 16 x 16 super-tile kernel (P > 8, k >= 6): ragged profile counts (clamped rows, idle
+    groups, several super-tiles), counts >= 2^31 in some bins (int64 path next to the float path), and at
+    k = 12 enough bins per thread for the packed byte counters of the term counts to be flushed."""
+    rs = np.random.RandomState(17)
+    for k, P in ((6, 9), (6, 16), (7, 17), (6, 33), (8, 20)):
+        profs = [rs.poisson(rs.choice([0.3, 5.0, 90.0]), 4 ** k).astype(np.int64) for _ in range(P)]
+        profs[P // 2][rs.randint(0, 4 ** k, 50)] = (1 << 31) + rs.randint(0, 1000, 50)     # beyond the float path
+        profs[1][::7] = 0
+        for metric in ('prod', 'sum', 'euclidean'):
+            code = ('prod', 'sum', 'euclidean').index(metric)
+            got = ctx.distance_matrix(profs, k, code)
+            if P <= 17:
+                want = oracle.distance_matrix_values(profs, k, False, metric)
+            else:
+                want = np.array([ctx.pair_distance(profs[i], profs[j], code) for i in range(1, P) for j in range(i)])
+            if metric == 'euclidean':
+                np.testing.assert_array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    k, P = 12, 10
+    profs = [ctx.count_bytes(k, oracle.synth_reads(300 + p, 0, 60000, 150)) for p in range(P)]
+    profs[3][:1000] += 1 << 32
+    for code in (0, 1, 2):
+        got = ctx.distance_matrix(profs, k, code)
+        want = np.array([ctx.pair_distance(profs[i], profs[j], code) for i in range(1, P) for j in range(i)])
+        if code == 2:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    metric = 'prod'
+    for i, j in ((1, 0), (3, 2), (9, 3)):
+        assert close(ctx.distance_matrix(profs, k, 0)[i * (i - 1) // 2 + j], oracle.distance(profs[i], profs[j], k, metric=metric))
+
+
 def test_g4_tutorial_end_to_end(golden_scalars, tutorial_dir):
     """doc/tutorial.rst:44-144 through the drop-in API: count 8 FASTA files (60-column wrapped
     records), merge, distance, matrix, showbalance."""
