@@ -6,13 +6,15 @@
 // [g*R, (g+1)*R), R = steps per workgroup / 4 + 1024 + margin -- enough in EVERY case: at most
 // steps/4 full chunks (a step is 1024 k-mers, a chunk 4096 keys), one partly filled and one
 // pre-assigned next chunk per bucket -- so allocation is an LDS counter, never a global atomic.  A retired chunk is recorded
-// as one word (chunk id | fill-1 << 22) in the table row of its (bucket, workgroup); rows hold four
+// as one word (chunk id | fill-1 << 20) in the table row of its (bucket, workgroup); rows hold four
 // entries, further ones (skewed input only) go to an overflow list that is grouped by bucket.
 // The histogram kernel walks its bucket's table rows and overflow entries.  Still exact, still
 // deterministic in its result (integer adds commute), no capacity estimates, and skew needs no
 // special layout: a bucket that receives everything simply owns more chunks.
 //
 //   C3  chunk_scatter_kernel<K>   ASCII -> 16-bit keys in chunks (LDS staging as in A3)
+//   C3' chunk_key_lines_kernel    level 2 of k = 13..16: 24-bit residuals -> keys in chunks, aligned 128-byte lines
+//       chunk_key_scatter_kernel  the same with per-tile runs (KPAL_LEVEL2=1)
 //   C4a chunk_plan_kernel         scan of the overflow counts per bucket, slice plan for C5
 //   C4b chunk_list_kernel         overflow entries grouped by bucket (empty for unskewed input)
 //   C5  chunk_hist_kernel<KB>     LDS histogram over a bucket's chunks, merge into the table

@@ -4,7 +4,8 @@
 //   strand balance     kmer.get_balance score     kpal/kmer.py:243-245
 //   pair distance      metrics.multiset/euclidean kpal/metrics.py:101-135
 //   distance matrix    kdistlib.distance_matrix   kpal/kdistlib.py:179-186
-// All are HBM-bandwidth kernels except the matrix, which is fp64-divide bound.
+// All are HBM-bandwidth kernels except the matrix, which is fp64-VALU bound (register tiles fed from
+// LDS-staged 16 x 16 super-tiles; a 6-instruction division for the operands of real profiles).
 // fp64 sums are reduced in a FIXED order (per-thread serial, wave shuffle tree, block tree,
 // then a single-workgroup pass over the per-block partials) so results are run-to-run
 // reproducible; they agree with NumPy's pairwise summation to ~1e-15 relative.
