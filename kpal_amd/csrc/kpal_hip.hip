@@ -776,7 +776,11 @@ static void staged_memcpy(void *dst, const void *src, size_t n)
         const size_t off = (size_t)i * part;
         if (off >= n) break;
         const size_t len = std::min(part, n - off);
-        workers.emplace_back([=] { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len); });
+        try {
+            workers.emplace_back([=] { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len); });
+        } catch (...) {   // no thread to be had: copy this part here (no exception may cross the C-ABI)
+            memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len);
+        }
     }
     memcpy(dst, src, std::min(part, n));
     for (auto &w : workers) w.join();
