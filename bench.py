@@ -74,6 +74,8 @@ def main():
     ap.add_argument('--strategy', default='auto')
     ap.add_argument('--cpu-reads', type=int, default=4_000_000, help='reads in the CPU-baseline sample')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: --reads is the TOTAL, split over the GPUs (default: weak, --reads per GPU)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -97,10 +99,15 @@ def main():
 
     ctx = _native.Context(local_rank)
     k, L = args.k, args.read_len
-    n_reads = args.reads
-    nbytes = n_reads * (L + 1)
     seed = 2 if world == 1 else 3
-    first_read = rank * n_reads                         # shard s = reads [s*R, (s+1)*R)
+    if args.strong:
+        first_read, n_reads = kdist.shard_range(args.reads, rank, world)   # fixed total, contiguous shards
+        total_reads = args.reads
+    else:
+        n_reads = args.reads
+        first_read = rank * n_reads                     # shard s = reads [s*R, (s+1)*R)
+        total_reads = world * n_reads
+    nbytes = n_reads * (L + 1)
     dev_buf = ctx.alloc(nbytes)
     ctx.synth_reads_device(seed, first_read, n_reads, L, dev_buf)
     ctx.sync()
@@ -150,11 +157,11 @@ def main():
         import numpy as np
         out = np.empty(bins, dtype=np.int64)
         ctx.d2h(out, table_ptr)
-        ok = int(out.sum()) == 2 * world * n_reads * (L - k + 1)
+        ok = int(out.sum()) == 2 * total_reads * (L - k + 1)
 
     if rank == 0:
         steps = max(args.steps, 1)
-        bases_per_step = world * n_reads * L
+        bases_per_step = total_reads * L
         ms_per_step = elapsed / steps * 1e3
         value = bases_per_step / (elapsed / steps) / 1e9
         # roofline of the dominant kernel (HIP events on the launch stream, this rank)
@@ -179,7 +186,7 @@ def main():
         line = {
             'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': value, 'unit': 'Gbases/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
             'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count%s+balance'
                                    % (k, n_reads, L, '+RCCL reduce' if world > 1 else ''),
                        'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy,
