@@ -311,42 +311,55 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
     pos[mine] = 0;
     __syncthreads();
     const uint64_t total_steps = (s.nchunks + 63) / 64;
-    const uint64_t steps_per_wave = steps_per_block / kScatterWaves;
-    const uint64_t block_step0 = (uint64_t)blockIdx.x * steps_per_block;
-    const uint64_t step0 = block_step0 + (uint64_t)wave * steps_per_wave;
-    Chunk carry = load_chunk(s, (int64_t)(step0 * 64) - 1);
-    // the tile's three 16-byte chunks per lane are fetched one tile ahead, so the loads fly during
-    // the copy-out of the previous tile (measured: 6 % faster)
+    // Tile j of this workgroup is tile j * G + blockIdx.x of the input, wave w takes its steps 3w .. 3w+2: at any
+    // moment the whole grid reads one sliding window of G * 24 KiB (12 MiB) instead of 4096 separate streams
+    // spread over the whole piece -- a handful of pages instead of hundreds, which the scatter's own 2500 pages of
+    // open chunks leave little translation-cache room for (piece sizes whose streams happened to collide there ran
+    // up to 1.6x slower).  The price: the chunk left of a tile is fetched per tile (one uniform 16-byte load).
+    const uint64_t tiles_per_block = steps_per_block / (kScatterWaves * kScatterSteps);
+    auto tile_step = [&](uint64_t j) -> uint64_t {
+        return ((j * gridDim.x + blockIdx.x) * kScatterWaves + (uint64_t)wave) * kScatterSteps;
+    };
+    const int lane = threadIdx.x & 63;
     uint4 raw[kScatterSteps];
+    uint4 rawh;   // the 16 bytes left of the tile's first chunk (same for every lane)
+    {
+        const uint64_t f = tile_step(0);
 #pragma unroll
-    for (int st = 0; st < kScatterSteps; ++st) raw[st] = fetch_chunk(s, (int64_t)((step0 + st) * 64 + (threadIdx.x & 63)));
-    for (uint64_t t = 0; t < steps_per_wave; t += kScatterSteps) {
-        if (block_step0 + t >= total_steps) break;  // block-uniform: wave 0 owns the lowest addresses
+        for (int st = 0; st < kScatterSteps; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+        rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
+    }
+    for (uint64_t j = 0; j < tiles_per_block; ++j) {
+        const uint64_t first = tile_step(j);
+        if ((j * gridDim.x + blockIdx.x) * (uint64_t)(kScatterWaves * kScatterSteps) >= total_steps) break;  // block-uniform
+        Chunk carry = encode16(rawh);
+        range_fix(s, (int64_t)(first * 64) - 1, carry);
         uint64_t window[kScatterSteps];
         uint32_t mask[kScatterSteps];
 #pragma unroll
-        for (int st = 0; st < kScatterSteps; ++st) encode_step<K>(s, step0 + t + st, raw[st], carry, window[st], mask[st]);
+        for (int st = 0; st < kScatterSteps; ++st) encode_step<K>(s, first + st, raw[st], carry, window[st], mask[st]);
         uint32_t smax = 0;
 #pragma unroll
         for (int st = 0; st < kScatterSteps; ++st) {
             uint32_t v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = chunk_scramble<KB>(kmer_at<K>(window[st], j));
+            for (int jj = 0; jj < 16; ++jj) v[jj] = chunk_scramble<KB>(kmer_at<K>(window[st], jj));
             smax = max(smax, place16_chunked<KB>(rows, pos, gcur, nextc, keys, v, mask[st]));
         }
         if (smax >= kChunkKeys) tile_over = 1;   // benign race: every writer stores 1
         __syncthreads();
-        if (t + kScatterSteps < steps_per_wave) {
+        if (j + 1 < tiles_per_block) {           // the next tile's chunks fly during the copy-out
+            const uint64_t f = tile_step(j + 1);
 #pragma unroll
-            for (int st = 0; st < kScatterSteps; ++st)
-                raw[st] = fetch_chunk(s, (int64_t)((step0 + t + kScatterSteps + st) * 64 + (threadIdx.x & 63)));
+            for (int st = 0; st < kScatterSteps; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+            rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
         }
         if (tile_over) {   // block-uniform, pathological input only: forget the tile, count it after the loop
             pos[mine] = 0;
             __syncthreads();
             if (threadIdx.x == 0) {
                 tile_over = 0;
-                defer_tile(defer_t, defer_n, (uint32_t)(t / kScatterSteps), p->error);
+                defer_tile(defer_t, defer_n, (uint32_t)j, p->error);
             }
             __syncthreads();
             continue;
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(kScatterThreads, 4) void chunk_scatter_kernel(Span 
     unsigned long long pend_cnt = 0;
     for (uint32_t i = 0; i < defer_n; ++i)
         for (uint32_t q = 0; q < defer_t[i].count; ++q)
-            chunk_count_tile_direct<K>(s, step0 + (uint64_t)(defer_t[i].first + q) * kScatterSteps, table, pend_hot, pend_cnt);
+            chunk_count_tile_direct<K>(s, tile_step((uint64_t)defer_t[i].first + q), table, pend_hot, pend_cnt);
     if (pend_cnt && (threadIdx.x & 63) == 0) atomicAdd(&table[pend_hot], pend_cnt);
 }
 

@@ -83,6 +83,7 @@ struct kpal_ctx {
     DevBuf table;  // int64[4^k]
     uint64_t bins = 0;
     size_t batch_bytes = (size_t)1 << 30;
+    bool batch_bytes_set = false;            // KPAL_BATCH_BYTES given (else the chunked path uses its own maximum)
     uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
@@ -276,7 +277,10 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
     }
     if (const char *e = getenv("KPAL_BATCH_BYTES")) {
         unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= (1ULL << 20)) ctx->batch_bytes = (size_t)v;
+        if (v >= (1ULL << 20)) {
+            ctx->batch_bytes = (size_t)v;
+            ctx->batch_bytes_set = true;
+        }
     }
     if (const char *e = getenv("KPAL_LEVEL2")) ctx->level2_mode = atoi(e);
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
@@ -570,6 +574,7 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
     const uint32_t G = (uint32_t)((total_steps + spb - 1) / spb);
     // chunks per workgroup, worst case: spb*1024/4096 full ones + a partly filled and a
     // pre-assigned next one per bucket (+ slack)
+    // (the stride of the ranges is harmless except at exact powers of two: R = 2048 -> 16 MiB costs 10 %)
     const uint64_t R = spb * 1024 / kChunkKeys + 2 * kNumBuckets + 64;
     ChunkLaunch cl;
     CHK(chunk_prepare(ctx, 1, G, R, cl));
@@ -705,7 +710,19 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
-    else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) piece = std::min<size_t>(ctx->batch_bytes, (size_t)1 << 30);   // chunk ids < 2^20
+    else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) {
+        // as large as the 20-bit chunk ids allow (G workgroups x R chunks each < 2^20, R = steps/4 + 1088 in
+        // launch_partition_chunked): every piece ends with a merge of the whole table and four launches.
+        // 1.86 GiB on 256 CUs; KPAL_BATCH_BYTES lowers it.
+        const uint64_t G = (uint64_t)ctx->num_cu * 2;
+        const uint64_t r_max = ((1ull << kChunkIdBits) - 1) / G;
+        const uint64_t fixed = 2 * kNumBuckets + 64;
+        uint64_t spb_max = r_max > fixed + 64 ? (r_max - fixed) * (kChunkKeys / 1024) : 64;
+        spb_max = spb_max > 3 * kStepsPerBlockQuantum ? spb_max - 2 * kStepsPerBlockQuantum : spb_max;   // margin: the halo may add a step
+        spb_max = spb_max / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+        const size_t cap = (size_t)(spb_max * G * 1024);
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
+    }
     else if (strat == KPAL_STRATEGY_PARTITION2) {
         // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
         // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
