@@ -171,3 +171,34 @@ def test_kmer_caller_host_logic():
         kmer.merge(one, empty, memh5.File())
     with pytest.raises(KeyError):
         kmer.balance(one, memh5.File(), names=['missing'])
+
+
+def test_pmc_summary_tool(tmp_path):
+    """tools/pmc_summary.py: per-kernel bytes per dispatch from two rocprofv3 counter passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, both in KB) and the input bytes per launch from the dispatch count of the named kernel."""
+    import json
+    header = 'Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n'
+
+    def rows(counter, values):
+        out = []
+        for i, (name, v) in enumerate(values):
+            out.append('%d,%d,1,1,1,1,1,1,"%s",256,0,0,8,0,16,%s,%s,0,1\n' % (i, i, name, counter, v))
+        return header + ''.join(out)
+
+    scatter = 'void kpal::chunk_scatter_kernel<12>(kpal::Span, unsigned long)'
+    hist = 'void kpal::chunk_hist_kernel<15>(kpal::ChunkPool)'
+    (tmp_path / 'f').mkdir()
+    (tmp_path / 'w').mkdir()
+    (tmp_path / 'f' / 'x_counter_collection.csv').write_text(rows('FETCH_SIZE', [(scatter, 1000), (hist, 500), (scatter, 3000)]))
+    (tmp_path / 'w' / 'x_counter_collection.csv').write_text(rows('WRITE_SIZE', [(scatter, 100), (hist, 10), (scatter, 300)]))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), str(tmp_path / 'f'), str(tmp_path / 'w'),
+                        '4000000', 'note', 'chunk_scatter'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    d = json.loads(p.stdout.decode())
+    assert d['launches'] == 2 and d['input_bytes_per_launch_avg'] == 2000000.0
+    s = d['kernels']['kpal::chunk_scatter_kernel<12>']
+    assert s['dispatches'] == 2 and s['FETCH_SIZE'] == 2000.0 and s['WRITE_SIZE'] == 200.0
+    assert s['hbm_bytes_per_dispatch_corrected'] == (2 * 2000.0 + 200.0) * 1024
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), str(tmp_path / 'f'), str(tmp_path / 'w'),
+                          '4000000', 'note', 'no_such_kernel'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode != 0
