@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity stress (developer tool, GPU box): random k, sizes (log-uniform 1 B .. 96 MB),
 compositions, separator densities, low-complexity stretches, feed kinds and strategies against the
-oracle.   python tools/stress.py [--seconds 150] [--seed 1]"""
+oracle.   python tests/stress_count.py [--seconds 150] [--seed 1]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

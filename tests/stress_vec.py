@@ -2,7 +2,7 @@
 """Randomised parity stress of the vector side (developer tool, GPU box): balance, split, strand
 balance, summaries / merge / shrink, every ProfileDistance option combination and the distance matrix
 against the oracle.
-    python tools/stress_vec.py [--seconds 90] [--seed 1]"""
+    python tests/stress_vec.py [--seconds 90] [--seed 1]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Developer harness for BASELINE config 5: P profiles at k, counted from synthetic reads
-(seed 100+p), kdistlib.distance_matrix values on the GPU; checks a few pairs against the oracle.
+(seed 100+p), kdistlib.distance_matrix values on the GPU; cross-checks a few pairs against kpal_pair_distance.
     python tools/mbench.py [--P 64] [--k 12] [--reads 2000000] [--metric prod] [--balance]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,11 +42,11 @@ for name, (ms, cnt) in sorted(ctx.prof_get().items()):
 pairs = a.P * (a.P - 1) // 2
 print('matrix P=%d k=%d metric=%s balance=%s: %.1f ms wall, %d pairs, %.1f Gterms/s, profiles read %.2f GB' % (
     a.P, a.k, a.metric, a.balance, wall * 1e3, pairs, pairs * n / wall / 1e9, a.P * n * 8 / 1e9))
-import oracle
+# cross-check against the pair kernel (IEEE divisions, other summation order); the oracle comparisons live in tests/
 worst = 0.0
 for i in range(1, min(a.check + 1, a.P)):
     for j in range(i):
-        want = oracle.distance(host[i], host[j], a.k, do_balance=a.balance, metric=a.metric)
+        want = ctx.pair_distance(host[i], host[j], metric, do_balance=a.balance, k=a.k)
         got = vals[i * (i - 1) // 2 + j]
         worst = max(worst, abs(got - want) / abs(want) if want else abs(got))
-print('max rel err vs oracle on %d pairs: %.3g' % (min(a.check, a.P - 1) * (min(a.check, a.P - 1) + 1) // 2, worst))
+print('max rel difference vs kpal_pair_distance on %d pairs: %.3g' % (min(a.check, a.P - 1) * (min(a.check, a.P - 1) + 1) // 2, worst))
