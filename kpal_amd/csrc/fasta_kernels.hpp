@@ -9,7 +9,10 @@
 // Rules (same as kpal_amd.klib._fasta_records, the host-side tokeniser):
 //   * a line is a header iff its first byte is '>'; lines end at '\n' or '\r';
 //   * the header's '>' becomes the record separator '\n', the rest of the header line is dropped;
-//   * in sequence lines all ASCII whitespace (space, \t, \n, \v, \f, \r) is dropped;
+//   * in sequence lines (Biopython's SimpleFastaParser: line.rstrip(), then ' ' and '\r' removed from the
+//     joined record) spaces and line ends are dropped everywhere, other whitespace (\t, \v, \f, 0x1c..0x1f, 0x85, 0xa0)
+//     only where it trails its line; an interior tab stays and separates k-mer windows like any byte
+//     outside the alphabet (kpal/klib.py:152-156);
 //   * the buffer handed to these kernels starts at a header (the host skips anything before the
 //     first header, like Biopython does).
 // Whether byte i is inside a header depends only on the first byte of its line, i.e. on the last
@@ -27,7 +30,18 @@ constexpr int kFaPerThread = 16;
 constexpr int kFaBlockBytes = kFaThreads * kFaPerThread;  // 4 KiB per workgroup
 
 __device__ __forceinline__ bool fa_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
-__device__ __forceinline__ bool fa_is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+// whitespace that str.rstrip() removes at the end of a line but that stays inside it
+__device__ __forceinline__ bool fa_is_soft_space(uint8_t c) { return c == 9 || c == 11 || c == 12 || (c >= 28 && c <= 31) || c == 0x85 || c == 0xA0; }   // str.isspace() of a latin-1 text handle
+// true iff only whitespace follows byte i on its line (rare bytes: a forward walk per occurrence)
+__device__ __forceinline__ bool fa_trailing(const uint8_t *__restrict__ in, uint64_t n, uint64_t i)
+{
+    for (uint64_t j = i + 1; j < n; ++j) {
+        const uint8_t d = in[j];
+        if (fa_is_eol(d)) return true;
+        if (d != ' ' && !fa_is_soft_space(d)) return false;
+    }
+    return true;
+}
 
 // inclusive prefix-max of one int64 per thread over a 256-thread workgroup; returns the exclusive
 // value for this thread (max over lower threads, or `seed`)
@@ -110,7 +124,7 @@ __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint
                 keep |= 1u << j;
                 out[j] = '\n';
             }
-        } else if (!fa_is_space(c)) {
+        } else if (c != ' ' && !fa_is_eol(c) && !(fa_is_soft_space(c) && fa_trailing(in, n, i))) {
             keep |= 1u << j;
             out[j] = c;
         }

@@ -115,6 +115,7 @@ struct kpal_ctx {
     std::vector<uint64_t> prof_launches;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
+    uint64_t prof_dropped = 0;               // launches whose timing events could not be recorded
 };
 
 static int ensure(kpal_ctx *ctx, DevBuf &b, size_t bytes)
@@ -154,7 +155,7 @@ static hipEvent_t prof_event(kpal_ctx *ctx)
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -168,14 +169,22 @@ struct ProfScope {
             rec.name = prof_name_id(c, name);
             rec.a = prof_event(c);
             rec.b = prof_event(c);
-            (void)hipEventRecord(rec.a, c->stream);
+            // a launch that cannot be timed is still launched: the pair is dropped, the failure is counted
+            if (!rec.a || !rec.b || hipEventRecord(rec.a, c->stream) != hipSuccess) drop();
         }
+    }
+    void drop()
+    {
+        on = false;
+        ++ctx->prof_dropped;
+        if (rec.a) ctx->ev_pool.push_back(rec.a);
+        if (rec.b) ctx->ev_pool.push_back(rec.b);
     }
     ~ProfScope()
     {
         if (on) {
-            (void)hipEventRecord(rec.b, ctx->stream);
-            ctx->prof_pending.push_back(rec);
+            if (hipEventRecord(rec.b, ctx->stream) == hipSuccess) ctx->prof_pending.push_back(rec);
+            else drop();
         }
     }
 };
@@ -255,16 +264,10 @@ KPAL_API int kpal_device_count(int *n)
     return KPAL_OK;
 }
 
-KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
+// Everything of kpal_ctx_create that can fail after the context object exists: on an error the
+// caller destroys the half-built context (streams, events), nothing leaks.
+static int ctx_init(kpal_ctx *ctx, int device)
 {
-    if (!out) return set_err(KPAL_E_INVALID, "out is NULL");
-    *out = nullptr;
-    int n = 0;
-    HIPCHK(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return set_err(KPAL_E_INVALID, "device %d not in 0..%d", device, n - 1);
-    HIPCHK(hipSetDevice(device));
-    kpal_ctx *ctx = new (std::nothrow) kpal_ctx();
-    if (!ctx) return set_err(KPAL_E_NOMEM, "out of host memory");
     ctx->device = device;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -286,6 +289,27 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;
+    }
+    return KPAL_OK;
+}
+
+KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx);
+
+KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
+{
+    if (!out) return set_err(KPAL_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return set_err(KPAL_E_INVALID, "device %d not in 0..%d", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    kpal_ctx *ctx = new (std::nothrow) kpal_ctx();
+    if (!ctx) return set_err(KPAL_E_NOMEM, "out of host memory");
+    const int rc = ctx_init(ctx, device);
+    if (rc != KPAL_OK) {
+        ctx->device = device;
+        kpal_ctx_destroy(ctx);   // keeps g_err: it only releases what was created
+        return rc;
     }
     *out = ctx;
     return KPAL_OK;
@@ -1701,6 +1725,7 @@ KPAL_API int kpal_prof_reset(kpal_ctx *ctx)
     CHK(prof_collect(ctx));
     std::fill(ctx->prof_ms.begin(), ctx->prof_ms.end(), 0.0);
     std::fill(ctx->prof_launches.begin(), ctx->prof_launches.end(), 0);
+    ctx->prof_dropped = 0;
     return KPAL_OK;
 }
 
@@ -1709,6 +1734,8 @@ KPAL_API int kpal_prof_count(kpal_ctx *ctx, int *n_kernels)
     CTX_ENTER(ctx);
     CHK(prof_collect(ctx));
     if (n_kernels) *n_kernels = (int)ctx->prof_names.size();
+    if (ctx->prof_dropped)   // totals would silently miss launches: say so instead
+        return set_err(KPAL_E_HIP, "%llu launches could not be timed (hipEventRecord failed)", (unsigned long long)ctx->prof_dropped);
     return KPAL_OK;
 }
 

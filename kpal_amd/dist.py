@@ -58,11 +58,3 @@ def count_synth_sharded(ctx, k, seed, n_reads_total, read_len, rank, world_size,
         if own:
             ctx.free(dev_buf)
     return first, n
-
-
-def merge_host_counts(parts):
-    """Host-side equivalent of the reduce for already-downloaded tables (tests)."""
-    out = np.zeros_like(parts[0])
-    for p in parts:
-        out += p
-    return out

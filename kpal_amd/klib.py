@@ -29,11 +29,14 @@ _FEED_BYTES = 32 << 20  # host-side join buffer per feed
 _JOIN_BLOCK = 4096       # sequences joined per C-level call
 _RECORD_BATCH_BYTES = 1 << 30   # tables downloaded per from_fasta_by_record batch
 _FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
-_WHITESPACE = {ord(c): None for c in ' \t\n\v\f\r'}
+_DROPPED = {ord(' '): None, ord('\r'): None}   # removed from the joined record (Biopython's SimpleFastaParser)
 
 
 def _fasta_records(handle):
-    """Yield ``(name, sequence)`` per FASTA record."""
+    """Yield ``(name, sequence)`` per FASTA record, tokenised like ``Bio.SeqIO.parse(handle, 'fasta')``
+    (what kpal/klib.py:111 delegates to): text before the first ``>`` is skipped, the name is the
+    first word of the title, every sequence line is ``rstrip()``-ed and the joined record loses its
+    spaces and ``\\r`` -- whitespace such as a tab INSIDE a line stays and separates k-mer windows."""
     name = None
     parts = []
     for line in handle:
@@ -41,14 +44,14 @@ def _fasta_records(handle):
             line = line.decode('ascii', 'replace')
         if line.startswith('>'):
             if name is not None:
-                yield name, ''.join(parts)
+                yield name, ''.join(parts).translate(_DROPPED)
             title = line[1:].strip()
             name = title.split(None, 1)[0] if title else ''
             parts = []
         elif name is not None:
-            parts.append(line.translate(_WHITESPACE))
+            parts.append(line.rstrip())
     if name is not None:
-        yield name, ''.join(parts)
+        yield name, ''.join(parts).translate(_DROPPED)
 
 
 def _first_boundary(text):
@@ -313,16 +316,25 @@ class Profile(object):
             self.counts = merger(self.counts, profile.counts)     # user callable / float profiles: as the reference
 
     # ---- hot path: balance / split ------------------------------------------------------------
-    def _int64_counts(self):
-        c = np.asanyarray(self.counts)
-        if c.dtype.kind not in 'iub':
-            raise TypeError('balance/split need integer counts (got %s)' % c.dtype)
-        return c
+    def _rc_index(self):
+        """rc(i) for every i (vectorised form of reverse_complement, kpal/klib.py:394-412)."""
+        k = self.length
+        i = np.arange(4 ** k, dtype=np.uint64)
+        rc = np.zeros_like(i)
+        comp = ~i
+        for d in range(k):
+            rc |= ((comp >> np.uint64(2 * d)) & np.uint64(3)) << np.uint64(2 * (k - 1 - d))
+        return rc.astype(np.int64)
 
     def balance(self):
         """``counts[i] += counts[rc(i)]`` for every k-mer, palindromes doubled, in place
-        (kpal/klib.py:285-298) -- one HIP kernel."""
-        c = self._int64_counts()
+        (kpal/klib.py:285-298) -- one HIP kernel for integer counts.  Non-integer counts (a scaled
+        profile) cannot enter the integer kernel: they take the same sums as one NumPy expression, in
+        the dtype of ``counts`` like the reference's loop."""
+        c = np.asanyarray(self.counts)
+        if c.dtype.kind not in 'iub':
+            c[...] = c + c[self._rc_index()]
+            return
         if c.dtype == np.int64 and c.flags['C_CONTIGUOUS'] and c.flags['WRITEABLE']:
             _native.context().balance_inplace(c, self.length)
         else:
@@ -332,8 +344,17 @@ class Profile(object):
 
     def split(self):
         """Doubled forward / reverse-complement halves in ascending k-mer order
-        (kpal/klib.py:300-327) -- ``kpal_split``."""
-        return _native.context().split(self._int64_counts(), self.length)
+        (kpal/klib.py:300-327) -- ``kpal_split``; NumPy for non-integer counts."""
+        c = np.asanyarray(self.counts)
+        if c.dtype.kind not in 'iub':
+            rc = self._rc_index()
+            i = np.arange(c.size)
+            lower, pal = i < rc, i == rc
+            keep = lower | pal
+            forward = np.where(pal, c, c * 2)[keep]
+            reverse = np.where(pal, c, c[rc] * 2)[keep]
+            return forward, reverse
+        return _native.context().split(c, self.length)
 
     # ---- container helpers ----------------------------------------------------------------------
     def shrink(self, factor=1):

@@ -569,39 +569,43 @@ ORACLE_API int kpal_oracle_count_piece(const uint8_t *buf, size_t begin, size_t 
     return 0;
 }
 
-/* All-cores variant of the count (baseline + at-scale oracle): T pthreads, each counts one
- * piece of the stream into a private histogram (kpal_oracle_count_piece), then the T
- * histograms are summed into `counts` in parallel over bin ranges.  Integer adds: the result
- * is identical to the sequential scan. */
+/* All-cores variant of the count (baseline + at-scale oracle): T pthreads, each scans one piece
+ * of the stream with the reference's rolling window (kpal/klib.py:157-168).
+ *   - small tables (4^k * 8 B <= 1 MiB, k <= 8): a private histogram per thread (stays in the
+ *     core's L2), summed into `counts` at the end;
+ *   - larger tables: ONE shared table, every increment a relaxed atomic add.  Replicating a
+ *     128 MiB (k = 12) or 8 GiB (k = 15) table per thread makes the baseline measure calloc and
+ *     the merge instead of counting; the shared table costs one locked add per k-mer, which at
+ *     these sizes is a cache miss either way.
+ * Integer adds: the result is identical to the sequential scan in both forms. */
 typedef struct {
     const uint8_t *buf;
     size_t begin, end;
     int k;
     int64_t *hist;
+    int shared;
 } count_job;
+
+static void count_piece_shared(const uint8_t *buf, size_t begin, size_t end, int k, int64_t *counts)
+{
+    const uint64_t bitmask = (k >= 32) ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
+    size_t i = begin >= (size_t)(k - 1) ? begin - (size_t)(k - 1) : 0;
+    uint64_t binary = 0;
+    size_t run = 0;
+    for (; i < end; i++) {
+        int code = nucleotide_to_binary(buf[i]);
+        if (code < 0) { run = 0; binary = 0; continue; }
+        binary = ((binary << 2) | (uint64_t)code) & bitmask;
+        run++;
+        if (run >= (size_t)k && i >= begin) __atomic_fetch_add(&counts[binary], 1, __ATOMIC_RELAXED);
+    }
+}
 
 static void *count_worker(void *arg)
 {
     count_job *j = (count_job *)arg;
-    kpal_oracle_count_piece(j->buf, j->begin, j->end, j->k, j->hist);
-    return NULL;
-}
-
-typedef struct {
-    int64_t **hists;
-    int T;
-    size_t b0, b1;
-    int64_t *out;
-} merge_job;
-
-static void *merge_worker(void *arg)
-{
-    merge_job *m = (merge_job *)arg;
-    for (size_t i = m->b0; i < m->b1; i++) {
-        int64_t s = 0;
-        for (int t = 0; t < m->T; t++) s += m->hists[t][i];
-        m->out[i] += s;
-    }
+    if (j->shared) count_piece_shared(j->buf, j->begin, j->end, j->k, j->hist);
+    else kpal_oracle_count_piece(j->buf, j->begin, j->end, j->k, j->hist);
     return NULL;
 }
 
@@ -610,33 +614,32 @@ ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, in
     if (k < 1 || k > 31 || threads < 1) return -1;
     const size_t bins = (size_t)1 << (2 * k);
     int T = threads > 256 ? 256 : threads;
+    const int shared = bins * sizeof(int64_t) > ((size_t)1 << 20);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
     count_job *jobs = (count_job *)malloc(sizeof(count_job) * T);
-    merge_job *mj = (merge_job *)malloc(sizeof(merge_job) * T);
-    int64_t **hists = (int64_t **)malloc(sizeof(int64_t *) * T);
+    int64_t **hists = (int64_t **)calloc(T, sizeof(int64_t *));
+    if (!th || !jobs || !hists) return -2;
     for (int t = 0; t < T; t++) {
-        hists[t] = (int64_t *)calloc(bins, sizeof(int64_t));
-        if (!hists[t]) return -2;
+        if (!shared) {
+            hists[t] = (int64_t *)calloc(bins, sizeof(int64_t));
+            if (!hists[t]) return -2;
+        }
         jobs[t].buf = buf;
         jobs[t].begin = n * (size_t)t / T;
         jobs[t].end = n * (size_t)(t + 1) / T;
         jobs[t].k = k;
-        jobs[t].hist = hists[t];
+        jobs[t].hist = shared ? counts : hists[t];
+        jobs[t].shared = shared;
         pthread_create(&th[t], NULL, count_worker, &jobs[t]);
     }
     for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
-    for (int t = 0; t < T; t++) {
-        mj[t].hists = hists;
-        mj[t].T = T;
-        mj[t].b0 = bins * (size_t)t / T;
-        mj[t].b1 = bins * (size_t)(t + 1) / T;
-        mj[t].out = counts;
-        pthread_create(&th[t], NULL, merge_worker, &mj[t]);
+    if (!shared) {
+        for (int t = 0; t < T; t++) {
+            for (size_t i = 0; i < bins; i++) counts[i] += hists[t][i];
+            free(hists[t]);
+        }
     }
-    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
-    for (int t = 0; t < T; t++) free(hists[t]);
     free(hists);
-    free(mj);
     free(jobs);
     free(th);
     return 0;

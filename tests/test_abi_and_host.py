@@ -202,3 +202,39 @@ def test_pmc_summary_tool(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), str(tmp_path / 'f'), str(tmp_path / 'w'),
                           '4000000', 'note', 'no_such_kernel'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode != 0
+
+
+def test_balance_split_of_scaled_profiles_without_gpu():
+    """Float counts (a profile multiplied by a scale factor) never enter the integer kernels:
+    balance / split follow the reference's loops (kpal/klib.py:285-327) in NumPy, in the counts'
+    dtype, like merge / shrink / the summaries do."""
+    import oracle
+    from kpal_amd import klib
+    rs = np.random.RandomState(3)
+    for k in (1, 2, 4):
+        c = rs.poisson(5, 4 ** k) * 0.37
+        want = c.copy()
+        fwd, rev = [], []
+        for i in range(4 ** k):
+            r = oracle.reverse_complement(i, k)
+            if i < r:
+                want[i], want[r] = c[i] + c[r], c[r] + c[i]
+                fwd.append(c[i] * 2)
+                rev.append(c[r] * 2)
+            elif i == r:
+                want[i] = c[i] + c[i]
+                fwd.append(c[i])
+                rev.append(c[i])
+        p = klib.Profile(c.copy())
+        p.balance()
+        np.testing.assert_array_equal(p.counts, want)
+        f, r_ = klib.Profile(c.copy()).split()
+        np.testing.assert_array_equal(f, np.array(fwd))
+        np.testing.assert_array_equal(r_, np.array(rev))
+
+
+def test_fasta_records_follow_seqio_rules():
+    """Bio.SeqIO tokenising (kpal/klib.py:111): rstrip per line, ' ' and '\\r' removed, interior tabs stay."""
+    from kpal_amd import klib
+    text = 'junk\n>r1 desc\nAC\tG T\t\n A\n>\n\tNN \n>r3\n'
+    assert list(klib._fasta_records(io.StringIO(text))) == [('r1', 'AC\tGTA'), ('', '\tNN'), ('r3', '')]

@@ -197,9 +197,9 @@ def test_two_level_batch_halving():
     buf = oracle.synth_reads(47, 0, 6000, 150, noisy=True)
     seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
     homo = np.frombuffer(b'A' * 300000 + b'C' * 17 + b'N' + b'ACGT' * 5000, dtype=np.uint8)
-    for k in (13, 14):
+    for k in (13, 14, 15):
         for data in (buf, seq, homo):
-            np.testing.assert_array_equal(c2.count_bytes(k, data), oracle.count_flat(data, k, threads=4))
+            assert np.array_equal(c2.count_bytes(k, data, 'partition2'), oracle.count_flat(data, k, threads=4)), k
     c2.close()
 
 
@@ -348,32 +348,98 @@ def test_full_size_properties_k12(ctx, k, n_reads):
         bal = np.empty(bins, dtype=np.int64)
         ctx.d2h(bal, ptr)
         assert bal.sum() == 2 * full.sum()
-        np.testing.assert_array_equal(bal[:4096], oracle.balance(full, k)[:4096])
+        np.testing.assert_array_equal(bal, oracle.balance(full, k))   # every bin (klib.py:285-298)
     finally:
         ctx.free(d)
 
 
 def test_full_size_k15(ctx):
-    """BASELINE config 4 (k = 15, 8 GiB table) on 20 M reads: exact total and linearity."""
-    k, n_reads = 15, 20_000_000
+    """BASELINE config 4 at its stated size (k = 15, 100 M x 150 bp reads, seed 4, 8 GiB table) through
+    AUTO (two-level path: coarse_scatter<15> -> chunk_key_lines -> chunk_hist at 64 coarse buckets):
+    exact total, linearity over two shards (compared on the device), bin for bin against the oracle on
+    a 2 M-read prefix and against the global-atomic kernel on a 10 M-read prefix."""
+    torch = pytest.importorskip('torch')
+    from kpal_amd import _native, dist
+    k, n_reads = 15, 100_000_000
     nbytes = n_reads * 151
     d = ctx.alloc(nbytes)
+    other = _native.Context(ctx.device)
     try:
         ctx.synth_reads_device(4, 0, n_reads, 150, d)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
-        full = ctx.count_finish()
-        assert full.sum() == n_reads * (150 - k + 1)
-        half = 10_000_000
+        ctx.count_finish(to_host=False)
+        ctx.sync()
+        full = dist.table_as_tensor(ctx)
+        assert full.numel() == 4 ** k
+        assert int(full.sum()) == n_reads * (150 - k + 1)
+        assert int(full.min()) >= 0
+        # linearity: the two half-shards counted by a second context add up to the same table
+        half = n_reads // 2
+        other.count_begin(k)
+        other.count_feed_device(d, half * 151)
+        other.count_finish(to_host=False)
+        other.sync()
+        acc = dist.table_as_tensor(other).clone()
+        torch.cuda.synchronize()                 # torch's stream is not the context's: the copy must be done before the table is zeroed
+        other.count_begin(k)
+        other.count_feed_device(d + half * 151, half * 151)
+        other.count_finish(to_host=False)
+        other.sync()
+        acc += dist.table_as_tensor(other)
+        assert torch.equal(acc, full)
+        del acc
+        torch.cuda.synchronize()
+        # bin for bin with the global-atomic kernel on a 10 M-read prefix (both tables stay on the device)
+        pre10 = 10_000_000 * 151
         ctx.count_begin(k)
-        ctx.count_feed_device(d, half * 151)
-        a = ctx.count_finish()
+        ctx.count_feed_device(d, pre10)
+        ctx.count_finish(to_host=False)
+        other.count_begin(k, 'global_atomic')
+        other.count_feed_device(d, pre10)
+        other.count_finish(to_host=False)
+        ctx.sync()
+        other.sync()
+        assert torch.equal(dist.table_as_tensor(ctx), dist.table_as_tensor(other))
+        torch.cuda.synchronize()
+        # bin for bin with the oracle on a 2 M-read prefix
+        pre = np.empty(2_000_000 * 151, dtype=np.uint8)
+        ctx.d2h(pre, d)
         ctx.count_begin(k)
-        ctx.count_feed_device(d + half * 151, half * 151)
-        a += ctx.count_finish()
-        assert np.array_equal(a, full)
+        ctx.count_feed_device(d, pre.size)
+        got = ctx.count_finish()
+        want = oracle.count_flat(pre, k, threads=8)
+        assert got.sum() == 2_000_000 * (150 - k + 1)
+        assert np.array_equal(got, want)
     finally:
+        other.close()
         ctx.free(d)
+
+
+@pytest.mark.parametrize('mode', ['0', '1', '2'])
+def test_two_level_k15_against_oracle(mode):
+    """k = 15 (64 coarse buckets) through every level-2 pipeline, on inputs large enough for AUTO to take
+    the two-level path (feeds above 256 KiB), bin for bin against the oracle: noisy reads, one unbroken
+    sequence, and skewed composition with a tile-abandoning homopolymer stretch."""
+    from kpal_amd import _native
+    os.environ['KPAL_LEVEL2'] = mode
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_LEVEL2']
+    rs = np.random.RandomState(int(mode) + 15)
+    buf = oracle.synth_reads(54, 0, 40000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    skew = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=5 << 20, p=[.4, .1, .1, .4])].copy()
+    skew[1 << 20:(1 << 20) + 700000] = ord('A')
+    skew[3 << 20:(3 << 20) + 300000] = np.resize(np.frombuffer(b'AC', dtype=np.uint8), 300000)
+    try:
+        for data in (buf, seq, skew):
+            got = c2.count_bytes(15, data, 'partition2')
+            assert np.array_equal(got, oracle.count_flat(data, 15, threads=8))
+            del got
+    finally:
+        c2.close()
 
 
 def test_partition_pipelines_on_skewed_inputs(ctx):

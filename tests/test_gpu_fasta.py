@@ -1,6 +1,7 @@
-"""FASTA ingest on the device (kpal_count_feed_fasta / kpal_fasta_flatten) against the host-side
-tokeniser kpal_amd.klib._fasta_records (the rules are listed in csrc/fasta_kernels.hpp) and the
-oracle's counts.  Run on the GPU box: pytest -m gpu."""
+"""FASTA ingest on the device (kpal_count_feed_fasta / kpal_fasta_flatten) against an independent
+restatement of the tokenising kPAL delegates to Bio.SeqIO.parse (kpal/klib.py:111; Biopython's
+SimpleFastaParser: skip text before the first '>', rstrip() every line, join, remove ' ' and '\\r')
+and the oracle's counts.  Run on the GPU box: pytest -m gpu."""
 import io
 import os
 import random
@@ -19,10 +20,31 @@ def ctx():
     return _native.context()
 
 
+def seqio_records(text):
+    """(name, sequence) per record by Biopython's rules, written independently of kpal_amd.klib:
+    universal newlines, lines before the first '>' skipped, name = first word of the title, every
+    sequence line rstrip()-ed, ' ' and '\\r' removed from the joined record -- so a tab inside a
+    line stays (and splits k-mer windows), a tab at the end of a line goes."""
+    import re
+    records, title, lines = [], None, []
+    for line in re.split('\r\n|\r|\n', text):
+        if line[:1] == '>':
+            if title is not None:
+                records.append((title, lines))
+            title, lines = line[1:].rstrip(), []
+        elif title is not None:
+            lines.append(line.rstrip())
+    if title is not None:
+        records.append((title, lines))
+    out = []
+    for title, lines in records:
+        words = title.split(None, 1)
+        out.append((words[0] if words else '', ''.join(lines).replace(' ', '').replace('\r', '')))
+    return out
+
+
 def expected_flat(text):
-    from kpal_amd import klib
-    recs = list(klib._fasta_records(io.StringIO(text, newline='')))   # newline='': keep \r as data
-    return b''.join(b'\n' + seq.encode('latin-1') for _, seq in recs)
+    return b''.join(b'\n' + seq.encode('latin-1') for _, seq in seqio_records(text))
 
 
 def random_fasta(rnd, n_records, max_len, eol='\n'):
@@ -40,7 +62,11 @@ def random_fasta(rnd, n_records, max_len, eol='\n'):
         for i in range(0, len(seq), width):
             line = seq[i:i + width]
             if rnd.random() < 0.1:
-                line = line[:len(line) // 2] + rnd.choice([' ', '\t', '  ']) + line[len(line) // 2:]
+                line = line[:len(line) // 2] + rnd.choice([' ', '\t', '  ', '\x0b', '\x0c']) + line[len(line) // 2:]
+            if rnd.random() < 0.08:
+                line += rnd.choice([' ', '\t', ' \t ', '\x0c'])      # trailing whitespace: stripped, k-mers join across the wrap
+            if rnd.random() < 0.03:
+                line = rnd.choice(['\t', ' ']) + line                # leading: a tab stays, a space goes
             parts.append(line + (eol if rnd.random() < 0.97 else eol + eol))
     text = ''.join(parts)
     if rnd.random() < 0.3:
@@ -51,7 +77,8 @@ def random_fasta(rnd, n_records, max_len, eol='\n'):
 def test_flatten_matches_host_tokeniser(ctx):
     rnd = random.Random(5)
     cases = ['', 'no header at all\nACGT\n', '>only header', '>h\n', '>h\nACGT', '>a\nAC\nGT\n>b\n\n>c\nTT',
-             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\n', 'x\n>a\nAC>GT\n>b\n A C\tG T \n']
+             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\n', 'x\n>a\nAC>GT\n>b\n A C\tG T \n',
+             '>t\nAC\tGT\n', '>t\nAC\t\nGT\n', '>t\nAC \t \nGT', '>t\n\tACGT\n', '>t\nAC\x0b\x0cGT\t\t\n\t\nAC\t']
     for _ in range(60):
         cases.append(random_fasta(rnd, rnd.randint(1, 12), 3000, eol=rnd.choice(['\n', '\n', '\r\n'])))
     for _ in range(6):
@@ -61,13 +88,23 @@ def test_flatten_matches_host_tokeniser(ctx):
         assert got == expected_flat(text), repr(text[:200])
 
 
+def test_interior_tab_separates_windows(ctx):
+    """'AC\\tGT' at k = 4: no k-mer in the reference (the tab stays in record.seq and splits the window,
+    kpal/klib.py:152-156); a tab at the END of a wrapped line is stripped and the window continues."""
+    from kpal_amd import klib
+    assert klib.Profile.from_fasta(io.StringIO('>r\nAC\tGT\n'), 4).total == 0
+    p = klib.Profile.from_fasta(io.StringIO('>r\nAC\t\nGT\n'), 4)
+    assert p.total == 1 and p.counts[int('0123', 4)] == 1
+    assert [r for r in klib._fasta_records(io.StringIO('>r x\nAC\tG T\t\nA\n'))] == [('r', 'AC\tGTA')]
+
+
 def test_from_fasta_counts(ctx, tutorial_dir):
     from kpal_amd import klib
     rnd = random.Random(9)
     for k in (3, 8, 12):
         text = random_fasta(rnd, 30, 5000)
         p = klib.Profile.from_fasta(io.StringIO(text), k)
-        seqs = [s for _, s in klib._fasta_records(io.StringIO(text))]
+        seqs = [s for _, s in seqio_records(text)]
         np.testing.assert_array_equal(p.counts, oracle.from_sequences(seqs, k))
     # binary handle and a real file (60-column wrapped tutorial data)
     path = os.path.join(tutorial_dir, 'a_1.fa')
@@ -83,7 +120,7 @@ def test_from_fasta_chunked_reads(ctx, monkeypatch):
     from kpal_amd import klib
     rnd = random.Random(13)
     text = random_fasta(rnd, 400, 900)
-    seqs = [s for _, s in klib._fasta_records(io.StringIO(text))]
+    seqs = [s for _, s in seqio_records(text)]
     want = oracle.from_sequences(seqs, 9)
     for chunk in (1 << 10, 4097, 1 << 16):
         monkeypatch.setattr(klib, '_FASTA_CHUNK', chunk)
@@ -91,7 +128,7 @@ def test_from_fasta_chunked_reads(ctx, monkeypatch):
         np.testing.assert_array_equal(p.counts, want)
     # CRLF line ends, bytes handle, chunks smaller than most records, junk before the first header
     text = 'junk line\r\n' + random_fasta(rnd, 60, 6000, eol='\r\n')
-    seqs = [s for _, s in klib._fasta_records(io.StringIO(text, newline=''))]
+    seqs = [s for _, s in seqio_records(text)]
     want = oracle.from_sequences(seqs, 7)
     for chunk in (257, 1 << 12, 1 << 20):
         monkeypatch.setattr(klib, '_FASTA_CHUNK', chunk)
@@ -117,7 +154,7 @@ def test_from_fasta_by_record_batched(ctx, monkeypatch):
     from kpal_amd import klib
     rnd = random.Random(21)
     text = '>r1 first\nACGTNACGT\n>\nAC\n>r3\n\n>r4\nA\n>r5\nC\n>r6\nGGGTTTAAACCC\n' + random_fasta(rnd, 300, 700)
-    recs = list(klib._fasta_records(io.StringIO(text)))
+    recs = seqio_records(text)
     for k in (1, 3, 8, 12):
         for batch in (1 << 30, 3 * 8 * 4 ** k):          # everything in a few batches / three records per batch
             monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', batch)

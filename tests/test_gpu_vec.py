@@ -281,3 +281,61 @@ def test_config5_matrix_k12_subset(ctx):
     got = ctx.distance_matrix(profs[:3], k, 0, do_balance=True)
     want = oracle.distance_matrix_values(profs[:3], k, True, 'prod')
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('n_reads', [2_000_000, 100_000], ids=['dense', 'sparse'])
+def test_config5_matrix_k12_64_profiles(ctx, n_reads):
+    """BASELINE config 5 at its stated size: 64 profiles at k = 12, profile p = the
+    count of n_reads synthetic reads with seed 100 + p (dense: 2 M reads, mean 16.6 per bin; sparse: 100 k
+    reads, ~43 % zero bins), kdistlib.distance_matrix values through kpal_distance_matrix_device (the
+    super-tile kernel) for prod / sum / euclidean with and without balancing (kdistlib.py:164-186):
+      * all 2016 entries against the pair kernel (IEEE divisions, another summation order),
+      * 64 random entries against the oracle (<= 1e-9 relative; euclidean bit-identical),
+      * the text of a 12-profile sub-matrix through kdistlib.distance_matrix against the oracle's text."""
+    from kpal_amd import klib, kdistlib
+    k, P = 12, 64
+    n = 4 ** k
+    rs = np.random.RandomState(n_reads % 1000 + 5)
+    d = ctx.alloc(n_reads * 151)
+    dprof = ctx.alloc(P * n * 8)
+    host = []
+    try:
+        for p in range(P):
+            ctx.synth_reads_device(100 + p, 0, n_reads, 150, d)
+            ctx.count_begin(k)
+            ctx.count_feed_device(d, n_reads * 151)
+            c = ctx.count_finish()
+            assert c.sum() == n_reads * (150 - k + 1)
+            host.append(c)
+            ctx.h2d(dprof + p * n * 8, c)
+        if n_reads == 100_000:
+            assert 0.40 < np.mean(host[0] == 0) < 0.46          # the sparse variant really is sparse
+        pairs = [(i, j) for i in range(1, P) for j in range(i)]
+        pick = [pairs[t] for t in rs.choice(len(pairs), 64, replace=False)]
+        for metric in ('prod', 'sum', 'euclidean'):
+            code = ('prod', 'sum', 'euclidean').index(metric)
+            for bal in (False, True):
+                got = ctx.distance_matrix_device(P, k, dprof, code, bal)
+                assert got.shape == (2016,)
+                byp = np.array([ctx.pair_distance_device(n, dprof + i * n * 8, dprof + j * n * 8, code, bal, k) for i, j in pairs])
+                if metric == 'euclidean':
+                    np.testing.assert_array_equal(got, byp)
+                else:
+                    np.testing.assert_allclose(got, byp, rtol=RTOL, atol=0)
+                for i, j in pick[:64 if not bal else 16]:
+                    want = oracle.distance(host[i], host[j], k, bal, metric)
+                    g = got[i * (i - 1) // 2 + j]
+                    if metric == 'euclidean':
+                        assert g == want, (metric, bal, i, j)
+                    else:
+                        assert close(g, want), (metric, bal, i, j, g, want)
+        # text (precision <= 8) of a sub-matrix through the drop-in API
+        sub = [klib.Profile(host[p], 'p%d' % p) for p in range(0, 60, 5)]
+        for prec in (3, 8):
+            out = io.StringIO()
+            kdistlib.distance_matrix(sub, out, prec, kdistlib.ProfileDistance())
+            want = oracle.distance_matrix_values([s.counts for s in sub], k, False, 'prod')
+            assert out.getvalue() == oracle.distance_matrix_text([s.name for s in sub], want, prec)
+    finally:
+        ctx.free(d)
+        ctx.free(dprof)

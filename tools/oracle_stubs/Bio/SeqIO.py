@@ -24,10 +24,10 @@ def parse(handle, fmt):
     for line in handle:
         if line.startswith('>'):
             if title is not None:
-                yield _Record(title, ''.join(chunks))
-            title = line[1:].rstrip('\r\n')
+                yield _Record(title, ''.join(chunks).replace(' ', '').replace('\r', ''))
+            title = line[1:].rstrip()
             chunks = []
         elif title is not None:
-            chunks.append(line.strip().replace(' ', '').replace('\r', ''))
+            chunks.append(line.rstrip())
     if title is not None:
-        yield _Record(title, ''.join(chunks))
+        yield _Record(title, ''.join(chunks).replace(' ', '').replace('\r', ''))
