@@ -44,6 +44,16 @@ def test_g3_config1_and_generator(golden_synth):
     assert sha(c) == g['sha256']
     # threaded variant (private histograms + merge) is the at-scale oracle
     assert sha(oracle.count_flat(buf, g['k'], threads=4)) == g['sha256']
+    # threaded variant on a table above the private-histogram limit: one shared table, atomic adds
+    assert np.array_equal(oracle.count_flat(buf, 11, threads=4), oracle.count_flat(buf, 11))
+    # the pure-Python restatement of klib.py:149-170 that bench.py times as the reference-speed figure
+    from oracle import pyref
+    reads = [bytes(r).decode() for r in buf.reshape(-1, 151)[:, :150]]
+    assert sha(pyref.from_sequences(reads, g['k'])) == g['sha256']
+    noisy = oracle.synth_reads(7, 0, 300, 150, noisy=True)
+    seqs = [bytes(r).decode() for r in noisy.reshape(-1, 151)[:, :150]] + ['', 'ACG', 'nnnACGTacgtRYACGTT']
+    for k in (1, 4, 6):
+        np.testing.assert_array_equal(pyref.from_sequences(seqs, k), oracle.from_sequences(seqs, k))
 
 
 def test_g3_noisy_and_long(golden_synth):
