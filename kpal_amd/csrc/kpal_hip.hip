@@ -18,8 +18,10 @@
 #include "count_kernels.hpp"
 #include "partition_kernels.hpp"
 #include "chunk_kernels.hpp"
+#include "quad_kernels.hpp"
 #include "fasta_kernels.hpp"
 #include "vec_kernels.hpp"
+#include "gram_kernels.hpp"
 #include "option_kernels.hpp"
 #include "stat_kernels.hpp"
 
@@ -88,6 +90,8 @@ struct kpal_ctx {
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
+    DevBuf quad_meta;                        // quad path: rounds per workgroup, error word
+    uint32_t *quad_error_word = nullptr;
     bool chunk_error_armed = false;
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     ChunkPool chunk_pool_sent = {};          // what the device copy of the pool descriptor holds
@@ -320,7 +324,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
@@ -400,6 +404,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
     if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->quad_error_word) HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
     ctx->chunk_error_armed = false;
     ctx->counting = true;
     return KPAL_OK;
@@ -408,7 +413,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_CHUNKED)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_QUADS)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -419,9 +424,9 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     int s = ctx->strategy;
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
-        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_CHUNKED : KPAL_STRATEGY_PARTITION2);
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2);
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
-    if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED) && (k < 8 || k > 12))
+    if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED || s == KPAL_STRATEGY_PARTITION_QUADS) && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
     if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 16))
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
@@ -611,6 +616,35 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
+// Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
+// one workgroup per bucket histograms.  pool[bucket][workgroup][round] holds one record per flush round.
+static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    const uint64_t tiles = (total_steps + kQuadTileSteps - 1) / kQuadTileSteps;
+    const uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cu, tiles);
+    const uint64_t tpb = (tiles + G - 1) / G;          // tiles (= flush rounds) per workgroup
+    if (tpb > 0xFFFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
+    const size_t pool_bytes = (size_t)kQuadRowWords * 4 * G * tpb;   // every round writes all rows: 128 KiB per workgroup
+    CHK(ensure(ctx, ctx->keys, pool_bytes));
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4) * sizeof(uint32_t)));
+    uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
+    uint32_t *error = nrounds + ctx->num_cu;
+    if (!ctx->quad_error_word) {
+        HIPCHK(hipMemsetAsync(error, 0, sizeof(uint32_t), ctx->stream));
+        ctx->quad_error_word = error;
+    }
+    uint32_t *pool = (uint32_t *)ctx->keys.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_8_12(ctx->k, {
+        LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K>), dim3(G), dim3(kQuadThreads), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
+        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
+               (const uint32_t *)nrounds, G, (uint32_t)tpb, table);
+    });
+    return KPAL_OK;
+}
+
 constexpr int kSplitBatch = 1;   // launch_partition2: a coarse bucket would overflow its 32-bit offsets
 
 // Two-level partition, k = 13..16: coarse count/scan/scatter into 24-bit residuals, then the
@@ -731,6 +765,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     // tiny feeds (single records, short reads lists): the partition pipelines cost a fixed
     // 0.1 - 0.5 ms (launches, one merge of the whole table); a quarter million atomics do not
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
+    // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
@@ -746,6 +782,10 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         spb_max = spb_max / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
         const size_t cap = (size_t)(spb_max * G * 1024);
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
+    }
+    else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+        // the record pool takes 4/3 of the input bytes: pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
     }
     else if (strat == KPAL_STRATEGY_PARTITION2) {
         // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
@@ -765,6 +805,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) CHK(launch_partition_quads(ctx, s));
         else {
             const int rc = launch_partition2(ctx, s);
             if (rc == kSplitBatch) {   // rare: process this piece as two halves
@@ -1004,9 +1045,11 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
-    uint32_t pool_error = 0;
+    uint32_t pool_error = 0, quad_error = 0;
     if (ctx->chunk_error_armed)
         HIPCHK(hipMemcpyAsync(&pool_error, ctx->chunk_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->quad_error_word)
+        HIPCHK(hipMemcpyAsync(&quad_error, ctx->quad_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     // (a double-buffered pinned staging path was measured slower than the runtime's pageable copy)
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, ctx->table.p, ctx->bins * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1014,6 +1057,10 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
     if (pool_error) {
         HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
         return set_err(KPAL_E_HIP, "chunked partition: the chunk pool ran out (internal sizing error %u); counts are invalid", pool_error);
+    }
+    if (quad_error) {
+        HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
+        return set_err(KPAL_E_HIP, "quad partition: internal sizing error %u; counts are invalid", quad_error);
     }
     return KPAL_OK;
 }
@@ -1260,6 +1307,70 @@ KPAL_API int kpal_pair_distance_f64(kpal_ctx *ctx, size_t n, const double *host_
                                         pairwise, out, aux_out);
 }
 
+// Euclidean distances of all pairs from the fp64 Gram matrix (gram_kernels.hpp).  *exact = false (and
+// out_lower untouched) when some |x|^2 >= 2^53: the caller then takes the wrapping-int64 path.
+static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, double *out_lower, bool *exact)
+{
+    const int nb = (P + 63) / 64;
+    std::vector<int2> diag, off;
+    for (int I = 0; I < nb; ++I)
+        for (int J = 0; J <= I; ++J) (I == J ? diag : off).push_back(make_int2(I, J));
+    const uint32_t nd = (uint32_t)diag.size(), no = (uint32_t)off.size();
+    const uint64_t slabs = n / kGramBins;
+    // diagonal blocks: two 68 KiB workgroups per CU; off-diagonal ones (P > 64): one
+    const unsigned gx_d = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(slabs, (uint64_t)ctx->num_cu * 2 / nd));
+    const unsigned gx_o = no ? (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(slabs, (uint64_t)ctx->num_cu / no)) : 0u;
+    std::vector<int2> all(diag);
+    all.insert(all.end(), off.begin(), off.end());
+    CHK(ensure(ctx, ctx->scratch[3], all.size() * sizeof(int2)));
+    HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, all.data(), all.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    const size_t part_d = (size_t)nd * 4096 * gx_d, part_o = (size_t)no * 4096 * gx_o;
+    CHK(ensure(ctx, ctx->partials, (part_d + part_o) * sizeof(Partial)));
+    CHK(ensure(ctx, ctx->result, (size_t)(nd + no) * 4096 * sizeof(Partial)));
+    Partial *pp = (Partial *)ctx->partials.p;
+    Partial *res_d = (Partial *)ctx->result.p;
+    const int2 *dt = (const int2 *)ctx->scratch[3].p;
+    LAUNCH(ctx, "gram_mfma", (gram_mfma_kernel<true>), dim3(gx_d, nd), dim3(256), prof, P, n, dt, pp);
+    LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(nd * 4096), dim3(256), (const Partial *)pp, gx_d, res_d);
+    if (no) {
+        LAUNCH(ctx, "gram_mfma", (gram_mfma_kernel<false>), dim3(gx_o, no), dim3(256), prof, P, n, dt + nd, pp + part_d);
+        LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(no * 4096), dim3(256), (const Partial *)(pp + part_d), gx_o,
+               res_d + (size_t)nd * 4096);
+    }
+    std::vector<Partial> res((size_t)(nd + no) * 4096);
+    HIPCHK(hipMemcpyAsync(res.data(), res_d, res.size() * sizeof(Partial), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // also: `all` was read by the asynchronous copy above
+    auto gram = [&](int i, int j) -> double {    // i >= j
+        const int I = i / 64, J = j / 64;
+        size_t blk;
+        if (I == J) blk = (size_t)I;             // diag[] is in order of I
+        else {
+            blk = nd;
+            for (size_t t = 0; t < off.size(); ++t)
+                if (off[t].x == I && off[t].y == J) blk = nd + t;
+        }
+        const int gi = (i % 64) / 16, gj = (j % 64) / 16;
+        return res[(blk * 16 + (size_t)(gi * 4 + gj)) * 256 + (size_t)((i % 16) * 16 + (j % 16))].s;
+    };
+    const double limit = 9007199254740992.0;     // 2^53
+    std::vector<double> norm(P);
+    for (int i = 0; i < P; ++i) {
+        norm[i] = gram(i, i);
+        if (!(norm[i] < limit)) {
+            *exact = false;
+            return KPAL_OK;
+        }
+    }
+    for (int i = 1; i < P; ++i)
+        for (int j = 0; j < i; ++j) {
+            // exact integers below 2^53 each: the int64 expression is the reference's sum of squared differences
+            const int64_t d2 = (int64_t)norm[i] + (int64_t)norm[j] - 2 * (int64_t)gram(i, j);
+            out_lower[(size_t)i * (i - 1) / 2 + j] = std::sqrt((double)d2);   // metrics.py:46: np.sqrt(np.dot(v, v))
+        }
+    *exact = true;
+    return KPAL_OK;
+}
+
 KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles, int metric,
                                          int do_balance, double *out_lower)
 {
@@ -1277,6 +1388,14 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
         for (int p = 0; p < P; ++p)
             CHK(launch_balance(ctx, k, dev_profiles + (uint64_t)p * n, (int64_t *)ctx->scratch[2].p + (uint64_t)p * n));
         prof = (const int64_t *)ctx->scratch[2].p;
+    }
+    // euclidean with enough profiles and bins: fp64 Gram matrix on the matrix cores (gram_kernels.hpp), exact
+    // while every |x|^2 < 2^53 (checked on the result); KPAL_MATRIX_MFMA=0 forces the int64 kernels
+    static const bool allow_mfma = [] { const char *e = getenv("KPAL_MATRIX_MFMA"); return !e || atoi(e) != 0; }();
+    if (metric == KPAL_EUCLIDEAN && allow_mfma && P > 8 && k >= 6) {
+        bool exact = false;
+        CHK(gram_euclidean(ctx, P, n, prof, out_lower, &exact));
+        if (exact) return KPAL_OK;
     }
     constexpr int TILE = 4;
     const int side = (P + TILE - 1) / TILE;

@@ -1,0 +1,402 @@
+// quad_kernels.hpp -- radix partition of QUADS of overlapping k-mers into aligned records (k = 8..12, gfx950).
+//
+// What bounds the chunked scatter of chunk_kernels.hpp (profiles/r2/): one range-checked
+// buffer_store_short per (bucket, tile) run of ~48 two-byte keys costs ~30 clk of the CU's store path
+// (SQ_INSTS_VMEM_WR: one store per 32 clk per CU over the whole kernel, LDS only 39 % busy), and the
+// path moves 8-10 B/clk/CU no matter how the bytes are cut -- provided they leave as whole ALIGNED
+// pieces of >= 64 B (tools/store_probe2.hip: 64 B 8 clk, 128 B 16 clk, 1 KiB 103 clk; 32 B 12.5 clk;
+// 64 lanes x 2 B 30 clk per 128 B).  So this pipeline cuts bytes per k-mer and stores only such pieces:
+//
+//   * ITEM = four overlapping k-mers.  The (K+3)-mer x ending at byte 4q+3 of a lane's 16-byte chunk
+//     holds the k-mers ending at bytes 4q .. 4q+3: k-mer i = x[2K+5-2i : 6-2i].  All four share the
+//     bits x[2K-1 : 6]; the top B of those are the BUCKET.  A 4-byte item keeps the rest: the six bits
+//     above the shared field, the L = 2K-B bits below the bucket, and a 4-bit mask of which of the four
+//     k-mers count (read ends, N, lower case handled by the mask exactly like emit_mask): one slot
+//     allocation + one 4-byte LDS write per FOUR k-mers, ~1.05 B per k-mer instead of 2.
+//   * RECORD = one bucket's items of one flush round, padded with null items (mask 0) to a fixed size
+//     (64 B at k = 12: 2048 buckets x 16 items; 256 B at k <= 11: 512 buckets x 64 items), written with
+//     16-byte stores to its own aligned place  pool[bucket][workgroup][round]  -- no cursors, no chunk
+//     allocation, no tables: the histogram stage reads pool[bucket] as one stream.
+//   * A row that overflows (Poisson tail, ~1.5 % of the items) spills into a small LDS list whose
+//     entries are placed again at the start of the next round; a round that spills more than the list
+//     holds (homopolymers, satellite repeats) is abandoned and its k-mers are counted directly
+//     (ballot-aggregated global atomics), as in chunk_scatter.
+//   * HISTOGRAM: one workgroup per bucket, four forms (one per k-mer position) of 2^L bins in LDS
+//     (128 KiB at k = 11, 12); the bins of form i are table entries (hi << (B+s)) | (bucket << s) | lo
+//     with s = L-6+2i; merged with global atomics (forms of different buckets interleave in the table).
+//
+// Integer adds commute, every k-mer is in exactly one item with its mask bit set: bit-exact.
+#pragma once
+#include "chunk_kernels.hpp"
+
+namespace kpal {
+
+constexpr int kQuadThreads = 1024;            // one workgroup per CU (rows take 128 KiB of LDS)
+constexpr int kQuadWaves = kQuadThreads / 64;
+constexpr int kQuadSteps = 6;                 // wave-steps per wave per tile
+constexpr int kQuadTileSteps = kQuadWaves * kQuadSteps;   // 96 KiB of input per tile
+constexpr int kQuadSpillCap = 1024;           // spilled items a round may carry over (one per thread)
+constexpr int kQuadDeferCap = 256;
+constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
+
+template <int K>
+struct QuadCfg {
+    static_assert(K >= 8 && K <= 12, "quads: k = 8..12");
+    static constexpr int kBucketBits = K == 12 ? 11 : 9;
+    static constexpr int kBuckets = 1 << kBucketBits;
+    static constexpr int kLowBits = 2 * K - kBucketBits;            // L: 13, 13, 11, 9, 7
+    static constexpr int kFormBins = 1 << kLowBits;
+    static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16 or 64
+    static constexpr int kRecordBytes = kSlots * 4;
+    static constexpr int kScrBits = (kLowBits - 6) < 4 ? (kLowBits - 6) : 4;   // bits of the low field that scramble the bucket
+    static constexpr uint32_t kXMask = (1u << (2 * K + 6)) - 1u;                       // the (K+3)-mer: at most 30 bits
+    static constexpr uint32_t kLowMask = (1u << kLowBits) - 1u;
+    // rows are rotated by a multiple of four words so that rows filling in lock-step hit different banks
+    // while the flush still reads whole 16-byte vectors
+    __host__ __device__ static constexpr uint32_t rot(uint32_t row) { return (4u * (kSlots == 16 ? row >> 1 : row)) & (uint32_t)(kSlots - 1); }
+    // bucket scrambling (see chunk_scramble): the top kScrBits of the low field pick one of 2^kScrBits masks
+    __host__ __device__ static constexpr uint32_t smask(uint32_t t)
+    {
+        return kScrBits > 0 ? (((t << (kBucketBits - kScrBits)) | t) & (uint32_t)(kBuckets - 1)) : 0u;
+    }
+};
+
+// item = hi6 << (L+4) | low << 4 | mask4 (mask bit 3 = oldest k-mer).  0 = null item.
+template <int K>
+__device__ __forceinline__ void quad_split(uint32_t x, uint32_t m4, uint32_t &row, uint32_t &item)
+{
+    using C = QuadCfg<K>;
+    const uint32_t low = x & C::kLowMask;
+    const uint32_t b = (x >> C::kLowBits) & (uint32_t)(C::kBuckets - 1);
+    const uint32_t hi6 = x >> (2 * K);
+    row = b ^ C::smask(low >> (C::kLowBits - C::kScrBits));
+    item = (hi6 << (C::kLowBits + 4)) | (low << 4) | m4;
+}
+
+// the k-mer at position i (0 = oldest) of an item of (scrambled) row `row`
+template <int K>
+__device__ __forceinline__ uint32_t quad_kmer(uint32_t row, uint32_t item, int i)
+{
+    using C = QuadCfg<K>;
+    const uint32_t low = (item >> 4) & C::kLowMask;
+    const uint32_t hi6 = item >> (C::kLowBits + 4);
+    const uint32_t b = row ^ C::smask(low >> (C::kLowBits - C::kScrBits));
+    const uint64_t x = ((uint64_t)hi6 << (2 * K)) | ((uint64_t)b << C::kLowBits) | low;
+    return (uint32_t)((x >> (6 - 2 * i)) & ((1ull << (2 * K)) - 1ull));
+}
+
+struct QuadSpill {
+    uint32_t row, item;
+};
+
+// One slot allocation + one LDS write per item; items whose row is full go to the spill list.
+template <int K>
+__device__ __forceinline__ void quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n,
+                                           const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *dbg_table = nullptr)
+{
+    using C = QuadCfg<K>;
+    uint32_t slot[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slot[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 1u : 0u);
+    bool over = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool counted = (item[q] & 15u) != 0u;
+        const bool fits = slot[q] < (uint32_t)C::kSlots;
+        const uint32_t at = row[q] * C::kSlots + ((slot[q] + C::rot(row[q])) & (uint32_t)(C::kSlots - 1));
+        rows[(counted && fits) ? at : (uint32_t)kQuadRowWords] = item[q];     // not counted / full row: dummy word
+        over |= counted && !fits;
+    }
+    if (__builtin_expect(__any(over), 0)) {   // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((item[q] & 15u) && slot[q] >= (uint32_t)C::kSlots) {
+#if defined(KPAL_QUAD_NO_CARRY)   // bisecting builds only: spilled items straight into the table
+                for (int i = 0; i < 4; ++i)
+                    if ((item[q] >> (3 - i)) & 1u) atomicAdd(&dbg_table[quad_kmer<K>(row[q], item[q], i)], 1ULL);
+                continue;
+#endif
+                const uint32_t at = atomicAdd(spill_n, 1u);
+                if (at < (uint32_t)kQuadSpillCap) spill[at] = QuadSpill{row[q], item[q]};
+            }
+        }
+    }
+}
+
+// Abandoned tile: its k-mers straight into the table (chunk_count_tile_direct with this tile shape).
+template <int K>
+__device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t first_step, unsigned long long *__restrict__ table,
+                                                       uint32_t &pend_hot, unsigned long long &pend_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    Chunk carry = load_chunk(s, (int64_t)(first_step * 64) - 1);
+    for (int st = 0; st < kQuadSteps; ++st) {
+        uint64_t window;
+        uint32_t mask;
+        part_step<K>(s, first_step + st, carry, window, mask);
+        const unsigned long long have = __builtin_amdgcn_ballot_w64(mask != 0);
+        if (!have) continue;   // wave-uniform
+        const int src = __ffsll((long long)have) - 1;
+        const uint32_t m0 = __builtin_amdgcn_readlane(mask, src);
+        const uint32_t w0_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(window >> 32), src);
+        const uint32_t w0_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)window, src);
+        const uint64_t w0 = ((uint64_t)w0_hi << 32) | w0_lo;
+        const uint32_t hot = kmer_at<K>(w0, 15 - (31 - __clz(m0)));
+        uint32_t same = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t v = kmer_at<K>(window, j);
+            const bool counted = (mask >> (15 - j)) & 1u;
+            const bool eq = counted && v == hot;
+            same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
+            if (counted && !eq) atomicAdd(&table[v], 1ULL);
+        }
+        if (hot != pend_hot) {   // wave-uniform
+            if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
+            pend_hot = hot;
+            pend_cnt = 0;
+        }
+        pend_cnt += same;
+    }
+}
+
+// Q1: ASCII -> records.  Tile j of workgroup g is tile j * G + g of the input (the grid reads one sliding
+// window), wave w takes its steps 6w .. 6w+5.  Per tile: place (the items carried over from the previous
+// round first; the next tile's chunks are requested step by step), barrier, read every row as one padded
+// record into registers, barrier, store the records -- they drain while the next tile is placed.
+// pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots.
+template <int K>
+__global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
+                                                                    uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
+                                                                    uint32_t *__restrict__ error,
+                                                                    unsigned long long *__restrict__ table)
+{
+    using C = QuadCfg<K>;
+    constexpr int S = C::kSlots, NB = C::kBuckets;
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
+    __shared__ uint32_t pos[NB];
+    __shared__ QuadSpill spill[kQuadSpillCap];
+    __shared__ uint32_t spill_cnt[2];           // appended-entries counter of even / odd tiles: the one of tile j is read by every
+                                                // thread after the placement barrier, so it may only be reset a barrier later --
+                                                // thread 0 resets the OTHER one (for tile j+1) during the flush of tile j
+    __shared__ uint32_t defer_n;
+    __shared__ DeferRun defer_t[kQuadDeferCap];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < NB; i += kQuadThreads) pos[i] = 0;
+    if (threadIdx.x == 0) {
+        spill_cnt[0] = 0;
+        spill_cnt[1] = 0;
+        defer_n = 0;
+    }
+    __syncthreads();
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    auto tile_step = [&](uint64_t j) -> uint64_t { return ((j * gridDim.x + blockIdx.x) * kQuadWaves + (uint64_t)wave) * kQuadSteps; };
+    auto tile_exists = [&](uint64_t j) -> bool { return j < tiles_per_block && (j * gridDim.x + blockIdx.x) * (uint64_t)kQuadTileSteps < total_steps; };
+    uint4 raw[kQuadSteps];
+    uint4 rawh;
+    {
+        const uint64_t f = tile_step(0);
+#pragma unroll
+        for (int st = 0; st < kQuadSteps; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+        rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
+    }
+    uint32_t round = 0;                         // records written per row so far
+    uint32_t carry_row = 0, carry_item = 0;     // this thread's item carried over from the previous round (0 = none)
+    // the flush: 8 store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores
+    constexpr int LPR = S / 4;                  // lanes per record
+    constexpr int RPI = 64 / LPR;               // records per instruction
+    const uint32_t frow0 = (uint32_t)wave * (NB / kQuadWaves) + (uint32_t)lane / LPR;
+    const uint32_t fvec = (uint32_t)lane % LPR;
+    for (uint64_t j = 0; tile_exists(j); ++j) {   // block-uniform
+        const uint64_t first = tile_step(j);
+        const bool more = tile_exists(j + 1);
+        const uint64_t fnext = tile_step(j + 1);
+        uint32_t *spill_n = &spill_cnt[j & 1];
+        // ---- place: carried items, then this tile's.  Each step's chunk of the NEXT tile is requested as soon as
+        // this tile's has been encoded: the loads fly under the placement, the barriers and the flush.
+        {
+            const uint32_t r4[4] = {carry_row, 0u, 0u, 0u};
+            const uint32_t i4[4] = {carry_item, 0u, 0u, 0u};
+            if (__any(carry_item != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
+        }
+        Chunk carry = encode16(rawh);
+        range_fix(s, (int64_t)(first * 64) - 1, carry);
+        if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
+#pragma unroll
+        for (int st = 0; st < kQuadSteps; ++st) {
+            uint64_t window;
+            uint32_t mask;
+            encode_step<K>(s, first + st, raw[st], carry, window, mask);
+            if (more) raw[st] = fetch_chunk(s, (int64_t)((fnext + st) * 64 + lane));
+            uint32_t row[4], item[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
+                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row[q], item[q]);
+            }
+            quad_place<K>(rows, pos, spill, spill_n, row, item, table);
+        }
+        lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
+        const uint32_t spilled = *spill_n;       // reset only during the flush of the NEXT tile
+        if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
+        if (__builtin_expect(spilled > (uint32_t)kQuadSpillCap, 0)) {
+            // block-uniform, pathological input only: forget the round, count the tile directly after the loop.
+            // The items carried INTO this round are placed again (they are still in registers); what spills of
+            // those (at most one per thread: it fits the list) is carried on.
+            __syncthreads();                     // every thread has read `spilled`
+            for (int i = threadIdx.x; i < NB; i += kQuadThreads) pos[i] = 0;
+            if (threadIdx.x == 0) {
+                *spill_n = 0;
+                defer_tile(defer_t, defer_n, (uint32_t)j, error);
+            }
+            __syncthreads();
+            {
+                const uint32_t r4[4] = {carry_row, 0u, 0u, 0u};
+                const uint32_t i4[4] = {carry_item, 0u, 0u, 0u};
+                if (__any(carry_item != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
+            }
+            __syncthreads();
+            const uint32_t again = *spill_n;
+            carry_item = 0;
+            if (threadIdx.x < again) {
+                carry_row = spill[threadIdx.x].row;
+                carry_item = spill[threadIdx.x].item;
+            }
+            __syncthreads();                     // the list is free again for the next tile's appends
+            continue;                            // the rows keep the re-placed items: they leave with the next flush
+        }
+        // ---- flush: every row leaves as one record of S items (null padded).  The records are read into
+        // registers, the barrier frees the rows, and the stores drain under the next tile's placement.
+        carry_item = 0;
+        if (threadIdx.x < spilled) {
+            carry_row = spill[threadIdx.x].row;
+            carry_item = spill[threadIdx.x].item;
+        }
+        constexpr int FI = NB / kQuadWaves / RPI;   // 8 store instructions per wave
+        uint4 rec[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t r = frow0 + (uint32_t)i * RPI;
+            const uint32_t n = pos[r];
+            uint4 v = *reinterpret_cast<const uint4 *>(&rows[r * S + 4 * fvec]);
+            const uint32_t s0 = (4u * fvec - C::rot(r)) & (uint32_t)(S - 1);   // slot of the vector's first word
+            v.x = s0 + 0 < n ? v.x : 0u;
+            v.y = s0 + 1 < n ? v.y : 0u;
+            v.z = s0 + 2 < n ? v.z : 0u;
+            v.w = s0 + 3 < n ? v.w : 0u;
+            rec[i] = v;
+            if (fvec == 0) pos[r] = 0;
+        }
+        lds_barrier();                           // every wave has its records in registers: the rows are free
+        if (round < rounds_cap) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const uint32_t r = frow0 + (uint32_t)i * RPI;
+                const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + round) * S;
+                *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
+            }
+        } else if (threadIdx.x == 0) {
+            *error = 2u;   // cannot happen: one round per tile, rounds_cap = tiles per workgroup
+        }
+        ++round;
+    }
+    if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
+    // what is still carried over: straight into the table (at most one item per thread)
+    if (carry_item) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((carry_item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(carry_row, carry_item, i)], 1ULL);
+    }
+    // items placed after the last flush (carried items of an abandoned last tile) are still in the rows
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < (uint32_t)NB; r += kQuadThreads) {
+        const uint32_t n = min(pos[r], (uint32_t)S);
+        for (uint32_t sl = 0; sl < n; ++sl) {
+            const uint32_t it = rows[r * S + ((sl + C::rot(r)) & (uint32_t)(S - 1))];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, i)], 1ULL);
+        }
+    }
+    uint32_t pend_hot = 0;
+    unsigned long long pend_cnt = 0;
+    for (uint32_t i = 0; i < defer_n; ++i)
+        for (uint32_t q = 0; q < defer_t[i].count; ++q)
+            quad_count_tile_direct<K>(s, tile_step((uint64_t)defer_t[i].first + q), table, pend_hot, pend_cnt);
+    if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
+}
+
+// Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
+// Same hot-key guard as part_hist_kernel: per form the wave counts the occurrences of its first lane's bin
+// with a ballot, those lanes add to private dummy words instead (64 adds to one LDS address serialise).
+template <int K>
+__global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ nrounds,
+                                                         uint32_t G, uint32_t rounds_cap, unsigned long long *__restrict__ table)
+{
+    using C = QuadCfg<K>;
+    constexpr int L = C::kLowBits, BINS = C::kFormBins, S = C::kSlots;
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * BINS + 64];
+    const uint32_t row = blockIdx.x;
+    for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto add_item = [&](uint32_t it) {
+        const uint32_t low = (it >> 4) & C::kLowMask;
+        const uint32_t hi6 = it >> (L + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t counted = (it >> (3 - i)) & 1u;
+            const uint32_t local = ((hi6 & ((1u << (6 - 2 * i)) - 1u)) << (L - 6 + 2 * i)) | (low >> (6 - 2 * i));
+#if defined(KPAL_QUAD_NO_HOT)     // bisecting builds only
+            atomicAdd(&hist[(uint32_t)(i * BINS) + local], counted);
+            continue;
+#endif
+            // hot-bin guard: only when the first active lane's bin repeats in the wave (one pair in ~130 for
+            // uniform k-mers; every lane for a homopolymer) are those lanes diverted and counted by the ballot
+            const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
+            const bool eq = counted && local == hot;
+            const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
+            if (same >= 2u) {   // wave-uniform
+                atomicAdd(&hist[eq ? (uint32_t)(4 * BINS + lane) : (uint32_t)(i * BINS) + local], counted);
+                if (lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[(uint32_t)(i * BINS) + hot], same);
+            } else {
+                atomicAdd(&hist[(uint32_t)(i * BINS) + local], counted);
+            }
+        }
+    };
+    auto add4 = [&](const uint4 q) {
+        if (q.x) add_item(q.x);
+        if (q.y) add_item(q.y);
+        if (q.z) add_item(q.z);
+        if (q.w) add_item(q.w);
+    };
+    for (uint32_t g = wave; g < G; g += 16) {   // wave-uniform
+        const uint4 *src = reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row * G + g) * rounds_cap) * S);
+        const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
+        uint32_t v = lane;
+        for (; v + 192 < nvec; v += 256) {
+            const uint4 q0 = src[v], q1 = src[v + 64], q2 = src[v + 128], q3 = src[v + 192];
+            add4(q0);
+            add4(q1);
+            add4(q2);
+            add4(q3);
+        }
+        for (; v < nvec; v += 64) add4(src[v]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sh = L - 6 + 2 * i;
+        for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
+            const uint32_t c = hist[i * BINS + local];
+            if (!c) continue;
+            const uint32_t lopart = (uint32_t)local & ((1u << sh) - 1u);
+            const uint32_t hipart = (uint32_t)local >> sh;
+            const uint32_t b = row ^ C::smask(C::kScrBits > 0 ? (lopart >> (sh - C::kScrBits)) : 0u);
+            const uint64_t idx = ((uint64_t)hipart << (C::kBucketBits + sh)) | ((uint64_t)b << sh) | lopart;
+            atomicAdd(&table[idx], (unsigned long long)c);
+        }
+    }
+}
+
+}  // namespace kpal

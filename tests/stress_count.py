@@ -35,7 +35,7 @@ while time.time() < t_end:
     want = oracle.count_flat(buf, k, threads=16)
     strategies = ['auto']
     if 8 <= k <= 12:
-        strategies += ['partition', 'partition_chunked']
+        strategies += ['partition', 'partition_chunked', 'partition_quads']
     for strat in strategies:
         if rs.rand() < 0.5:
             got = ctx.count_bytes(k, buf, strat)

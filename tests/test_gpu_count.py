@@ -24,6 +24,7 @@ def strategies(k):
     if 8 <= k <= 12:
         s.append('partition')
         s.append('partition_chunked')
+        s.append('partition_quads')
     if 13 <= k <= 16:
         s.append('partition2')
     return s
@@ -234,7 +235,7 @@ def test_chunk_overflow_lists(ctx):
     d = ctx.alloc(n)       # one device feed: a workgroup's share must be large enough to fill many chunks
     try:
         ctx.h2d(d, buf)
-        for k, strat in ((12, 'auto'), (13, 'auto'), (12, 'partition')):
+        for k, strat in ((12, 'auto'), (12, 'partition_chunked'), (12, 'partition_quads'), (13, 'auto'), (12, 'partition')):
             ctx.count_begin(k, strat)
             ctx.count_feed_device(d, n)
             np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(buf, k, threads=32), err_msg='k=%d %s' % (k, strat))
@@ -282,6 +283,8 @@ def test_small_partition_batches():
         np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition'), oracle.count_flat(seq, k, threads=4))
         np.testing.assert_array_equal(c2.count_bytes(k, buf, 'partition_chunked'), oracle.count_flat(buf, k, threads=4))
         np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition_chunked'), oracle.count_flat(seq, k, threads=4))
+        np.testing.assert_array_equal(c2.count_bytes(k, buf, 'partition_quads'), oracle.count_flat(buf, k, threads=4))
+        np.testing.assert_array_equal(c2.count_bytes(k, seq, 'partition_quads'), oracle.count_flat(seq, k, threads=4))
     c2.close()
 
 
@@ -322,7 +325,7 @@ def test_full_size_properties_k12(ctx, k, n_reads):
             parts.append(ctx.count_finish())
         np.testing.assert_array_equal(parts[0] + parts[1], full)
         # the two partition pipelines agree bin for bin at full size (key indices beyond 2^31)
-        for strat in ('partition', 'partition_chunked'):
+        for strat in ('partition', 'partition_chunked', 'partition_quads'):
             ctx.count_begin(k, strat)
             ctx.count_feed_device(d, nbytes)
             np.testing.assert_array_equal(ctx.count_finish(), full, err_msg=strat)
@@ -471,7 +474,7 @@ def test_partition_pipelines_on_skewed_inputs(ctx):
     for name, buf in cases.items():
         for k in (12, 9):
             want = oracle.count_flat(buf, k, threads=8)
-            for strat in ('partition_chunked', 'partition'):
+            for strat in ('partition_quads', 'partition_chunked', 'partition'):
                 np.testing.assert_array_equal(ctx.count_bytes(k, buf, strat), want, err_msg='%s k=%d %s' % (name, k, strat))
 
 
