@@ -624,6 +624,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     if (total_steps == 0) return KPAL_OK;
     const uint64_t tiles = (total_steps + kQuadTileSteps - 1) / kQuadTileSteps;
     const uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cu, tiles);
+    static const int waves = [] { const char *e = getenv("KPAL_QUAD_WAVES"); const int w = e ? atoi(e) : 8; return w == 16 ? 16 : 8; }();   // A/B
     const uint64_t tpb = (tiles + G - 1) / G;          // tiles (= flush rounds) per workgroup
     if (tpb > 0xFFFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
     const size_t pool_bytes = (size_t)kQuadRowWords * 4 * G * tpb;   // every round writes all rows: 128 KiB per workgroup
@@ -638,7 +639,10 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_8_12(ctx->k, {
-        LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K>), dim3(G), dim3(kQuadThreads), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
+        if (waves == 16)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
+        else
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8>), dim3(G), dim3(512), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
                (const uint32_t *)nrounds, G, (uint32_t)tpb, table);
     });

@@ -31,11 +31,8 @@
 
 namespace kpal {
 
-constexpr int kQuadThreads = 1024;            // one workgroup per CU (rows take 128 KiB of LDS)
-constexpr int kQuadWaves = kQuadThreads / 64;
-constexpr int kQuadSteps = 6;                 // wave-steps per wave per tile
-constexpr int kQuadTileSteps = kQuadWaves * kQuadSteps;   // 96 KiB of input per tile
-constexpr int kQuadSpillCap = 1024;           // spilled items a round may carry over (one per thread)
+constexpr int kQuadTileSteps = 96;            // 96 KiB of input per tile: ~11.4 items per 16-slot row (71 % full records)
+constexpr int kQuadSpillCap = 1024;           // spilled items a round may carry over
 constexpr int kQuadDeferCap = 256;
 constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
 
@@ -124,13 +121,13 @@ __device__ __forceinline__ void quad_place(uint32_t *rows, uint32_t *pos, QuadSp
 }
 
 // Abandoned tile: its k-mers straight into the table (chunk_count_tile_direct with this tile shape).
-template <int K>
+template <int K, int STEPS>
 __device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t first_step, unsigned long long *__restrict__ table,
                                                        uint32_t &pend_hot, unsigned long long &pend_cnt)
 {
     const int lane = threadIdx.x & 63;
     Chunk carry = load_chunk(s, (int64_t)(first_step * 64) - 1);
-    for (int st = 0; st < kQuadSteps; ++st) {
+    for (int st = 0; st < STEPS; ++st) {
         uint64_t window;
         uint32_t mask;
         part_step<K>(s, first_step + st, carry, window, mask);
@@ -161,18 +158,26 @@ __device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t f
 }
 
 // Q1: ASCII -> records.  Tile j of workgroup g is tile j * G + g of the input (the grid reads one sliding
-// window), wave w takes its steps 6w .. 6w+5.  Per tile: place (the items carried over from the previous
-// round first; the next tile's chunks are requested step by step), barrier, read every row as one padded
-// record into registers, barrier, store the records -- they drain while the next tile is placed.
+// window); wave w takes its steps STEPS*w .. STEPS*w+STEPS-1 (WAVES x STEPS = 96).  Per tile: place (the items
+// carried over from the previous round first), barrier, read every row as one padded record into registers,
+// barrier.  The records are STORED during the placement of the next tile, a store instruction or two per
+// step, and each step's chunk of the next tile is requested as soon as this tile's has been encoded: the
+// CU's memory pipe (8-10 B/clk for loads + stores together, tools/store_probe2.hip) stays busy under the
+// LDS / VALU work instead of alternating with it.  WAVES = 8 (12 steps per wave, 256 registers per lane:
+// 16 records + 12 chunks live) or 16 (6 steps, 128 registers).
 // pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots.
-template <int K>
-__global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
-                                                                    uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
-                                                                    uint32_t *__restrict__ error,
-                                                                    unsigned long long *__restrict__ table)
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
+                                                                  uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
+                                                                  uint32_t *__restrict__ error,
+                                                                  unsigned long long *__restrict__ table)
 {
     using C = QuadCfg<K>;
     constexpr int S = C::kSlots, NB = C::kBuckets;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int STEPS = kQuadTileSteps / WAVES;
+    constexpr int CARRY = kQuadSpillCap / THREADS;      // carried items per thread
+    static_assert(WAVES * STEPS == kQuadTileSteps && CARRY * THREADS == kQuadSpillCap, "tile shape");
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
     __shared__ uint32_t pos[NB];
     __shared__ QuadSpill spill[kQuadSpillCap];
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint
     __shared__ uint32_t defer_n;
     __shared__ DeferRun defer_t[kQuadDeferCap];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < NB; i += kQuadThreads) pos[i] = 0;
+    for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
     if (threadIdx.x == 0) {
         spill_cnt[0] = 0;
         spill_cnt[1] = 0;
@@ -190,44 +195,78 @@ __global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint
     }
     __syncthreads();
     const uint64_t total_steps = (s.nchunks + 63) / 64;
-    auto tile_step = [&](uint64_t j) -> uint64_t { return ((j * gridDim.x + blockIdx.x) * kQuadWaves + (uint64_t)wave) * kQuadSteps; };
+    auto tile_step = [&](uint64_t j) -> uint64_t { return ((j * gridDim.x + blockIdx.x) * WAVES + (uint64_t)wave) * STEPS; };
     auto tile_exists = [&](uint64_t j) -> bool { return j < tiles_per_block && (j * gridDim.x + blockIdx.x) * (uint64_t)kQuadTileSteps < total_steps; };
-    uint4 raw[kQuadSteps];
+    uint4 raw[STEPS];
     uint4 rawh;
     {
         const uint64_t f = tile_step(0);
 #pragma unroll
-        for (int st = 0; st < kQuadSteps; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+        for (int st = 0; st < STEPS; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
         rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
     }
     uint32_t round = 0;                         // records written per row so far
-    uint32_t carry_row = 0, carry_item = 0;     // this thread's item carried over from the previous round (0 = none)
-    // the flush: 8 store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores
+    uint32_t carry_row[CARRY], carry_item[CARRY];   // items carried over from the previous round (item 0 = none)
+#pragma unroll
+    for (int c = 0; c < CARRY; ++c) carry_row[c] = carry_item[c] = 0;
+    auto place_carried = [&](uint32_t *spill_n) {
+#pragma unroll
+        for (int c = 0; c < CARRY; ++c) {
+            const uint32_t r4[4] = {carry_row[c], 0u, 0u, 0u};
+            const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
+            if (__any(carry_item[c] != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
+        }
+    };
+    auto take_carried = [&](uint32_t n) {
+#pragma unroll
+        for (int c = 0; c < CARRY; ++c) {
+            const uint32_t e = threadIdx.x + (uint32_t)c * THREADS;
+            carry_item[c] = 0;
+            if (e < n) {
+                carry_row[c] = spill[e].row;
+                carry_item[c] = spill[e].item;
+            }
+        }
+    };
+    // the flush: FI store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores
     constexpr int LPR = S / 4;                  // lanes per record
     constexpr int RPI = 64 / LPR;               // records per instruction
-    const uint32_t frow0 = (uint32_t)wave * (NB / kQuadWaves) + (uint32_t)lane / LPR;
+    constexpr int FI = NB / WAVES / RPI;        // 8 (16 waves) or 16 (8 waves)
+    const uint32_t frow0 = (uint32_t)wave * (NB / WAVES) + (uint32_t)lane / LPR;
     const uint32_t fvec = (uint32_t)lane % LPR;
+    uint4 rec[FI];                              // the previous round's records, stored during this tile's placement
+    bool have_rec = false;                      // block-uniform
+    auto store_rec = [&](int i) {
+        uint32_t r = frow0 + (uint32_t)i * RPI;
+        asm volatile("" : "+v"(r));             // the FI record addresses are recomputed per store (3 VALU), not hoisted
+                                                // out of the tile loop as 2 * FI live registers (see chunk_store_rows)
+        const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + (round - 1u)) * S;
+        *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
+    };
     for (uint64_t j = 0; tile_exists(j); ++j) {   // block-uniform
         const uint64_t first = tile_step(j);
         const bool more = tile_exists(j + 1);
         const uint64_t fnext = tile_step(j + 1);
         uint32_t *spill_n = &spill_cnt[j & 1];
-        // ---- place: carried items, then this tile's.  Each step's chunk of the NEXT tile is requested as soon as
-        // this tile's has been encoded: the loads fly under the placement, the barriers and the flush.
-        {
-            const uint32_t r4[4] = {carry_row, 0u, 0u, 0u};
-            const uint32_t i4[4] = {carry_item, 0u, 0u, 0u};
-            if (__any(carry_item != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
-        }
+        // ---- place: carried items, then this tile's
+        place_carried(spill_n);
         Chunk carry = encode16(rawh);
         range_fix(s, (int64_t)(first * 64) - 1, carry);
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
 #pragma unroll
-        for (int st = 0; st < kQuadSteps; ++st) {
+        for (int st = 0; st < STEPS; ++st) {
+            if (have_rec) {
+#pragma unroll
+                for (int i = st; i < FI; i += STEPS) store_rec(i);
+            }
             uint64_t window;
             uint32_t mask;
             encode_step<K>(s, first + st, raw[st], carry, window, mask);
-            if (more) raw[st] = fetch_chunk(s, (int64_t)((fnext + st) * 64 + lane));
+            if (more) {
+                uint32_t l = (uint32_t)lane;
+                asm volatile("" : "+v"(l));     // (same: no STEPS hoisted 64-bit load addresses)
+                raw[st] = fetch_chunk(s, (int64_t)((fnext + st) * 64 + l));
+            }
             uint32_t row[4], item[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -236,44 +275,29 @@ __global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint
             }
             quad_place<K>(rows, pos, spill, spill_n, row, item, table);
         }
+        have_rec = false;
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
         const uint32_t spilled = *spill_n;       // reset only during the flush of the NEXT tile
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
         if (__builtin_expect(spilled > (uint32_t)kQuadSpillCap, 0)) {
             // block-uniform, pathological input only: forget the round, count the tile directly after the loop.
             // The items carried INTO this round are placed again (they are still in registers); what spills of
-            // those (at most one per thread: it fits the list) is carried on.
+            // those (they fit the list) is carried on.
             __syncthreads();                     // every thread has read `spilled`
-            for (int i = threadIdx.x; i < NB; i += kQuadThreads) pos[i] = 0;
+            for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
             if (threadIdx.x == 0) {
                 *spill_n = 0;
                 defer_tile(defer_t, defer_n, (uint32_t)j, error);
             }
             __syncthreads();
-            {
-                const uint32_t r4[4] = {carry_row, 0u, 0u, 0u};
-                const uint32_t i4[4] = {carry_item, 0u, 0u, 0u};
-                if (__any(carry_item != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
-            }
+            place_carried(spill_n);
             __syncthreads();
-            const uint32_t again = *spill_n;
-            carry_item = 0;
-            if (threadIdx.x < again) {
-                carry_row = spill[threadIdx.x].row;
-                carry_item = spill[threadIdx.x].item;
-            }
+            take_carried(*spill_n);
             __syncthreads();                     // the list is free again for the next tile's appends
             continue;                            // the rows keep the re-placed items: they leave with the next flush
         }
-        // ---- flush: every row leaves as one record of S items (null padded).  The records are read into
-        // registers, the barrier frees the rows, and the stores drain under the next tile's placement.
-        carry_item = 0;
-        if (threadIdx.x < spilled) {
-            carry_row = spill[threadIdx.x].row;
-            carry_item = spill[threadIdx.x].item;
-        }
-        constexpr int FI = NB / kQuadWaves / RPI;   // 8 store instructions per wave
-        uint4 rec[FI];
+        // ---- flush: every row becomes one record of S items (null padded), kept in registers
+        take_carried(spilled);
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
             const uint32_t r = frow0 + (uint32_t)i * RPI;
@@ -287,29 +311,31 @@ __global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint
             rec[i] = v;
             if (fvec == 0) pos[r] = 0;
         }
-        lds_barrier();                           // every wave has its records in registers: the rows are free
-        if (round < rounds_cap) {
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const uint32_t r = frow0 + (uint32_t)i * RPI;
-                const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + round) * S;
-                *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
-            }
-        } else if (threadIdx.x == 0) {
-            *error = 2u;   // cannot happen: one round per tile, rounds_cap = tiles per workgroup
+        if (round >= rounds_cap) {               // cannot happen: one round per tile, rounds_cap = tiles per workgroup
+            if (threadIdx.x == 0) *error = 2u;
+        } else {
+            have_rec = true;
+            ++round;
         }
-        ++round;
+        lds_barrier();                           // every wave has its records in registers: the rows are free
+    }
+    if (have_rec) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) store_rec(i);
     }
     if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
-    // what is still carried over: straight into the table (at most one item per thread)
-    if (carry_item) {
+    // what is still carried over: straight into the table
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if ((carry_item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(carry_row, carry_item, i)], 1ULL);
+    for (int c = 0; c < CARRY; ++c) {
+        if (carry_item[c]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((carry_item[c] >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(carry_row[c], carry_item[c], i)], 1ULL);
+        }
     }
     // items placed after the last flush (carried items of an abandoned last tile) are still in the rows
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < (uint32_t)NB; r += kQuadThreads) {
+    for (uint32_t r = threadIdx.x; r < (uint32_t)NB; r += THREADS) {
         const uint32_t n = min(pos[r], (uint32_t)S);
         for (uint32_t sl = 0; sl < n; ++sl) {
             const uint32_t it = rows[r * S + ((sl + C::rot(r)) & (uint32_t)(S - 1))];
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(kQuadThreads) void quad_scatter_kernel(Span s, uint
     unsigned long long pend_cnt = 0;
     for (uint32_t i = 0; i < defer_n; ++i)
         for (uint32_t q = 0; q < defer_t[i].count; ++q)
-            quad_count_tile_direct<K>(s, tile_step((uint64_t)defer_t[i].first + q), table, pend_hot, pend_cnt);
+            quad_count_tile_direct<K, STEPS>(s, tile_step((uint64_t)defer_t[i].first + q), table, pend_hot, pend_cnt);
     if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
 }
 
@@ -340,48 +366,67 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto add_item = [&](uint32_t it) {
+    // Fast path: one ds_add per k-mer.  GUARD = true (skewed input only, chosen per 16-byte load when the wave's
+    // first items repeat): per form the occurrences of the first active lane's bin are counted with a ballot and
+    // those lanes add to private dummy words -- 64 adds to one LDS address serialise.
+    auto add_item = [&](uint32_t it, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
         const uint32_t low = (it >> 4) & C::kLowMask;
         const uint32_t hi6 = it >> (L + 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t counted = (it >> (3 - i)) & 1u;
             const uint32_t local = ((hi6 & ((1u << (6 - 2 * i)) - 1u)) << (L - 6 + 2 * i)) | (low >> (6 - 2 * i));
-#if defined(KPAL_QUAD_NO_HOT)     // bisecting builds only
-            atomicAdd(&hist[(uint32_t)(i * BINS) + local], counted);
-            continue;
-#endif
-            // hot-bin guard: only when the first active lane's bin repeats in the wave (one pair in ~130 for
-            // uniform k-mers; every lane for a homopolymer) are those lanes diverted and counted by the ballot
-            const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
-            const bool eq = counted && local == hot;
-            const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
-            if (same >= 2u) {   // wave-uniform
+            if constexpr (GUARD) {
+                const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
+                const bool eq = counted && local == hot;
+                const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
                 atomicAdd(&hist[eq ? (uint32_t)(4 * BINS + lane) : (uint32_t)(i * BINS) + local], counted);
-                if (lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[(uint32_t)(i * BINS) + hot], same);
+                if (same && lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[(uint32_t)(i * BINS) + hot], same);
             } else {
                 atomicAdd(&hist[(uint32_t)(i * BINS) + local], counted);
             }
         }
     };
     auto add4 = [&](const uint4 q) {
-        if (q.x) add_item(q.x);
-        if (q.y) add_item(q.y);
-        if (q.z) add_item(q.z);
-        if (q.w) add_item(q.w);
+        // low-complexity sequence repeats whole items across the lanes of a load
+        const uint32_t first = __builtin_amdgcn_readfirstlane(q.x);
+        const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64(q.x == first)) >= 8;   // wave-uniform
+        if (__builtin_expect(skew, 0)) {
+            if (q.x) add_item(q.x, std::true_type{});
+            if (q.y) add_item(q.y, std::true_type{});
+            if (q.z) add_item(q.z, std::true_type{});
+            if (q.w) add_item(q.w, std::true_type{});
+        } else {
+            if (q.x) add_item(q.x, std::false_type{});
+            if (q.y) add_item(q.y, std::false_type{});
+            if (q.z) add_item(q.z, std::false_type{});
+            if (q.w) add_item(q.w, std::false_type{});
+        }
     };
     for (uint32_t g = wave; g < G; g += 16) {   // wave-uniform
         const uint4 *src = reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row * G + g) * rounds_cap) * S);
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
+        // four 16-byte loads per lane in flight; the next four are requested before these are counted
+        auto fetch = [&](uint32_t at) -> uint4 {   // (a select between src[at] and a zero constant becomes a flat load of a selected address)
+            uint4 r = make_uint4(0u, 0u, 0u, 0u);
+            if (at < nvec) r = src[at];
+            return r;
+        };
         uint32_t v = lane;
-        for (; v + 192 < nvec; v += 256) {
-            const uint4 q0 = src[v], q1 = src[v + 64], q2 = src[v + 128], q3 = src[v + 192];
+        uint4 q0 = fetch(v), q1 = fetch(v + 64u), q2 = fetch(v + 128u), q3 = fetch(v + 192u);
+        while (v < nvec) {
+            v += 256u;
+            const uint4 n0 = fetch(v), n1 = fetch(v + 64u), n2 = fetch(v + 128u), n3 = fetch(v + 192u);
             add4(q0);
             add4(q1);
             add4(q2);
             add4(q3);
+            q0 = n0;
+            q1 = n1;
+            q2 = n2;
+            q3 = n3;
         }
-        for (; v < nvec; v += 64) add4(src[v]);
     }
     __syncthreads();
 #pragma unroll

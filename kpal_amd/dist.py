@@ -58,3 +58,125 @@ def count_synth_sharded(ctx, k, seed, n_reads_total, read_len, rank, world_size,
         if own:
             ctx.free(dev_buf)
     return first, n
+
+
+class TableReducer(object):
+    """The multi-GPU merge step of the counting path: per-rank count tables -> their sum on rank 0
+    (+ ``balance`` there), one collective per step.
+
+    ``table``   torch int64 tensor viewing this rank's count table (``table_as_tensor``; a CPU tensor in
+                the gloo tests).
+    ``sync``    callable that waits for the counting kernels (the context's stream is not torch's).
+    ``balance`` callable(tensor) run on the merged table on rank 0, or None.
+    ``mode``    'int64' (default): ``reduce(SUM)`` of the table in place, 128 MiB per rank at k = 12.
+                'u32': the counts travel as 32-bit words -- half the bytes over xGMI (a ring reduce is
+                bound by the per-link rate) -- whenever the LARGEST per-rank bin times the number of ranks
+                fits 31 bits (one scalar all-reduce(MAX) decides, identically on every rank); otherwise
+                that step falls back to int64.  Integer sums: bit-exact either way.
+    ``overlap`` False (default): reduce, then balance, inside the step.  True: the table is copied to a
+                second buffer and reduced asynchronously while the NEXT step counts into the table; the
+                reduce of step i is waited for (and balanced) at the start of step i+1's reduce, the last
+                one by ``drain()``.  Costs one extra table of HBM.
+
+    Both options default off until a multi-GPU scaling run has validated them (SCALE_r*.json)."""
+
+    def __init__(self, table, sync=None, balance=None, mode='int64', overlap=False, dst=0, group=None):
+        if mode not in ('int64', 'u32'):
+            raise ValueError('mode must be int64 or u32')
+        self.table = table
+        self.sync = sync or (lambda: None)
+        self.balance = balance
+        self.mode = mode
+        self.overlap = bool(overlap)
+        self.dst = dst
+        self.group = group
+        self._buf = None          # overlap / u32: the buffer the merged counts end up in
+        self._pending = None      # (work, tensor32 or None)
+        self._result = table
+        self.steps_u32 = 0
+        self.steps_int64 = 0
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def _torch_sync(self):
+        if self.table.is_cuda:
+            import torch
+            torch.cuda.current_stream().synchronize()
+
+    def _fits_32(self, world):
+        """Same answer on every rank: max over ranks of the largest (and smallest) bin."""
+        import torch
+        import torch.distributed as dist
+        m = torch.stack([self.table.max(), -self.table.min()])
+        if world > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        hi, neg_lo = int(m[0]), int(m[1])
+        return neg_lo <= 0 and hi * world < 2 ** 31
+
+    def _start(self):
+        """Launch the collective for the current table; returns (work or None, source tensor, is32)."""
+        import torch
+        import torch.distributed as dist
+        world, _ = self._world()
+        use32 = self.mode == 'u32' and self._fits_32(world)
+        if use32:
+            src = self.table.to(torch.int32)
+            self.steps_u32 += 1
+        elif self.overlap:
+            if self._buf is None:
+                self._buf = torch.empty_like(self.table)
+            self._buf.copy_(self.table)
+            src = self._buf
+            self.steps_int64 += 1
+        else:
+            src = self.table
+            self.steps_int64 += 1
+        work = None
+        if world > 1:
+            work = dist.reduce(src, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=self.overlap)
+        return work, src, use32
+
+    def _finish(self, work, src, use32):
+        import torch
+        _, rank = self._world()
+        if work is not None:
+            work.wait()
+        if use32:
+            if self._buf is None:
+                self._buf = torch.empty_like(self.table)
+            if rank == self.dst:
+                self._buf.copy_(src)          # int32 -> int64
+            self._result = self._buf
+        else:
+            self._result = src
+        self._torch_sync()                     # the context's stream may touch the result now
+        if rank == self.dst and self.balance is not None:
+            self.balance(self._result)
+
+    # -- the step --------------------------------------------------------------------------------
+    def reduce_step(self):
+        """Call after the step's counting kernels have been launched."""
+        self.sync()                            # the table is complete before torch / RCCL read it
+        if not self.overlap:
+            self._finish(*self._start())
+            return
+        self.drain()                           # the previous step's reduce: wait, widen, balance
+        self._pending = self._start()
+        self._torch_sync()                     # the copy out of the table is done: the next count may zero it
+
+    def drain(self):
+        if self._pending is not None:
+            pending, self._pending = self._pending, None
+            self._finish(*pending)
+
+    def result(self):
+        """The merged (and balanced) table of the last finished step; valid on ``dst``."""
+        return self._result
+
+    def result_ptr(self):
+        return self._result.data_ptr()

@@ -121,6 +121,45 @@ if rank == 0:
     want = oracle.count_flat(oracle.synth_reads(3, 0, n_reads, 150), k)
     assert np.array_equal(t.numpy(), want), 'sharded + reduced counts differ from the single-stream count'
     print('GLOO_OK', int(t.sum()))
+# the reducer bench.py uses, every flag combination: three steps over different shards of reads; the merged
+# + balanced table of every step must equal balance(single-stream count), whichever dtype travelled
+for mode in ('int64', 'u32'):
+    for overlap in (False, True):
+        for big in (False, True):          # big: one bin near 2^31 on rank 1 forces the int64 fall-back of the u32 mode
+            table = torch.zeros(4 ** k, dtype=torch.int64)
+            merged = []
+            red = dist.TableReducer(table, balance=lambda t: t.copy_(torch.from_numpy(oracle.balance(t.numpy().copy(), k))),
+                                    mode=mode, overlap=overlap)
+            wants = []
+            for step in range(3):
+                if overlap and step:        # the previous step's result is valid until the next reduce_step starts
+                    red.drain()
+                    if rank == 0:
+                        merged.append(red.result().numpy().copy())
+                mine = oracle.count_flat(oracle.synth_reads(30 + step, first, n, 150), k)
+                if big and rank == 1:
+                    mine[5] += 2 ** 31 - 7
+                table.copy_(torch.from_numpy(mine))
+                red.reduce_step()
+                if not overlap and rank == 0:
+                    merged.append(red.result().numpy().copy())
+                w = oracle.count_flat(oracle.synth_reads(30 + step, 0, n_reads, 150), k)
+                if big:
+                    w[5] += 2 ** 31 - 7
+                wants.append(oracle.balance(w, k))
+            red.drain()
+            if overlap and rank == 0:
+                merged.append(red.result().numpy().copy())
+            if rank == 0:
+                assert len(merged) == 3
+                for got, want in zip(merged, wants):
+                    assert np.array_equal(got, want), (mode, overlap, big)
+                if mode == 'u32':
+                    assert (red.steps_u32, red.steps_int64) == ((0, 3) if big else (3, 0)), (red.steps_u32, red.steps_int64)
+                else:
+                    assert red.steps_u32 == 0
+if rank == 0:
+    print('REDUCER_OK')
 td.barrier()
 td.destroy_process_group()
 '''
@@ -139,6 +178,7 @@ def test_world_size_2_gloo_reduce(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GLOO_OK %d' % (1001 * 145) in outs[0]
+    assert 'REDUCER_OK' in outs[0], outs[0]
 
 
 def test_kmer_caller_host_logic():
