@@ -282,6 +282,15 @@ class Profile(object):
         s = self._device_stats()
         return self.counts.std() if s is None else np.float64(s.std)
 
+    def summary(self):
+        """``total``, ``non_zero``, ``mean``, ``median`` and ``std`` at once: one ``kpal_stats`` call for integer
+        counts (the attributes ``save`` writes and ``kpal info`` prints), the properties otherwise."""
+        s = self._device_stats()
+        if s is None:
+            return dict((key, getattr(self, key)) for key in ('total', 'non_zero', 'mean', 'median', 'std'))
+        return {'total': np.int64(s.total), 'non_zero': int(s.non_zero), 'mean': np.float64(s.mean),
+                'median': np.float64(s.median), 'std': np.float64(s.std)}
+
     # ---- I/O -------------------------------------------------------------------------------
     def save(self, handle, name=None):
         """Write to an open HDF5 k-mer file, dataset ``profiles/<name>`` with the summary
@@ -290,12 +299,7 @@ class Profile(object):
             raise ValueError('Profile name may not contain / or . characters.')
         name = name or self.name or next(str(n) for n in itertools.count(1) if str(n) not in handle['profiles'])
         dataset = handle.create_dataset('profiles/' + name, data=self.counts, dtype='int64', compression='gzip')
-        s = self._device_stats()      # all five summaries from one pass over the counts
-        if s is None:
-            attrs = dict((key, getattr(self, key)) for key in ('total', 'non_zero', 'mean', 'median', 'std'))
-        else:
-            attrs = {'total': np.int64(s.total), 'non_zero': int(s.non_zero), 'mean': np.float64(s.mean),
-                     'median': np.float64(s.median), 'std': np.float64(s.std)}
+        attrs = self.summary()        # all five summaries from one pass over the counts
         dataset.attrs['length'] = self.length
         for key in ('total', 'non_zero', 'mean', 'median', 'std'):
             dataset.attrs[key] = attrs[key]

@@ -278,3 +278,59 @@ def test_fasta_records_follow_seqio_rules():
     from kpal_amd import klib
     text = 'junk\n>r1 desc\nAC\tG T\t\n A\n>\n\tNN \n>r3\n'
     assert list(klib._fasta_records(io.StringIO(text))) == [('r1', 'AC\tGTA'), ('', '\tNN'), ('r3', '')]
+
+
+def test_command_line_surface_without_gpu(tmp_path, monkeypatch):
+    """kpal_amd.kmer.main (kpal/kmer.py:703-975): the seventeen sub-commands with the reference's options and
+    defaults, and the usage errors that are raised before any profile is touched (golden G12's wording)."""
+    import contextlib
+    import json
+    import memh5
+    from kpal_amd import files, kmer
+    parser = kmer.build_parser()
+    ns = parser.parse_args(['distance', os.devnull, os.devnull]) if False else None
+    # defaults of the reference's front end
+    with open(os.path.join(ROOT, 'tests', 'golden', 'cli.json')) as fh:
+        g = json.load(fh)['G12']
+    store = memh5.Store()
+    monkeypatch.setattr(files, 'open_profile_file', store.open)
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / 'a_1.fa').write_text('>r\nACGT\n')
+    (tmp_path / 'a_2.fa').write_text('>r\nACGT\n')
+    for name in ('counted.k8', 'merged.k8'):
+        h = files.ProfileFileType('w')(name)
+        assert h.attrs == {'format': 'kMer', 'version': '1.0.0', 'producer': files.PRODUCER}
+    args = parser.parse_args(['count', 'a_1.fa', 'out.k9'])
+    assert (args.size, args.by_record, args.names) == (9, False, None)
+    args = parser.parse_args(['matrix', 'counted.k8', 'm.txt'])
+    assert (args.precision, args.pairwise, args.distance_function, args.summary, args.threshold) == (10, 'prod', 'default', 'min', 0)
+    assert not (args.do_balance or args.do_positive or args.do_scale or args.do_smooth or args.down)
+    args = parser.parse_args(['shrink', 'counted.k8', 's.k7'])
+    assert args.factor == 1
+    args = parser.parse_args(['merge', 'counted.k8', 'merged.k8', 'mm.k8'])
+    assert (args.merger, args.custom_merger) == ('sum', None)
+    wanted = {' '.join(s['argv']): s for s in g['steps'] if s['status']}
+    for argv in (['count', '-k', '8', 'a_1.fa', 'counted.k8'], ['nosuchcommand'], ['info', 'a_1.fa'], ['info', 'nosuch.k8'],
+                 ['count', '-k', '4', 'a_1.fa', 'a_2.fa', 'bad_names.k4', '-p', 'only_one'],
+                 ['cat', 'counted.k8', 'merged.k8', 'bad_prefix.k8', '-x', 'p_']):
+        se = io.StringIO()
+        with contextlib.redirect_stderr(se), pytest.raises(SystemExit) as exc:
+            kmer.main(argv)
+        assert exc.value.code == 2
+        err = se.getvalue().strip().split('\n')[-1].split('error: ', 1)[1]
+        want = wanted[' '.join(argv)]['error']
+        if 'Unable to open file' in want or 'invalid choice' in want:
+            assert err.split(':')[:2] == want.split(':')[:2]
+        else:
+            assert err == want
+    # versions the reference accepts: >=1.0.0,<2.0.0 (kpal/__init__.py:41)
+    assert files.format_version_accepted('1.0.0') and files.format_version_accepted(b'1.4.2') and not files.format_version_accepted('2.0.0')
+    h = store.open('counted.k8', 'r')
+    h.attrs['version'] = '2.1.0'
+    with pytest.raises(Exception, match='not supported'):
+        files.ProfileFileType('r')('counted.k8')
+    h.attrs['format'] = 'other'
+    with pytest.raises(Exception, match='not a k-mer profile file'):
+        files.ProfileFileType('r')('counted.k8')
+    with pytest.raises(Exception, match='file exists'):
+        files.FileType('w')('a_1.fa')

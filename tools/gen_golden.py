@@ -14,7 +14,12 @@ Fixture groups follow SURVEY.md section 8c (G1..G8); G9 pins every ProfileDistan
 kpal/kdistlib.py:126-161); G10 pins the profile summaries, Profile.merge with every built-in
 merger and Profile.shrink (kpal/klib.py:193-225,269-283,329-352); G11 pins the callers of section 8
 row a14 (kmer.count/merge/balance/get_balance/get_stats/distance/distance_matrix) through real HDF5
-files.  Only DATA is written: inputs and the reference's outputs.
+files; G12 pins the command line: kpal.kmer.main([...]) for every sub-command on the tutorial files
+(kpal/kmer.py:703-975) -- stdout / text outputs, the stored counts (sha256), dataset and file attributes,
+and the usage errors.  Only DATA is written: inputs and the reference's outputs.
+
+    ... tools/gen_golden.py            # everything
+    ... tools/gen_golden.py g12        # only tests/golden/cli.json
 """
 from __future__ import print_function
 
@@ -534,11 +539,152 @@ def g11():
     return out
 
 
+def g12():
+    """The command line (kpal/kmer.py:703-975): every sub-command through kmer.main in a scratch directory
+    holding the tutorial FASTA files.  Per step: argv, exit status, stdout, the text files and the profile
+    files it created (root attributes, per-profile attributes, sha256 of the stored counts; for `shuffle`
+    the sha256 of the SORTED counts), and for failing steps the message after "error: "."""
+    import contextlib
+    import shutil
+    import tempfile
+    import h5py
+    tdir = os.path.join(OUT, 'tutorial')
+    tmp = tempfile.mkdtemp()
+    for n in ('a_1', 'a_2', 'b_1', 'b_2', 'c_1', 'c_2'):
+        shutil.copy(os.path.join(tdir, n + '.fa'), tmp)
+    inputs = {
+        'rec.fa': '>first some title\nACGTTGCAACGT\nACG\n>second\nNNACGTN\n>third\nAC\n',
+        # old plaintext format: three header lines (length, total, non-zero), then one count per line
+        'old1.txt': '2\n20\n9\n' + '\n'.join(str(v) for v in [3, 0, 1, 2, 0, 0, 4, 1, 0, 5, 0, 0, 2, 1, 0, 1]) + '\n',
+        'old2.txt': '2\n16\n16\n' + '\n'.join(['1'] * 16) + '\n',
+    }
+    for name, text in inputs.items():
+        with open(os.path.join(tmp, name), 'w') as fh:
+            fh.write(text)
+
+    def describe(path, sort_counts=False):
+        with h5py.File(path, 'r') as f:
+            root = dict((k, v.decode() if isinstance(v, bytes) else str(v)) for k, v in f.attrs.items())
+            profiles = {}
+            for name in sorted(f['profiles']):
+                ds = f['profiles/' + name]
+                counts = ds[:].astype('<i8')
+                if sort_counts:
+                    counts = np.sort(counts)
+                profiles[name] = {'attrs': dict((k, float(v) if isinstance(v, (float, np.floating)) else int(v))
+                                                for k, v in ds.attrs.items()),
+                                  'sha256': hashlib.sha256(counts.tobytes()).hexdigest()}
+                if sort_counts:      # the attributes that do not depend on the order
+                    profiles[name]['attrs'] = dict((k, v) for k, v in profiles[name]['attrs'].items())
+        return {'root': root, 'profiles': profiles}
+
+    steps = [
+        ['count', '-k', '8', 'a_1.fa', 'a_2.fa', 'b_1.fa', 'b_2.fa', 'c_1.fa', 'c_2.fa', 'counted.k8'],
+        ['count', '-k', '5', 'a_1.fa', 'a_2.fa', 'named.k5', '-p', 'x', 'y'],
+        ['count', '-k', '4', '--by-record', 'rec.fa', 'rec.k4'],
+        ['count', '-k', '3', '-r', 'rec.fa', 'rec.fa', 'rec2.k3', '-p', 'p', 'q'],
+        ['count', 'a_1.fa', 'default.k9'],
+        ['info', 'counted.k8'],
+        ['info', 'counted.k8', '-p', 'b_2'],
+        ['stats', 'counted.k8'],
+        ['stats', '-n', '4', 'counted.k8', '-p', 'b_2', 'a_1'],
+        ['showbalance', 'counted.k8'],
+        ['showbalance', '-n', '3', 'counted.k8', '-p', 'b_1'],
+        ['distr', 'counted.k8', 'distr.txt', '-p', 'a_1', 'c_2'],
+        ['getcount', 'counted.k8', 'ACGTACGT'],
+        ['getcount', 'counted.k8', 'TTTTTTTT', '-p', 'c_1'],
+        ['merge', 'counted.k8', 'counted.k8', 'merged.k8', '-l', 'a_1', 'b_1', '-r', 'a_2', 'b_2'],
+        ['merge', '-m', 'xor', 'counted.k8', 'counted.k8', 'merged_xor.k8', '-l', 'a_1', '-r', 'a_2'],
+        ['merge', '-m', 'nint', 'counted.k8', 'counted.k8', 'merged_nint.k8', '-l', 'c_1', '-r', 'c_1'],
+        ['merge', '-c', 'np.maximum(left, right)', 'counted.k8', 'counted.k8', 'merged_custom.k8', '-l', 'c_1', '-r', 'c_2'],
+        ['balance', 'counted.k8', 'balanced.k8', '-p', 'a_1', 'c_2'],
+        ['cat', 'counted.k8', 'merged.k8', 'cat.k8', '-x', 'p_', 'q_'],
+        ['cat', 'counted.k8', 'merged.k8', 'cat_sel.k8', '-p', 'a_1', 'b_1_b_2', 'nosuch'],
+        ['cat', 'counted.k8', 'left.k8', '-p', 'a_1', 'b_1', 'c_1'],
+        ['cat', 'counted.k8', 'right.k8', '-p', 'a_2', 'b_2', 'c_2'],
+        ['positive', 'left.k8', 'right.k8', 'pos_l.k8', 'pos_r.k8'],
+        ['scale', 'left.k8', 'right.k8', 'sc_l.k8', 'sc_r.k8'],
+        ['scale', '-d', 'left.k8', 'right.k8', 'scd_l.k8', 'scd_r.k8', '-l', 'a_1', '-r', 'c_2'],
+        ['shrink', 'counted.k8', 'shrunk.k7'],
+        ['shrink', '-f', '3', 'counted.k8', 'shrunk.k5', '-p', 'c_1'],
+        ['shuffle', 'counted.k8', 'shuffled.k8', '-p', 'a_1'],
+        ['smooth', 'left.k8', 'right.k8', 'sm_l.k8', 'sm_r.k8', '-s', 'average', '-t', '2'],
+        ['smooth', 'left.k8', 'right.k8', 'smc_l.k8', 'smc_r.k8', '-M', 'np.max(values)', '-t', '3', '-l', 'a_1', '-r', 'b_2'],
+        ['distance', 'left.k8', 'right.k8'],
+        ['distance', '-n', '3', 'left.k8', 'right.k8'],
+        ['distance', '-b', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '-P', 'sum', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '-D', 'euclidean', '-n', '6', 'left.k8', 'right.k8'],
+        ['distance', '-D', 'cosine', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '-m', '-s', 'median', '-t', '1', '-S', '-d', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '--positive', '-S', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '-f', 'abs(left - right) / (left + right + 2)', '-n', '8', 'left.k8', 'right.k8'],
+        ['distance', '-n', '8', 'left.k8', 'right.k8', '-l', 'c_1', 'a_1', '-r', 'b_2', 'b_2'],
+        ['matrix', 'counted.k8', 'matrix.txt', '-n', '3'],
+        ['matrix', '-b', '-n', '8', 'counted.k8', 'matrix_b.txt', '-p', 'c_2', 'a_1', 'b_1'],
+        ['matrix', '-D', 'euclidean', '-n', '6', 'counted.k8', 'matrix_e.txt'],
+        ['matrix', '-m', '-s', 'min', '-t', '1', '-S', '-n', '8', 'counted.k8', 'matrix_s.txt'],
+        ['convert', 'old1.txt', 'old2.txt', 'converted.k2'],
+        ['convert', 'old1.txt', 'converted_named.k2', '-p', 'o1'],
+        # usage errors (exit status 2)
+        ['count', '-k', '8', 'a_1.fa', 'counted.k8'],                              # the output exists
+        ['info', 'a_1.fa'],                                                         # not a k-mer profile file
+        ['info', 'nosuch.k8'],
+        ['getcount', 'counted.k8', 'ACGT'],
+        ['getcount', 'counted.k8', 'ACGTNCGT'],
+        ['matrix', 'counted.k8', 'matrix_one.txt', '-p', 'a_1'],
+        ['distance', 'left.k8', 'right.k8', '-l', 'a_1'],
+        ['distance', 'left.k8', 'named.k5', '-l', 'a_1', '-r', 'x'],
+        ['count', '-k', '4', 'a_1.fa', 'a_2.fa', 'bad_names.k4', '-p', 'only_one'],
+        ['cat', 'counted.k8', 'merged.k8', 'bad_prefix.k8', '-x', 'p_'],
+        ['shrink', '-f', '8', 'counted.k8', 'bad_shrink.k0'],
+        ['nosuchcommand'],
+    ]
+    out = []
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        for argv in steps:
+            before = set(os.listdir(tmp))
+            so, se = io.StringIO(), io.StringIO()
+            status = 0
+            with contextlib.redirect_stdout(so), contextlib.redirect_stderr(se):
+                try:
+                    kmer.main(argv)
+                except SystemExit as e:
+                    status = e.code
+            rec = {'argv': argv, 'status': status, 'stdout': so.getvalue()}
+            if status:
+                err = se.getvalue().strip().split('\n')[-1]
+                rec['error'] = err.split('error: ', 1)[1] if 'error: ' in err else err
+            created = sorted(set(os.listdir(tmp)) - before)
+            rec['text_files'] = {}
+            rec['profile_files'] = {}
+            for name in created:
+                path = os.path.join(tmp, name)
+                if name.endswith('.txt'):
+                    with open(path) as fh:
+                        rec['text_files'][name] = fh.read()
+                elif status == 0:
+                    rec['profile_files'][name] = describe(path, sort_counts=argv[0] == 'shuffle')
+                else:
+                    rec['left_behind'] = rec.get('left_behind', []) + [name]
+            out.append(rec)
+    finally:
+        os.chdir(cwd)
+    return {'inputs': inputs, 'steps': out}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     arrays = {}
     meta = {'generator': 'tools/gen_golden.py', 'reference': 'kPAL 2.1.2.dev (/root/reference)',
             'python': sys.version.split()[0], 'numpy': np.__version__}
+    if sys.argv[1:] == ['g12']:
+        with open(os.path.join(OUT, 'cli.json'), 'w') as fh:
+            json.dump({'meta': meta, 'G12': g12()}, fh, indent=0)
+        print('wrote cli.json')
+        return
     with open(os.path.join(OUT, 'counts.json'), 'w') as fh:
         json.dump({'meta': meta, 'G1': g1(), 'G2': g2()}, fh)
     with open(os.path.join(OUT, 'synth.json'), 'w') as fh:
@@ -557,6 +703,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'summaries.npz'), **sum_arrays)
     with open(os.path.join(OUT, 'callers.json'), 'w') as fh:
         json.dump({'meta': meta, 'G11': g11()}, fh, indent=0)
+    with open(os.path.join(OUT, 'cli.json'), 'w') as fh:
+        json.dump({'meta': meta, 'G12': g12()}, fh, indent=0)
     print('wrote', sorted(os.listdir(OUT)))
 
 

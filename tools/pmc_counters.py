@@ -29,12 +29,14 @@ def main():
                         rec = acc[name][row['Counter_Name']]
                         rec[0] += float(row['Counter_Value'])
                         rec[1].add(row['Dispatch_Id'])
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_sha
     try:
         head = subprocess.check_output(['git', 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL,
                                        cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
     except Exception:
         head = os.environ.get('KPAL_HEAD', 'unknown')
-    out = {'note': note, 'head': head, 'kernels': {}}
+    out = {'note': note, 'head': head, 'src_sha': source_sha(), 'kernels': {}}
     for name, counters in sorted(acc.items()):
         rec = {}
         for c, (total, ids) in sorted(counters.items()):

@@ -15,6 +15,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 def collect(root, counter):
     per = collections.defaultdict(lambda: [0.0, set()])
@@ -39,7 +41,8 @@ def main():
     launches = [n for name, (_, n) in fetch.items() if kernel in name]
     if len(launches) != 1:
         sys.exit('pmc_summary: %d kernels match %r' % (len(launches), kernel))
-    out = {'note': note, 'input_bytes_of_the_run': run_bytes, 'launches_of': kernel, 'launches': launches[0],
+    from bench import source_sha
+    out = {'note': note, 'head': os.environ.get('KPAL_HEAD', 'unknown'), 'src_sha': source_sha(), 'input_bytes_of_the_run': run_bytes, 'launches_of': kernel, 'launches': launches[0],
            'input_bytes_per_launch_avg': run_bytes / launches[0], 'kernels': {}}
     for name in fetch:
         f, n = fetch[name]
