@@ -618,34 +618,107 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
 
 // Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
 // one workgroup per bucket histograms.  pool[bucket][workgroup][round] holds one record per flush round.
+// Expected number of items per round that do not fit their row: sum over rows of E[max(X - slots, 0)], X ~ Poisson(mu).
+static double quad_expected_overflow(const std::vector<double> &mu, int slots)
+{
+    double total = 0.0;
+    for (double m : mu) {
+        if (m <= 0.0) continue;
+        if (m > 4.0 * slots) {   // far above the capacity: no tail to speak of
+            total += m - slots;
+            continue;
+        }
+        // E[max(X - c, 0)] = sum_{x > c} (x - c) p(x); p by recurrence from p(0) = exp(-m)
+        double p = std::exp(-m), acc = 0.0;
+        const int upto = (int)(m + 12.0 * std::sqrt(m) + 40.0);
+        for (int x = 1; x <= upto; ++x) {
+            p *= m / x;
+            if (x > slots) acc += (x - slots) * p;
+        }
+        total += acc;
+    }
+    return total;
+}
+
+// Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
+// one workgroup per bucket histograms.  pool[bucket][workgroup][round] holds one record per flush round.
 static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    const uint64_t tiles = (total_steps + kQuadTileSteps - 1) / kQuadTileSteps;
+    const int buckets = ctx->k == 12 ? 2048 : 512, slots = kQuadRowWords / buckets;
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048) * sizeof(uint32_t)));
+    uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
+    uint32_t *error = nrounds + ctx->num_cu;
+    uint32_t *load = error + 4;
+    if (!ctx->quad_error_word) {
+        HIPCHK(hipMemsetAsync(error, 0, 4 * sizeof(uint32_t), ctx->stream));
+        ctx->quad_error_word = error;
+    }
+    // ---- tile size.  A tile of 8 waves x STEPS wave-steps brings ~0.119 x 8 x STEPS items per 16-slot row at k = 12 when
+    // the k-mers are uniform; the row loads of a 1/64 sample say what THIS input brings.  The largest STEPS whose expected
+    // overflow per round stays well inside the spill list is used (KPAL_QUAD_STEPS forces one: A/B timing, tests).
+    static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
+    static const int candidates[] = {13, 12, 8, 6, 4, 3, 2};
+    int steps = 0;
+    for (int c : candidates)
+        if (c == steps_env) steps = c;
+    if (!steps) {
+        const uint32_t sample_steps = 4;                                       // per wave: 32 KiB per workgroup
+        const uint64_t want = std::max<uint64_t>(1, total_steps / (64ull * 8 * sample_steps));   // ~1/64 of the input
+        const uint32_t groups = (uint32_t)std::min<uint64_t>(want, 1024);
+        const uint64_t stride = std::max<uint64_t>(8 * sample_steps, total_steps / groups);
+        HIPCHK(hipMemsetAsync(load, 0, (size_t)buckets * sizeof(uint32_t), ctx->stream));
+        DISPATCH_K_8_12(ctx->k, LAUNCH(ctx, "quad_sample", (quad_sample_kernel<K>), dim3(groups), dim3(512), s, stride, sample_steps, load));
+        std::vector<uint32_t> h((size_t)buckets);
+        HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
+        std::vector<double> per_step((size_t)buckets), mu((size_t)buckets);
+        for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
+        steps = candidates[sizeof(candidates) / sizeof(candidates[0]) - 1];
+        for (int c : candidates) {
+            for (int b = 0; b < buckets; ++b) mu[b] = per_step[b] * 8 * c;
+            if (quad_expected_overflow(mu, slots) <= 700.0) {                  // list: 2048 entries
+                steps = c;
+                break;
+            }
+        }
+    }
+    const uint64_t tile_steps = 8ull * steps;
+    const uint64_t tiles = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cu, tiles);
-    static const int waves = [] { const char *e = getenv("KPAL_QUAD_WAVES"); const int w = e ? atoi(e) : 8; return w == 16 ? 16 : 8; }();   // A/B
     const uint64_t tpb = (tiles + G - 1) / G;          // tiles (= flush rounds) per workgroup
     if (tpb > 0xFFFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
     const size_t pool_bytes = (size_t)kQuadRowWords * 4 * G * tpb;   // every round writes all rows: 128 KiB per workgroup
     CHK(ensure(ctx, ctx->keys, pool_bytes));
-    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4) * sizeof(uint32_t)));
-    uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
-    uint32_t *error = nrounds + ctx->num_cu;
-    if (!ctx->quad_error_word) {
-        HIPCHK(hipMemsetAsync(error, 0, sizeof(uint32_t), ctx->stream));
-        ctx->quad_error_word = error;
-    }
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
+#define KPAL_QUAD_LAUNCH(S)                                                                                                \
+    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, S, S>), dim3(G), dim3(512), s, tpb, pool, (uint32_t)tpb, nrounds, \
+           error, table)
     DISPATCH_K_8_12(ctx->k, {
-        if (waves == 16)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
-        else
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8>), dim3(G), dim3(512), s, tpb, pool, (uint32_t)tpb, nrounds, error, table);
+        switch (steps) {
+        case 13: KPAL_QUAD_LAUNCH(13); break;
+        case 8: KPAL_QUAD_LAUNCH(8); break;
+        case 6: KPAL_QUAD_LAUNCH(6); break;
+        case 4: KPAL_QUAD_LAUNCH(4); break;
+        case 3: KPAL_QUAD_LAUNCH(3); break;
+        case 2: KPAL_QUAD_LAUNCH(2); break;
+        default: KPAL_QUAD_LAUNCH(12); break;
+        }
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
                (const uint32_t *)nrounds, G, (uint32_t)tpb, table);
     });
+#undef KPAL_QUAD_LAUNCH
+    static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
+    if (verbose) {   // diagnostics: tile size chosen, tiles abandoned to the direct path
+        uint32_t st[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(st, error, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[kpal quad] k=%d steps/wave/tile=%d tiles=%llu workgroups=%u abandoned tiles so far=%u\n", ctx->k, steps,
+                (unsigned long long)tiles, G, st[1]);
+    }
     return KPAL_OK;
 }
 
@@ -788,7 +861,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
     }
     else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
-        // the record pool takes 4/3 of the input bytes: pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
+        // the record pool takes 4/3 of the input bytes (up to 8 x that for heavily skewed input, whose tiles are
+        // smaller): pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
     }
     else if (strat == KPAL_STRATEGY_PARTITION2) {

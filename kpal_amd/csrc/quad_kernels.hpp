@@ -31,8 +31,7 @@
 
 namespace kpal {
 
-constexpr int kQuadTileSteps = 96;            // 96 KiB of input per tile: ~11.4 items per 16-slot row (71 % full records)
-constexpr int kQuadSpillCap = 1024;           // spilled items a round may carry over
+constexpr int kQuadSpillCap = 2048;           // spilled items a round may carry over (16 KiB of LDS)
 constexpr int kQuadDeferCap = 256;
 constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
 
@@ -86,38 +85,74 @@ struct QuadSpill {
     uint32_t row, item;
 };
 
-// One slot allocation + one LDS write per item; items whose row is full go to the spill list.
+// Items straight into the table (overflow of carried items, the carried items of an abandoned round, what is
+// still carried at the end).  Call wave-converged; `active` selects the lanes that hold an item.  Low-complexity
+// input makes these items identical across lanes: up to four rounds of "the first remaining lane's item, counted
+// with a ballot, one lane adds the count" before the rest adds individually.
 template <int K>
-__device__ __forceinline__ void quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n,
-                                           const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *dbg_table = nullptr)
+__device__ __forceinline__ void quad_items_direct(bool active, uint32_t row, uint32_t item, unsigned long long *__restrict__ table)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
+    for (int round = 0; round < 4 && todo; ++round) {   // wave-uniform
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(row, src);
+        const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(item, src);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(active && row == hot_row && item == hot_item) & todo;
+        if (lane == src) {
+            const unsigned long long n = (unsigned long long)__popcll(same);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((hot_item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(hot_row, hot_item, i)], n);
+        }
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(row, item, i)], 1ULL);
+    }
+}
+
+// One slot allocation + one LDS write per item; items whose row is full go to the spill list -- or, with
+// DIRECT (items that were carried over once already: their row is persistently over-full), straight into the
+// table, so that a hot row cannot pile up carried items round after round.
+// Returns the mask (bit q) of this lane's items that did not fit their row.
+template <int K, bool DIRECT = false>
+__device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
+                                               const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *table = nullptr)
 {
     using C = QuadCfg<K>;
     uint32_t slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) slot[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 1u : 0u);
-    bool over = false;
+    uint32_t over = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const bool counted = (item[q] & 15u) != 0u;
         const bool fits = slot[q] < (uint32_t)C::kSlots;
         const uint32_t at = row[q] * C::kSlots + ((slot[q] + C::rot(row[q])) & (uint32_t)(C::kSlots - 1));
         rows[(counted && fits) ? at : (uint32_t)kQuadRowWords] = item[q];     // not counted / full row: dummy word
-        over |= counted && !fits;
+        over |= (counted && !fits) ? (1u << q) : 0u;
     }
-    if (__builtin_expect(__any(over), 0)) {   // wave-uniform
+    if (__builtin_expect(__any(over != 0u), 0)) {   // wave-uniform
+#if defined(KPAL_QUAD_NO_CARRY)   // bisecting builds only: spilled items straight into the table
+        constexpr bool direct = true;
+#else
+        constexpr bool direct = DIRECT;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if ((item[q] & 15u) && slot[q] >= (uint32_t)C::kSlots) {
-#if defined(KPAL_QUAD_NO_CARRY)   // bisecting builds only: spilled items straight into the table
-                for (int i = 0; i < 4; ++i)
-                    if ((item[q] >> (3 - i)) & 1u) atomicAdd(&dbg_table[quad_kmer<K>(row[q], item[q], i)], 1ULL);
-                continue;
-#endif
+            const bool ov = (item[q] & 15u) && slot[q] >= (uint32_t)C::kSlots;
+            if constexpr (direct) {
+                quad_items_direct<K>(ov, row[q], item[q], table);
+            } else if (ov) {
                 const uint32_t at = atomicAdd(spill_n, 1u);
-                if (at < (uint32_t)kQuadSpillCap) spill[at] = QuadSpill{row[q], item[q]};
+                if (at < cap) spill[at] = QuadSpill{row[q], item[q]};
             }
         }
     }
+    return over;
 }
 
 // Abandoned tile: its k-mers straight into the table (chunk_count_tile_direct with this tile shape).
@@ -157,16 +192,86 @@ __device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t f
     }
 }
 
+// The items a thread carries from one round to the next (entries threadIdx.x + c * THREADS of the spill list).
+// Plain functions on array references: as [&] lambdas the arrays were kept in scratch memory.
+template <int K, int CARRY>
+__device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
+                                                   const uint32_t (&carry_row)[CARRY], uint32_t (&carry_item)[CARRY],
+                                                   unsigned long long *table)
+{
+#pragma unroll
+    for (int c = 0; c < CARRY; ++c) {
+        const uint32_t r4[4] = {carry_row[c], 0u, 0u, 0u};
+        const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
+        if (__any(carry_item[c] != 0u)) {
+            // an item that does not fit even now went straight into the table: it is no longer carried (an
+            // abandoned round adds what is still carried, and must not add it twice)
+            if (quad_place<K, true>(rows, pos, spill, spill_n, cap, r4, i4, table) & 1u) carry_item[c] = 0;
+        }
+    }
+}
+
+template <int CARRY, int THREADS>
+__device__ __forceinline__ void quad_take_carried(const QuadSpill *spill, uint32_t n, uint32_t (&carry_row)[CARRY],
+                                                  uint32_t (&carry_item)[CARRY])
+{
+#pragma unroll
+    for (int c = 0; c < CARRY; ++c) {
+        const uint32_t e = threadIdx.x + (uint32_t)c * THREADS;
+        carry_item[c] = 0;
+        if (e < n) {
+            carry_row[c] = spill[e].row;
+            carry_item[c] = spill[e].item;
+        }
+    }
+}
+
+// Q0: row loads of a sample of the input.  Workgroup g encodes `steps` wave-steps starting at its share of the
+// stream and adds every item to load[row] (global atomics: a few hundred thousand).  The host picks the tile size
+// from these loads: rows that would be over-full every round (compositional skew, e.g. an AT-rich genome) call
+// for smaller tiles, a handful of very hot rows (poly-A, satellites) are left to the spill list.
+template <int K>
+__global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t stride_steps, uint32_t steps, uint32_t *__restrict__ load)
+{
+    using C = QuadCfg<K>;
+    __shared__ uint32_t cnt[C::kBuckets];
+    for (int i = threadIdx.x; i < C::kBuckets; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6;
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint64_t first = (uint64_t)blockIdx.x * stride_steps + (uint64_t)wave * steps;
+    if (first < total_steps) {
+        Chunk carry = load_chunk(s, (int64_t)(first * 64) - 1);
+        for (uint32_t st = 0; st < steps && first + st < total_steps; ++st) {
+            uint64_t window;
+            uint32_t mask;
+            part_step<K>(s, first + st, carry, window, mask);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
+                uint32_t row, item;
+                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row, item);
+                atomicAdd(&cnt[row], (item & 15u) ? 1u : 0u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C::kBuckets; i += blockDim.x)
+        if (cnt[i]) atomicAdd(&load[i], cnt[i]);
+}
+
 // Q1: ASCII -> records.  Tile j of workgroup g is tile j * G + g of the input (the grid reads one sliding
-// window); wave w takes its steps STEPS*w .. STEPS*w+STEPS-1 (WAVES x STEPS = 96).  Per tile: place (the items
+// window); wave w takes its steps STEPS*w .. STEPS*w+STEPS-1.  A tile of WAVES x STEPS KiB brings
+// 0.119 x WAVES x STEPS items per 16-slot row at k = 12 (96 steps: 11.4, records 71 % full, 1.5 % of the items
+// spill; 112: 13.3, 83 %, 4 %; 120: 14.3, 89 %, 6 %).  Per tile: place (the items
 // carried over from the previous round first), barrier, read every row as one padded record into registers,
 // barrier.  The records are STORED during the placement of the next tile, a store instruction or two per
 // step, and each step's chunk of the next tile is requested as soon as this tile's has been encoded: the
 // CU's memory pipe (8-10 B/clk for loads + stores together, tools/store_probe2.hip) stays busy under the
-// LDS / VALU work instead of alternating with it.  WAVES = 8 (12 steps per wave, 256 registers per lane:
-// 16 records + 12 chunks live) or 16 (6 steps, 128 registers).
+// LDS / VALU work instead of alternating with it.  WAVES = 8 (256 registers per lane; 16 records live) or 16 (128
+// registers; 8 records live).
 // pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots.
-template <int K, int WAVES>
+template <int K, int WAVES, int STEPS, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
                                                                   uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
                                                                   uint32_t *__restrict__ error,
@@ -175,9 +280,10 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     using C = QuadCfg<K>;
     constexpr int S = C::kSlots, NB = C::kBuckets;
     constexpr int THREADS = WAVES * 64;
-    constexpr int STEPS = kQuadTileSteps / WAVES;
+    constexpr int kQuadTileSteps = WAVES * STEPS;
     constexpr int CARRY = kQuadSpillCap / THREADS;      // carried items per thread
-    static_assert(WAVES * STEPS == kQuadTileSteps && CARRY * THREADS == kQuadSpillCap, "tile shape");
+    constexpr uint32_t CAP = CARRY * THREADS;           // spill list entries in use (2048; 1536 with 12 waves)
+    static_assert(CARRY >= 1 && STEPS % DEPTH == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
     __shared__ uint32_t pos[NB];
     __shared__ QuadSpill spill[kQuadSpillCap];
@@ -197,49 +303,33 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     auto tile_step = [&](uint64_t j) -> uint64_t { return ((j * gridDim.x + blockIdx.x) * WAVES + (uint64_t)wave) * STEPS; };
     auto tile_exists = [&](uint64_t j) -> bool { return j < tiles_per_block && (j * gridDim.x + blockIdx.x) * (uint64_t)kQuadTileSteps < total_steps; };
-    uint4 raw[STEPS];
+    // input chunks are requested DEPTH steps ahead (DEPTH KiB per wave in flight) into a ring of DEPTH
+    // register quadruples; DEPTH divides STEPS, so the ring position of a step does not depend on the tile
+    uint4 raw[DEPTH];
     uint4 rawh;
     {
         const uint64_t f = tile_step(0);
 #pragma unroll
-        for (int st = 0; st < STEPS; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+        for (int st = 0; st < DEPTH; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
         rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
     }
     uint32_t round = 0;                         // records written per row so far
     uint32_t carry_row[CARRY], carry_item[CARRY];   // items carried over from the previous round (item 0 = none)
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) carry_row[c] = carry_item[c] = 0;
-    auto place_carried = [&](uint32_t *spill_n) {
-#pragma unroll
-        for (int c = 0; c < CARRY; ++c) {
-            const uint32_t r4[4] = {carry_row[c], 0u, 0u, 0u};
-            const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
-            if (__any(carry_item[c] != 0u)) quad_place<K>(rows, pos, spill, spill_n, r4, i4, table);
-        }
-    };
-    auto take_carried = [&](uint32_t n) {
-#pragma unroll
-        for (int c = 0; c < CARRY; ++c) {
-            const uint32_t e = threadIdx.x + (uint32_t)c * THREADS;
-            carry_item[c] = 0;
-            if (e < n) {
-                carry_row[c] = spill[e].row;
-                carry_item[c] = spill[e].item;
-            }
-        }
-    };
     // the flush: FI store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores
-    constexpr int LPR = S / 4;                  // lanes per record
-    constexpr int RPI = 64 / LPR;               // records per instruction
-    constexpr int FI = NB / WAVES / RPI;        // 8 (16 waves) or 16 (8 waves)
-    const uint32_t frow0 = (uint32_t)wave * (NB / WAVES) + (uint32_t)lane / LPR;
-    const uint32_t fvec = (uint32_t)lane % LPR;
+    // thread t handles the 16-byte vectors t, t + THREADS, ... of the 8192 that make up the rows
+    constexpr int LPR = S / 4;                  // lanes (vectors) per record
+    constexpr int NVEC = NB * LPR;
+    constexpr int FI = (NVEC + THREADS - 1) / THREADS;   // 8 (16 waves), 11 (12 waves), 16 (8 waves)
     uint4 rec[FI];                              // the previous round's records, stored during this tile's placement
     bool have_rec = false;                      // block-uniform
     auto store_rec = [&](int i) {
-        uint32_t r = frow0 + (uint32_t)i * RPI;
-        asm volatile("" : "+v"(r));             // the FI record addresses are recomputed per store (3 VALU), not hoisted
+        uint32_t v = threadIdx.x + (uint32_t)i * THREADS;
+        asm volatile("" : "+v"(v));             // the FI record addresses are recomputed per store (a few VALU), not hoisted
                                                 // out of the tile loop as 2 * FI live registers (see chunk_store_rows)
+        if (NVEC % THREADS != 0 && v >= (uint32_t)NVEC) return;
+        const uint32_t r = v / LPR, fvec = v % LPR;
         const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + (round - 1u)) * S;
         *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
     };
@@ -249,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const uint64_t fnext = tile_step(j + 1);
         uint32_t *spill_n = &spill_cnt[j & 1];
         // ---- place: carried items, then this tile's
-        place_carried(spill_n);
+        quad_place_carried<K, CARRY>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table);
         Chunk carry = encode16(rawh);
         range_fix(s, (int64_t)(first * 64) - 1, carry);
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
@@ -261,11 +351,12 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             }
             uint64_t window;
             uint32_t mask;
-            encode_step<K>(s, first + st, raw[st], carry, window, mask);
-            if (more) {
+            encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask);
+            {
                 uint32_t l = (uint32_t)lane;
                 asm volatile("" : "+v"(l));     // (same: no STEPS hoisted 64-bit load addresses)
-                raw[st] = fetch_chunk(s, (int64_t)((fnext + st) * 64 + l));
+                if (st + DEPTH < STEPS) raw[st % DEPTH] = fetch_chunk(s, (int64_t)((first + st + DEPTH) * 64 + l));
+                else if (more) raw[st % DEPTH] = fetch_chunk(s, (int64_t)((fnext + (st + DEPTH - STEPS)) * 64 + l));
             }
             uint32_t row[4], item[4];
 #pragma unroll
@@ -273,34 +364,37 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                 const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row[q], item[q]);
             }
-            quad_place<K>(rows, pos, spill, spill_n, row, item, table);
+            quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table);
         }
         have_rec = false;
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
         const uint32_t spilled = *spill_n;       // reset only during the flush of the NEXT tile
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
-        if (__builtin_expect(spilled > (uint32_t)kQuadSpillCap, 0)) {
+        if (__builtin_expect(spilled > CAP, 0)) {
             // block-uniform, pathological input only: forget the round, count the tile directly after the loop.
-            // The items carried INTO this round are placed again (they are still in registers); what spills of
-            // those (they fit the list) is carried on.
+            // The items carried INTO this round (still in registers) go straight into the table: nothing stays
+            // parked in the rows, so any number of consecutive rounds may be abandoned.
             __syncthreads();                     // every thread has read `spilled`
             for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
             if (threadIdx.x == 0) {
                 *spill_n = 0;
                 defer_tile(defer_t, defer_n, (uint32_t)j, error);
             }
+#pragma unroll
+            for (int c = 0; c < CARRY; ++c) {
+                quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table);
+                carry_item[c] = 0;
+            }
             __syncthreads();
-            place_carried(spill_n);
-            __syncthreads();
-            take_carried(*spill_n);
-            __syncthreads();                     // the list is free again for the next tile's appends
-            continue;                            // the rows keep the re-placed items: they leave with the next flush
+            continue;
         }
         // ---- flush: every row becomes one record of S items (null padded), kept in registers
-        take_carried(spilled);
+        quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
-            const uint32_t r = frow0 + (uint32_t)i * RPI;
+            const uint32_t vi = threadIdx.x + (uint32_t)i * THREADS;
+            if (NVEC % THREADS != 0 && vi >= (uint32_t)NVEC) continue;
+            const uint32_t r = vi / LPR, fvec = vi % LPR;
             const uint32_t n = pos[r];
             uint4 v = *reinterpret_cast<const uint4 *>(&rows[r * S + 4 * fvec]);
             const uint32_t s0 = (4u * fvec - C::rot(r)) & (uint32_t)(S - 1);   // slot of the vector's first word
@@ -323,27 +417,16 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 #pragma unroll
         for (int i = 0; i < FI; ++i) store_rec(i);
     }
-    if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
+    if (threadIdx.x == 0) {
+        nrounds[blockIdx.x] = min(round, rounds_cap);
+        uint32_t abandoned = 0;
+        for (uint32_t i = 0; i < defer_n; ++i) abandoned += defer_t[i].count;
+        if (abandoned) atomicAdd(error + 1, abandoned);   // statistics only (KPAL_QUAD_VERBOSE)
+    }
     // what is still carried over: straight into the table
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) {
-        if (carry_item[c]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((carry_item[c] >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(carry_row[c], carry_item[c], i)], 1ULL);
-        }
-    }
-    // items placed after the last flush (carried items of an abandoned last tile) are still in the rows
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table);
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < (uint32_t)NB; r += THREADS) {
-        const uint32_t n = min(pos[r], (uint32_t)S);
-        for (uint32_t sl = 0; sl < n; ++sl) {
-            const uint32_t it = rows[r * S + ((sl + C::rot(r)) & (uint32_t)(S - 1))];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, i)], 1ULL);
-        }
-    }
     uint32_t pend_hot = 0;
     unsigned long long pend_cnt = 0;
     for (uint32_t i = 0; i < defer_n; ++i)

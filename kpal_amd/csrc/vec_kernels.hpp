@@ -466,6 +466,14 @@ __device__ __forceinline__ double div_counts(double num, double den)
 #endif
 }
 
+// 1 / d for d in [1, 2^32]: v_rcp_f64 and two Newton steps (within 1 ulp; no zero, infinite, NaN or denormal operand)
+__device__ __forceinline__ double rcp_counts(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
 // ---- distance matrix --------------------------------------------------------------------------
 // Lower triangle of P x P in TILE x TILE register tiles.  blockIdx.y = tile (ti >= tj),
 // blockIdx.x strides over bins.  Each thread streams one bin at a time for the TILE row
@@ -549,6 +557,43 @@ __device__ __forceinline__ void matrix_accumulate(const int64_t (&x)[TILE], cons
         }
 }
 
+// Multiset 'prod' terms with the reciprocals 1 / (x + 1) of the staged values precomputed ONCE per value by the
+// loader of matrix_super_kernel instead of one division per pair: |x - y| / ((x + 1)(y + 1)) = |x - y| * rx * ry --
+// a subtraction, a multiplication and a fused multiply-add per term (3 fp64 issue slots instead of ~12).  Each
+// factor is within 1 ulp, so a term is within ~2 ulp of the reference's quotient and the sum of the non-negative
+// terms within ~5e-16 relative -- the contract for fp64 results is 1e-9 (metrics.py:101-123).  Counts >= 2^31
+// anywhere in the wave's values take the int64 formulation (matrix_accumulate), like before.
+template <int TILE>
+__device__ __forceinline__ void matrix_accumulate_prod_rcp(const int64_t (&x)[TILE], const int64_t (&y)[TILE],
+                                                           const double (&rx)[TILE], const double (&ry)[TILE],
+                                                           double (&s)[TILE][TILE], unsigned long long (&m)[TILE][TILE],
+                                                           uint32_t (&mf)[TILE][TILE], TermBytes<TILE> &tb)
+{
+    uint64_t any = 0;
+#pragma unroll
+    for (int a = 0; a < TILE; ++a) any |= (uint64_t)x[a] | (uint64_t)y[a];
+    if (!__all((any >> 31) == 0)) {   // wave-uniform
+        matrix_accumulate<0, TILE>(x, y, s, m, mf, tb);
+        return;
+    }
+    double xd[TILE], yd[TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a) {
+        xd[a] = (double)(uint32_t)x[a];
+        yd[a] = (double)(uint32_t)y[a];
+    }
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) s[a][b] = __builtin_fma(fabs(xd[a] - yd[b]) * rx[a], ry[b], s[a][b]);
+    uint32_t ynz = 0u;   // byte b = 1 iff y[b] != 0
+#pragma unroll
+    for (int b = 0; b < TILE; ++b) ynz |= min((uint32_t)y[b], 1u) << (8 * b);
+#pragma unroll
+    for (int a = 0; a < TILE; ++a) tb.packed[a] += (uint32_t)x[a] != 0u ? 0x01010101u : ynz;
+    if (++tb.bins == 255u) term_bytes_flush(tb, mf);   // wave-uniform
+}
+
 template <int METRIC, int TILE>
 __global__ __launch_bounds__(256) void matrix_tile_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
                                                           const int2 *__restrict__ tiles,
@@ -610,7 +655,13 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
                                                            Partial *__restrict__ partials)
 {
     constexpr int TILE = 4;
+    constexpr bool RCP = METRIC == 0;              // 'prod': reciprocals 1 / (x + 1) staged next to the values
     __shared__ int64_t stage[2][32][kSuperRow];
+    __shared__ double rstage[RCP ? 2 : 1][RCP ? 32 : 1][RCP ? kSuperRow : 1];
+    auto put = [&](int buf, int row, int col, int64_t v) {
+        stage[buf][row][col] = v;
+        if constexpr (RCP) rstage[buf][row][col] = rcp_counts((double)(uint32_t)v + 1.0);   // (unused when v >= 2^31)
+    };
     const int si = supers[blockIdx.y].x, sj = supers[blockIdx.y].y;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int ti = si * 4 + (g >> 2), tj = sj * 4 + (g & 3);
@@ -642,7 +693,7 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
     uint64_t c = blockIdx.x;
     if (c < chunks) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) stage[0][4 * q + lrow][lcol] = src[q][c * kSuperBins];
+        for (int q = 0; q < 8; ++q) put(0, 4 * q + lrow, lcol, src[q][c * kSuperBins]);
     }
     __syncthreads();
     int cur = 0;
@@ -661,12 +712,22 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
                     x[a] = stage[cur][4 * (g >> 2) + a][16 * u + l];
                     y[a] = stage[cur][16 + 4 * (g & 3) + a][16 * u + l];
                 }
-                matrix_accumulate<METRIC, TILE>(x, y, s, m, mf, tb);
+                if constexpr (RCP) {
+                    double rx[TILE], ry[TILE];
+#pragma unroll
+                    for (int a = 0; a < TILE; ++a) {
+                        rx[a] = rstage[cur][4 * (g >> 2) + a][16 * u + l];
+                        ry[a] = rstage[cur][16 + 4 * (g & 3) + a][16 * u + l];
+                    }
+                    matrix_accumulate_prod_rcp<TILE>(x, y, rx, ry, s, m, mf, tb);
+                } else {
+                    matrix_accumulate<METRIC, TILE>(x, y, s, m, mf, tb);
+                }
             }
         }
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) stage[cur ^ 1][4 * q + lrow][lcol] = next[q];
+            for (int q = 0; q < 8; ++q) put(cur ^ 1, 4 * q + lrow, lcol, next[q]);
         }
         __syncthreads();
         cur ^= 1;

@@ -12,6 +12,10 @@ from conftest import dense
 
 pytestmark = pytest.mark.gpu
 
+# imported before any HIP work of this process: a late first import (inside a test, after tens of GB of device
+# traffic) once sat in torch's module loading until the per-test timeout
+torch = pytest.importorskip('torch')
+
 
 def sha(v):
     return hashlib.sha256(np.ascontiguousarray(v, dtype='<i8').tobytes()).hexdigest()
