@@ -674,11 +674,16 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
-        std::vector<double> per_step((size_t)buckets), mu((size_t)buckets);
+        // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
+        // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
+        std::vector<double> per_step((size_t)buckets);
         for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
+        std::sort(per_step.begin(), per_step.end());
+        per_step.resize((size_t)buckets - 32);
+        std::vector<double> mu(per_step.size());
         steps = candidates[sizeof(candidates) / sizeof(candidates[0]) - 1];
         for (int c : candidates) {
-            for (int b = 0; b < buckets; ++b) mu[b] = per_step[b] * 8 * c;
+            for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * 8 * c;
             if (quad_expected_overflow(mu, slots) <= 700.0) {                  // list: 2048 entries
                 steps = c;
                 break;
@@ -716,7 +721,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         uint32_t st[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(st, error, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[kpal quad] k=%d steps/wave/tile=%d tiles=%llu workgroups=%u abandoned tiles so far=%u\n", ctx->k, steps,
+        fprintf(stderr, "[kpal quad] k=%d steps/wave/tile=%d tiles=%llu workgroups=%u hot-table entries used so far=%u\n", ctx->k, steps,
                 (unsigned long long)tiles, G, st[1]);
     }
     return KPAL_OK;

@@ -18,9 +18,10 @@
 //     16-byte stores to its own aligned place  pool[bucket][workgroup][round]  -- no cursors, no chunk
 //     allocation, no tables: the histogram stage reads pool[bucket] as one stream.
 //   * A row that overflows (Poisson tail, ~1.5 % of the items) spills into a small LDS list whose
-//     entries are placed again at the start of the next round; a round that spills more than the list
-//     holds (homopolymers, satellite repeats) is abandoned and its k-mers are counted directly
-//     (ballot-aggregated global atomics), as in chunk_scatter.
+//     entries are placed again at the start of the next round.  Items that do not fit even then, or that
+//     the list cannot hold (a row that is over-full every round: homopolymers, satellite repeats), are
+//     counted on the spot: ballot-aggregated per wave into a 256-entry (row, item) hash table in LDS that is
+//     added to the count table once per workgroup.  No round is ever abandoned, no input is read twice.
 //   * HISTOGRAM: one workgroup per bucket, four forms (one per k-mer position) of 2^L bins in LDS
 //     (128 KiB at k = 11, 12); the bins of form i are table entries (hi << (B+s)) | (bucket << s) | lo
 //     with s = L-6+2i; merged with global atomics (forms of different buckets interleave in the table).
@@ -32,7 +33,6 @@
 namespace kpal {
 
 constexpr int kQuadSpillCap = 2048;           // spilled items a round may carry over (16 KiB of LDS)
-constexpr int kQuadDeferCap = 256;
 constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
 
 template <int K>
@@ -85,42 +85,88 @@ struct QuadSpill {
     uint32_t row, item;
 };
 
-// Items straight into the table (overflow of carried items, the carried items of an abandoned round, what is
-// still carried at the end).  Call wave-converged; `active` selects the lanes that hold an item.  Low-complexity
-// input makes these items identical across lanes: up to four rounds of "the first remaining lane's item, counted
-// with a ballot, one lane adds the count" before the rest adds individually.
+// Items that can neither stay in their row nor ride in the spill list (a row that is over-full round after
+// round: poly-A, satellite repeats, adapter / primer prefixes shared by many reads, a strongly skewed stretch) are
+// counted here.  Such items are mostly IDENTICAL across lanes and rounds, and a global atomic per item on one
+// table entry serialises chip-wide (measured: 10-40x slower on 2 % low-complexity reads or a shared 40-base
+// prefix).  So they are counted in LDS: a 256-entry hash table (row, item) -> count per workgroup that is added
+// to the table once, at the end of the kernel.
+//   * up to eight rounds of "the first remaining lane's item, its occurrences in the wave counted with a ballot":
+//     four lanes probe the item's four hash slots; a hit adds the count; a miss claims a free slot (64-bit
+//     compare-and-swap of the key) if the item occurred at least twice in the wave (singletons -- the partly
+//     masked items at the ends of a hot stretch -- would only fill the table), else takes global atomics;
+//   * lanes left after eight rounds probe for themselves.
+// Call wave-converged; `active` selects the lanes that hold an item.
+struct QuadHot {
+    unsigned long long key;   // row << 32 | item; 0 = free (an item always has mask bits set)
+    uint32_t count, pad;
+};
+constexpr int kQuadHotEntries = 256;
+
+__device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
+{
+    return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
+}
+
 template <int K>
-__device__ __forceinline__ void quad_items_direct(bool active, uint32_t row, uint32_t item, unsigned long long *__restrict__ table)
+__device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, unsigned long long *__restrict__ table,
+                                                            QuadHot *hot)   // (rare path, called from the unrolled placement
+                                                                            // loop: kept out of line)
 {
     const int lane = threadIdx.x & 63;
+    auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, i)], n);
+    };
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
-    for (int round = 0; round < 4 && todo; ++round) {   // wave-uniform
+    for (int round = 0; round < 8 && todo; ++round) {   // wave-uniform
         const int src = __ffsll((long long)todo) - 1;
         const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(row, src);
         const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(item, src);
         const unsigned long long same = __builtin_amdgcn_ballot_w64(active && row == hot_row && item == hot_item) & todo;
-        if (lane == src) {
-            const unsigned long long n = (unsigned long long)__popcll(same);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((hot_item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(hot_row, hot_item, i)], n);
+        const uint32_t n = (uint32_t)__popcll(same);
+        const unsigned long long key = ((unsigned long long)hot_row << 32) | hot_item;
+        const uint32_t slot = (quad_hot_hash(hot_row, hot_item) + (uint32_t)(lane & 3)) & (uint32_t)(kQuadHotEntries - 1);
+        const unsigned long long seen = lane < 4 ? hot[slot].key : ~0ull;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(seen == key);
+        if (hit) {
+            if (lane == __ffsll((long long)hit) - 1) atomicAdd(&hot[slot].count, n);
+        } else {
+            const unsigned long long free_slots = __builtin_amdgcn_ballot_w64(seen == 0ull);
+            bool placed = false;
+            if (n >= 2u && free_slots) {
+                const int who = __ffsll((long long)free_slots) - 1;
+                // (another wave may claim the slot first, or insert the same key elsewhere: both harmless)
+                const unsigned long long old = lane == who ? atomicCAS(&hot[slot].key, 0ull, key) : 1ull;
+                placed = __builtin_amdgcn_ballot_w64(lane == who && (old == 0ull || old == key)) != 0ull;
+                if (placed && lane == who) atomicAdd(&hot[slot].count, n);
+            }
+            if (!placed && lane == src) to_table(hot_row, hot_item, n);
         }
         todo &= ~same;
     }
-    if ((todo >> lane) & 1ull) {
+    if ((todo >> lane) & 1ull) {   // many different items in one wave: every lane for itself
+        const unsigned long long key = ((unsigned long long)row << 32) | item;
+        const uint32_t h = quad_hot_hash(row, item);
+        bool done = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if ((item >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(row, item, i)], 1ULL);
+        for (int pr = 0; pr < 4 && !done; ++pr) {
+            const uint32_t slot = (h + (uint32_t)pr) & (uint32_t)(kQuadHotEntries - 1);
+            if (hot[slot].key == key) {
+                atomicAdd(&hot[slot].count, 1u);
+                done = true;
+            }
+        }
+        if (!done) to_table(row, item, 1ULL);
     }
 }
 
-// One slot allocation + one LDS write per item; items whose row is full go to the spill list -- or, with
-// DIRECT (items that were carried over once already: their row is persistently over-full), straight into the
-// table, so that a hot row cannot pile up carried items round after round.
 // Returns the mask (bit q) of this lane's items that did not fit their row.
 template <int K, bool DIRECT = false>
 __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
-                                               const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *table = nullptr)
+                                               const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *table,
+                                               QuadHot *hot)
 {
     using C = QuadCfg<K>;
     uint32_t slot[4];
@@ -144,52 +190,19 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ov = (item[q] & 15u) && slot[q] >= (uint32_t)C::kSlots;
-            if constexpr (direct) {
-                quad_items_direct<K>(ov, row[q], item[q], table);
-            } else if (ov) {
-                const uint32_t at = atomicAdd(spill_n, 1u);
-                if (at < cap) spill[at] = QuadSpill{row[q], item[q]};
+            bool listed = false;
+            if constexpr (!direct) {
+                if (ov) {
+                    const uint32_t at = atomicAdd(spill_n, 1u);
+                    listed = at < cap;
+                    if (listed) spill[at] = QuadSpill{row[q], item[q]};
+                }
             }
+            // carried items that still do not fit, and whatever the list cannot hold: counted now
+            if (__any(ov && !listed)) quad_items_direct<K>(ov && !listed, row[q], item[q], table, hot);
         }
     }
     return over;
-}
-
-// Abandoned tile: its k-mers straight into the table (chunk_count_tile_direct with this tile shape).
-template <int K, int STEPS>
-__device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t first_step, unsigned long long *__restrict__ table,
-                                                       uint32_t &pend_hot, unsigned long long &pend_cnt)
-{
-    const int lane = threadIdx.x & 63;
-    Chunk carry = load_chunk(s, (int64_t)(first_step * 64) - 1);
-    for (int st = 0; st < STEPS; ++st) {
-        uint64_t window;
-        uint32_t mask;
-        part_step<K>(s, first_step + st, carry, window, mask);
-        const unsigned long long have = __builtin_amdgcn_ballot_w64(mask != 0);
-        if (!have) continue;   // wave-uniform
-        const int src = __ffsll((long long)have) - 1;
-        const uint32_t m0 = __builtin_amdgcn_readlane(mask, src);
-        const uint32_t w0_hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(window >> 32), src);
-        const uint32_t w0_lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)window, src);
-        const uint64_t w0 = ((uint64_t)w0_hi << 32) | w0_lo;
-        const uint32_t hot = kmer_at<K>(w0, 15 - (31 - __clz(m0)));
-        uint32_t same = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t v = kmer_at<K>(window, j);
-            const bool counted = (mask >> (15 - j)) & 1u;
-            const bool eq = counted && v == hot;
-            same += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
-            if (counted && !eq) atomicAdd(&table[v], 1ULL);
-        }
-        if (hot != pend_hot) {   // wave-uniform
-            if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
-            pend_hot = hot;
-            pend_cnt = 0;
-        }
-        pend_cnt += same;
-    }
 }
 
 // The items a thread carries from one round to the next (entries threadIdx.x + c * THREADS of the spill list).
@@ -197,16 +210,15 @@ __device__ __forceinline__ void quad_count_tile_direct(const Span &s, uint64_t f
 template <int K, int CARRY>
 __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                    const uint32_t (&carry_row)[CARRY], uint32_t (&carry_item)[CARRY],
-                                                   unsigned long long *table)
+                                                   unsigned long long *table, QuadHot *hot)
 {
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) {
         const uint32_t r4[4] = {carry_row[c], 0u, 0u, 0u};
         const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
         if (__any(carry_item[c] != 0u)) {
-            // an item that does not fit even now went straight into the table: it is no longer carried (an
-            // abandoned round adds what is still carried, and must not add it twice)
-            if (quad_place<K, true>(rows, pos, spill, spill_n, cap, r4, i4, table) & 1u) carry_item[c] = 0;
+            // an item that does not fit even now has been counted: it is no longer carried
+            if (quad_place<K, true>(rows, pos, spill, spill_n, cap, r4, i4, table, hot) & 1u) carry_item[c] = 0;
         }
     }
 }
@@ -290,14 +302,13 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     __shared__ uint32_t spill_cnt[2];           // appended-entries counter of even / odd tiles: the one of tile j is read by every
                                                 // thread after the placement barrier, so it may only be reset a barrier later --
                                                 // thread 0 resets the OTHER one (for tile j+1) during the flush of tile j
-    __shared__ uint32_t defer_n;
-    __shared__ DeferRun defer_t[kQuadDeferCap];
+    __shared__ QuadHot hot[kQuadHotEntries];    // items of persistently over-full rows, counted here instead of in the table
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
+    for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
     if (threadIdx.x == 0) {
         spill_cnt[0] = 0;
         spill_cnt[1] = 0;
-        defer_n = 0;
     }
     __syncthreads();
     const uint64_t total_steps = (s.nchunks + 63) / 64;
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const uint64_t fnext = tile_step(j + 1);
         uint32_t *spill_n = &spill_cnt[j & 1];
         // ---- place: carried items, then this tile's
-        quad_place_carried<K, CARRY>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table);
+        quad_place_carried<K, CARRY>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
         Chunk carry = encode16(rawh);
         range_fix(s, (int64_t)(first * 64) - 1, carry);
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
@@ -364,30 +375,12 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                 const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row[q], item[q]);
             }
-            quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table);
+            quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
         }
         have_rec = false;
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
-        const uint32_t spilled = *spill_n;       // reset only during the flush of the NEXT tile
+        const uint32_t spilled = min(*spill_n, CAP);         // (beyond CAP: counted directly by quad_place); reset only during the flush of the NEXT tile
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
-        if (__builtin_expect(spilled > CAP, 0)) {
-            // block-uniform, pathological input only: forget the round, count the tile directly after the loop.
-            // The items carried INTO this round (still in registers) go straight into the table: nothing stays
-            // parked in the rows, so any number of consecutive rounds may be abandoned.
-            __syncthreads();                     // every thread has read `spilled`
-            for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
-            if (threadIdx.x == 0) {
-                *spill_n = 0;
-                defer_tile(defer_t, defer_n, (uint32_t)j, error);
-            }
-#pragma unroll
-            for (int c = 0; c < CARRY; ++c) {
-                quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table);
-                carry_item[c] = 0;
-            }
-            __syncthreads();
-            continue;
-        }
         // ---- flush: every row becomes one record of S items (null padded), kept in registers
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
 #pragma unroll
@@ -417,22 +410,23 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 #pragma unroll
         for (int i = 0; i < FI; ++i) store_rec(i);
     }
-    if (threadIdx.x == 0) {
-        nrounds[blockIdx.x] = min(round, rounds_cap);
-        uint32_t abandoned = 0;
-        for (uint32_t i = 0; i < defer_n; ++i) abandoned += defer_t[i].count;
-        if (abandoned) atomicAdd(error + 1, abandoned);   // statistics only (KPAL_QUAD_VERBOSE)
-    }
-    // what is still carried over: straight into the table
+    if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
+    // what is still carried over, then the table of hot items: into the count table
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot);
     __syncthreads();
-    uint32_t pend_hot = 0;
-    unsigned long long pend_cnt = 0;
-    for (uint32_t i = 0; i < defer_n; ++i)
-        for (uint32_t q = 0; q < defer_t[i].count; ++q)
-            quad_count_tile_direct<K, STEPS>(s, tile_step((uint64_t)defer_t[i].first + q), table, pend_hot, pend_cnt);
-    if (pend_cnt && lane == 0) atomicAdd(&table[pend_hot], pend_cnt);
+    uint32_t used = 0;
+    for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
+        const QuadHot h = hot[i];
+        if (h.key && h.count) {
+            ++used;
+            const uint32_t r = (uint32_t)(h.key >> 32), it = (uint32_t)h.key;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((it >> (3 - q)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, q)], (unsigned long long)h.count);
+        }
+    }
+    if (used) atomicAdd(error + 1, used);   // statistics only (KPAL_QUAD_VERBOSE)
 }
 
 // Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
