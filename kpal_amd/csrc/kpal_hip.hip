@@ -618,6 +618,8 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
 
 // Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
 // one workgroup per bucket histograms.  pool[bucket][workgroup][round] holds one record per flush round.
+constexpr int kQuadsUseChunked = 2;   // launch_partition_quads (AUTO): the sample shows a feed for the chunked pipeline
+
 // Expected number of items per round that do not fit their row: sum over rows of E[max(X - slots, 0)], X ~ Poisson(mu).
 static double quad_expected_overflow(const std::vector<double> &mu, int slots)
 {
@@ -679,6 +681,18 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         std::vector<double> per_step((size_t)buckets);
         for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
         std::sort(per_step.begin(), per_step.end());
+        // When those hot rows hold more than 1.5 % of all items (reads that share an adapter / primer prefix, several
+        // per cent of low-complexity reads) the slow path of the scatter would run in nearly every placement step --
+        // measured 20-50x slower on a 20..40-base prefix shared by all reads.  The chunked pipeline takes such a feed
+        // in its stride (its buckets simply own more chunks), so AUTO hands the feed over; an explicitly chosen quad
+        // strategy stays (tests, A/B).
+        {
+            double all = 0.0, hot = 0.0;
+            const double median = per_step[(size_t)buckets / 2];
+            for (int b = 0; b < buckets; ++b) all += per_step[b];
+            for (int b = buckets - 32; b < buckets; ++b) hot += std::max(0.0, per_step[b] - median);
+            if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all) return kQuadsUseChunked;
+        }
         per_step.resize((size_t)buckets - 32);
         std::vector<double> mu(per_step.size());
         steps = candidates[sizeof(candidates) / sizeof(candidates[0]) - 1];
@@ -888,7 +902,17 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
-        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) CHK(launch_partition_quads(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+            const int rc = launch_partition_quads(ctx, s);
+            if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size
+                ctx->strategy = KPAL_STRATEGY_PARTITION_CHUNKED;
+                const int r2 = count_device_range(ctx, addr + off, len, halo + off);
+                ctx->strategy = KPAL_STRATEGY_AUTO;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
         else {
             const int rc = launch_partition2(ctx, s);
             if (rc == kSplitBatch) {   // rare: process this piece as two halves

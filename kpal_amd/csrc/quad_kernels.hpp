@@ -342,7 +342,14 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         if (NVEC % THREADS != 0 && v >= (uint32_t)NVEC) return;
         const uint32_t r = v / LPR, fvec = v % LPR;
         const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + (round - 1u)) * S;
+#if defined(KPAL_QUAD_NT)   // A/B builds: non-temporal record stores
+        __builtin_nontemporal_store(rec[i].x, pool + at + 4 * fvec);
+        __builtin_nontemporal_store(rec[i].y, pool + at + 4 * fvec + 1);
+        __builtin_nontemporal_store(rec[i].z, pool + at + 4 * fvec + 2);
+        __builtin_nontemporal_store(rec[i].w, pool + at + 4 * fvec + 3);
+#else
         *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
+#endif
     };
     for (uint64_t j = 0; tile_exists(j); ++j) {   // block-uniform
         const uint64_t first = tile_step(j);

@@ -25,10 +25,10 @@ for plen in (0, 20, 40):
     b = base.copy()
     if plen:
         b[:, :plen] = b[0, :plen]
-    for strat in ('partition_quads', 'partition_chunked'):
+    for strat in ('auto', 'partition_quads', 'partition_chunked'):
         run('all reads share a %d-base prefix' % plen, b, strat)
 b = base.copy()
 hit = rs.rand(reads) < 0.3
 b[hit, :40] = b[0, :40]
-for strat in ('partition_quads', 'partition_chunked'):
+for strat in ('auto', 'partition_quads', 'partition_chunked'):
     run('30 %% of the reads share a 40-base prefix', b, strat)
