@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('KPAL_HIP_LIBRARY', os.path.join(_HERE, 'libkpal_hip.s
 KPAL_MAX_K = 16
 PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN, COSINE = 0, 1, 2, 3
 SUMMARY_MIN, SUMMARY_AVERAGE, SUMMARY_MEDIAN = 0, 1, 2
-STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6}
+STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7}
 
 _E_INVALID, _E_NOMEM, _E_HIP, _E_STATE = -1, -2, -3, -4
 

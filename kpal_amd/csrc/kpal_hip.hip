@@ -90,7 +90,7 @@ struct kpal_ctx {
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
-    DevBuf quad_meta;                        // quad path: rounds per workgroup, error word
+    DevBuf quad_meta, quad_meta2;            // quad path: rounds per workgroup, error word; level-2 rounds (k >= 13)
     uint32_t *quad_error_word = nullptr;
     bool chunk_error_armed = false;
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
@@ -324,7 +324,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
@@ -413,7 +413,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_QUADS)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2_QUADS)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -424,11 +424,11 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     int s = ctx->strategy;
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
-        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2);
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2_QUADS);
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
     if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED || s == KPAL_STRATEGY_PARTITION_QUADS) && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
-    if (s == KPAL_STRATEGY_PARTITION2 && (k < 13 || k > 16))
+    if ((s == KPAL_STRATEGY_PARTITION2 || s == KPAL_STRATEGY_PARTITION2_QUADS) && (k < 13 || k > 16))
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
     *out = s;
     return KPAL_OK;
@@ -727,7 +727,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         default: KPAL_QUAD_LAUNCH(12); break;
         }
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
-               (const uint32_t *)nrounds, G, (uint32_t)tpb, table);
+               (const uint32_t *)nrounds, G, (uint32_t)tpb, table, (uint32_t *)nullptr);
     });
 #undef KPAL_QUAD_LAUNCH
     static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
@@ -738,6 +738,68 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         fprintf(stderr, "[kpal quad] k=%d steps/wave/tile=%d tiles=%llu workgroups=%u hot-table entries used so far=%u\n", ctx->k, steps,
                 (unsigned long long)tiles, G, st[1]);
     }
+    return KPAL_OK;
+}
+
+// Two-level partition of quads, k = 13..16 (quad_kernels.hpp, end): level-1 records by coarse bucket, level-2 records
+// by (coarse, fine) bucket, histogram per (coarse, fine) bucket.
+static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    const int K = ctx->k;
+    const uint32_t NB1 = 1u << (2 * K - 22);
+    const uint32_t REP = NB1 >= 256 ? 1u : 256u / NB1;
+    const uint32_t S1 = (uint32_t)kQuadRowWords / (NB1 * REP);
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048) * sizeof(uint32_t)));
+    uint32_t *nrounds1 = (uint32_t *)ctx->quad_meta.p;
+    uint32_t *error = nrounds1 + ctx->num_cu;
+    if (!ctx->quad_error_word) {
+        HIPCHK(hipMemsetAsync(error, 0, 4 * sizeof(uint32_t), ctx->stream));
+        ctx->quad_error_word = error;
+    }
+    // level 1: 12 wave-steps per wave per tile bring 91 items per 128-slot row (22.8 per 32 at k = 16) for uniform
+    // k-mers; KPAL_QUAD_STEPS = 6 halves the tile (skewed composition; no sampling on this path yet)
+    static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
+    const int steps1 = steps_env == 6 ? 6 : 12;
+    const uint64_t tile_steps = 8ull * steps1;
+    const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
+    const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
+    const uint64_t tpb1 = (tiles1 + G1 - 1) / G1;
+    if (tpb1 > 0xFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
+    CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * tpb1));
+    uint32_t *pool1 = (uint32_t *)ctx->residuals.p;
+    // level 2: ~4 workgroups per CU in total; workgroup (g2, c) takes `upw` of the REP x G1 units of coarse bucket c
+    const uint32_t units = REP * G1;
+    uint32_t G2 = std::max<uint32_t>(1, std::min<uint32_t>(units, (uint32_t)ctx->num_cu * 4 / NB1));
+    const uint32_t upw = (units + G2 - 1) / G2;
+    G2 = (units + upw - 1) / upw;
+    const uint64_t unit_cap = tpb1 * S1 * 4;                                   // bytes
+    if ((uint64_t)upw * unit_cap >= (1ull << 32)) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
+    constexpr int kSteps2 = 16;
+    const uint64_t tile2_bytes = 8ull * kSteps2 * 1024;
+    const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
+    CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));
+    CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
+    // the staged forms of the histogram stage (16 bytes per table entry: 17 GB at k = 15) reuse the level-1 pool's buffer:
+    // level 2 has read it completely before the histogram kernel starts (same stream)
+    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * tpb1, (size_t)ctx->bins * 16)));
+    pool1 = (uint32_t *)ctx->residuals.p;
+    uint32_t *stage = pool1;
+    uint32_t *pool2 = (uint32_t *)ctx->keys.p;
+    uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_13_16(ctx->k, {
+        if (steps1 == 6)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 6, 6>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)tpb1, nrounds1, error, table);
+        else
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 12, 12>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)tpb1, nrounds1, error, table);
+        LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kSteps2>), dim3(G2, NB1), dim3(512), (const uint32_t *)pool1,
+               (const uint32_t *)nrounds1, G1, (uint32_t)tpb1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
+        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
+               G2, (uint32_t)tiles2, table, stage);
+        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 1024)), dim3(256), (const uint32_t *)stage, table);
+    });
     return KPAL_OK;
 }
 
@@ -863,6 +925,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
     else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS && n < ((size_t)64 << 20)) strat = KPAL_STRATEGY_PARTITION2;
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
@@ -884,6 +947,10 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         // smaller): pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
     }
+    else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
+        // two record pools of ~4/3 of the input bytes each: pieces of up to 16 GiB
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes * 16, (size_t)16 << 30) : (size_t)16 << 30;
+    }
     else if (strat == KPAL_STRATEGY_PARTITION2) {
         // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
         // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
@@ -902,6 +969,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) CHK(launch_partition2_quads(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
             const int rc = launch_partition_quads(ctx, s);
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size

@@ -28,6 +28,8 @@
 //
 // Integer adds commute, every k-mer is in exactly one item with its mask bit set: bit-exact.
 #pragma once
+#include <type_traits>
+
 #include "chunk_kernels.hpp"
 
 namespace kpal {
@@ -37,15 +39,22 @@ constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
 
 template <int K>
 struct QuadCfg {
-    static_assert(K >= 8 && K <= 12, "quads: k = 8..12");
-    static constexpr int kBucketBits = K == 12 ? 11 : 9;
-    static constexpr int kBuckets = 1 << kBucketBits;
-    static constexpr int kLowBits = 2 * K - kBucketBits;            // L: 13, 13, 11, 9, 7
+    static_assert(K >= 8 && K <= 16, "quads: k = 8..16");
+    // k = 13..16 (two levels, see the end of this file): these are the rows of LEVEL 1 -- the coarse bucket (the top
+    // 2K-22 shared bits, scrambled) x a replica, 256 rows of 128 slots (1024 of 32 at k = 16); the 4-byte item keeps
+    // the 9-bit fine bucket of level 2 as well:  hi6 << 26 | fine9 << 17 | low13 << 4 | mask4.
+    static constexpr bool kTwoLevel = K >= 13;
+    static constexpr int kCoarseBits = kTwoLevel ? 2 * K - 22 : 0;           // 4, 6, 8, 10
+    static constexpr int kCoarse = 1 << kCoarseBits;
+    static constexpr int kRep = kTwoLevel ? (kCoarse >= 256 ? 1 : 256 / kCoarse) : 1;   // 16, 4, 1, 1
+    static constexpr int kBucketBits = kTwoLevel ? 9 : (K == 12 ? 11 : 9);  // (fine) bucket bits of the histogram stage
+    static constexpr int kBuckets = kTwoLevel ? kCoarse * kRep : (1 << kBucketBits);   // ROWS of the scatter
+    static constexpr int kLowBits = kTwoLevel ? 13 : 2 * K - kBucketBits;   // L: 13, 13, 11, 9, 7 (k = 12 .. 8); 13
     static constexpr int kFormBins = 1 << kLowBits;
-    static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16 or 64
+    static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16, 64; 128, 32
     static constexpr int kRecordBytes = kSlots * 4;
     static constexpr int kScrBits = (kLowBits - 6) < 4 ? (kLowBits - 6) : 4;   // bits of the low field that scramble the bucket
-    static constexpr uint32_t kXMask = (1u << (2 * K + 6)) - 1u;                       // the (K+3)-mer: at most 30 bits
+    static constexpr uint64_t kXMask = (1ull << (2 * K + 6)) - 1ull;            // the (K+3)-mer: at most 38 bits
     static constexpr uint32_t kLowMask = (1u << kLowBits) - 1u;
     // rows are rotated by a multiple of four words so that rows filling in lock-step hit different banks
     // while the flush still reads whole 16-byte vectors
@@ -53,31 +62,50 @@ struct QuadCfg {
     // bucket scrambling (see chunk_scramble): the top kScrBits of the low field pick one of 2^kScrBits masks
     __host__ __device__ static constexpr uint32_t smask(uint32_t t)
     {
-        return kScrBits > 0 ? (((t << (kBucketBits - kScrBits)) | t) & (uint32_t)(kBuckets - 1)) : 0u;
+        return kScrBits > 0 ? (((t << (kBucketBits - kScrBits)) | t) & (uint32_t)((1 << kBucketBits) - 1)) : 0u;
     }
+    // the same for the coarse bucket of the two-level path
+    __host__ __device__ static constexpr uint32_t smask1(uint32_t t) { return ((t << (kCoarseBits - 4)) | t) & (uint32_t)(kCoarse - 1); }
 };
 
 // item = hi6 << (L+4) | low << 4 | mask4 (mask bit 3 = oldest k-mer).  0 = null item.
 template <int K>
-__device__ __forceinline__ void quad_split(uint32_t x, uint32_t m4, uint32_t &row, uint32_t &item)
+__device__ __forceinline__ void quad_split(uint64_t x, uint32_t m4, uint32_t lane, uint32_t &row, uint32_t &item)
 {
     using C = QuadCfg<K>;
-    const uint32_t low = x & C::kLowMask;
-    const uint32_t b = (x >> C::kLowBits) & (uint32_t)(C::kBuckets - 1);
-    const uint32_t hi6 = x >> (2 * K);
-    row = b ^ C::smask(low >> (C::kLowBits - C::kScrBits));
-    item = (hi6 << (C::kLowBits + 4)) | (low << 4) | m4;
+    const uint32_t low = (uint32_t)x & C::kLowMask;
+    const uint32_t hi6 = (uint32_t)(x >> (2 * K));
+    if constexpr (C::kTwoLevel) {
+        const uint32_t fine = ((uint32_t)x >> 13) & 511u;
+        const uint32_t coarse = (uint32_t)(x >> 22) & (uint32_t)(C::kCoarse - 1);
+        row = (coarse ^ C::smask1(low >> 9)) * C::kRep + (lane & (uint32_t)(C::kRep - 1));
+        item = (hi6 << 26) | (fine << 17) | (low << 4) | m4;
+    } else {
+        const uint32_t b = ((uint32_t)x >> C::kLowBits) & (uint32_t)(C::kBuckets - 1);
+        row = b ^ C::smask(low >> (C::kLowBits - C::kScrBits));
+        item = (hi6 << (C::kLowBits + 4)) | (low << 4) | m4;
+    }
 }
 
-// the k-mer at position i (0 = oldest) of an item of (scrambled) row `row`
-template <int K>
-__device__ __forceinline__ uint32_t quad_kmer(uint32_t row, uint32_t item, int i)
+// the k-mer at position i (0 = oldest) of an item of (scrambled) row `row`.  LEVEL 2: an item of the second
+// level of the two-level path (hi6 << 17 | low13 << 4 | mask4 in fine row `row` of scrambled coarse bucket `coarse`).
+template <int K, int LEVEL = 1>
+__device__ __forceinline__ uint32_t quad_kmer(uint32_t row, uint32_t item, int i, uint32_t coarse = 0)
 {
     using C = QuadCfg<K>;
-    const uint32_t low = (item >> 4) & C::kLowMask;
-    const uint32_t hi6 = item >> (C::kLowBits + 4);
-    const uint32_t b = row ^ C::smask(low >> (C::kLowBits - C::kScrBits));
-    const uint64_t x = ((uint64_t)hi6 << (2 * K)) | ((uint64_t)b << C::kLowBits) | low;
+    uint64_t x;
+    if constexpr (LEVEL == 2) {
+        const uint32_t low = (item >> 4) & 8191u, hi6 = item >> 17, t = low >> 9;
+        x = ((uint64_t)hi6 << (2 * K)) | ((uint64_t)(coarse ^ C::smask1(t)) << 22) | ((uint64_t)(row ^ C::smask(t)) << 13) | low;
+    } else if constexpr (C::kTwoLevel) {
+        const uint32_t low = (item >> 4) & 8191u, fine = (item >> 17) & 511u, hi6 = item >> 26, t = low >> 9;
+        x = ((uint64_t)hi6 << (2 * K)) | ((uint64_t)((row / C::kRep) ^ C::smask1(t)) << 22) | ((uint64_t)fine << 13) | low;
+    } else {
+        const uint32_t low = (item >> 4) & C::kLowMask;
+        const uint32_t hi6 = item >> (C::kLowBits + 4);
+        const uint32_t b = row ^ C::smask(low >> (C::kLowBits - C::kScrBits));
+        x = ((uint64_t)hi6 << (2 * K)) | ((uint64_t)b << C::kLowBits) | low;
+    }
     return (uint32_t)((x >> (6 - 2 * i)) & ((1ull << (2 * K)) - 1ull));
 }
 
@@ -108,16 +136,16 @@ __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
 }
 
-template <int K>
+template <int K, int LEVEL = 1>
 __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, unsigned long long *__restrict__ table,
-                                                            QuadHot *hot)   // (rare path, called from the unrolled placement
-                                                                            // loop: kept out of line)
+                                                            QuadHot *hot, uint32_t coarse = 0)   // (rare path, called from the
+                                                                            // unrolled placement loop: kept out of line)
 {
     const int lane = threadIdx.x & 63;
     auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, i)], n);
+            if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K, LEVEL>(r, it, i, coarse)], n);
     };
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
     for (int round = 0; round < 8 && todo; ++round) {   // wave-uniform
@@ -163,12 +191,12 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
 }
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.
-template <int K, bool DIRECT = false>
+template <int K, bool DIRECT = false, int LEVEL = 1>
 __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *table,
-                                               QuadHot *hot)
+                                               QuadHot *hot, uint32_t coarse = 0)
 {
-    using C = QuadCfg<K>;
+    using C = typename std::conditional<LEVEL == 2, QuadCfg<11>, QuadCfg<K>>::type;   // level 2: 512 rows x 64 slots
     uint32_t slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) slot[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 1u : 0u);
@@ -199,7 +227,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
                 }
             }
             // carried items that still do not fit, and whatever the list cannot hold: counted now
-            if (__any(ov && !listed)) quad_items_direct<K>(ov && !listed, row[q], item[q], table, hot);
+            if (__any(ov && !listed)) quad_items_direct<K, LEVEL>(ov && !listed, row[q], item[q], table, hot, coarse);
         }
     }
     return over;
@@ -207,10 +235,10 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 
 // The items a thread carries from one round to the next (entries threadIdx.x + c * THREADS of the spill list).
 // Plain functions on array references: as [&] lambdas the arrays were kept in scratch memory.
-template <int K, int CARRY>
+template <int K, int CARRY, int LEVEL = 1>
 __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                    const uint32_t (&carry_row)[CARRY], uint32_t (&carry_item)[CARRY],
-                                                   unsigned long long *table, QuadHot *hot)
+                                                   unsigned long long *table, QuadHot *hot, uint32_t coarse = 0)
 {
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) {
@@ -218,7 +246,7 @@ __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos
         const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
         if (__any(carry_item[c] != 0u)) {
             // an item that does not fit even now has been counted: it is no longer carried
-            if (quad_place<K, true>(rows, pos, spill, spill_n, cap, r4, i4, table, hot) & 1u) carry_item[c] = 0;
+            if (quad_place<K, true, LEVEL>(rows, pos, spill, spill_n, cap, r4, i4, table, hot, coarse) & 1u) carry_item[c] = 0;
         }
     }
 }
@@ -260,9 +288,9 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
             part_step<K>(s, first + st, carry, window, mask);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
+                const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
                 uint32_t row, item;
-                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row, item);
+                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, threadIdx.x & 63u, row, item);
                 atomicAdd(&cnt[row], (item & 15u) ? 1u : 0u);
             }
         }
@@ -379,8 +407,8 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             uint32_t row[4], item[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t x = (uint32_t)(window >> (24 - 8 * q)) & C::kXMask;
-                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, row[q], item[q]);
+                const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
+                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, (uint32_t)lane, row[q], item[q]);
             }
             quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
         }
@@ -436,17 +464,176 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     if (used) atomicAdd(error + 1, used);   // statistics only (KPAL_QUAD_VERBOSE)
 }
 
+// ==========================================================================================
+// Two-level path, k = 13..16.  The (K+3)-mer of an item has up to 38 bits; its shared field x[2K-1:6] is cut into
+//   coarse (2K-22 bits: 16 / 64 / 256 / 1024 buckets) | fine (9 bits) | the upper 7 bits of low13,
+// so that after the coarse bucket is fixed an item is again  hi6 | fine9 | low13 | mask4 = 32 bits, and after the
+// fine bucket is fixed it is the 23-bit item of the one-level path with L = 13: level 2 and the histogram are the
+// k = 11 machinery (512 rows of 64 slots, four forms of 8192 bins), the count table index only gains the coarse
+// field:  hi << (B1+9+s) | coarse << (9+s) | fine << s | lo.
+//   Q1  quad_scatter_kernel<K>   ASCII -> level-1 records pool1[coarse row][workgroup][round]  (the kernel above)
+//   Q3  quad2_scatter_kernel<K>  level-1 records of one coarse bucket -> pool2[coarse][fine row][workgroup][round]
+//   Q2  quad_hist_kernel<K>      grid (512, coarse)
+// 1 B/base read, then 4 x ~1.4 B per k-mer (two record pools written and read once each) instead of the 4-byte
+// residuals + 2-byte keys + two counting passes of the round-1 two-level pipeline.
+// ==========================================================================================
+// Q3.  Workgroup (g2, c) takes the units [g2 * upw, (g2+1) * upw) of coarse bucket c; unit u = (replica u / G1,
+// level-1 workgroup u % G1) is the run of nrounds1[u % G1] records that workgroup wrote for that row.  The units
+// are addressed as one stream of `unit_cap` bytes each (records never written read as null items): a wave-step is
+// 1 KiB of it, four items per lane -- the shape of the ASCII path, so the tile loop is the same.
+template <int K, int STEPS>
+__global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__restrict__ pool1, const uint32_t *__restrict__ nrounds1,
+                                                            uint32_t G1, uint32_t rounds_cap1, uint32_t upw, uint32_t tiles_per_block,
+                                                            uint32_t *__restrict__ pool2, uint32_t rounds_cap2,
+                                                            uint32_t *__restrict__ nrounds2, uint32_t *__restrict__ error,
+                                                            unsigned long long *__restrict__ table)
+{
+    using C1 = QuadCfg<K>;
+    using C = QuadCfg<11>;                      // rows of level 2: 512 x 64 slots, items of 23 bits
+    constexpr int S = C::kSlots, NB = C::kBuckets, S1 = C1::kSlots;
+    constexpr int WAVES = 8, THREADS = 512;
+    constexpr int CARRY = kQuadSpillCap / THREADS;
+    constexpr uint32_t CAP = CARRY * THREADS;
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
+    __shared__ uint32_t pos[NB];
+    __shared__ QuadSpill spill[kQuadSpillCap];
+    __shared__ uint32_t spill_cnt[2];
+    __shared__ QuadHot hot[kQuadHotEntries];
+    __shared__ uint32_t nr1[256];               // rounds written by every level-1 workgroup
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t coarse = blockIdx.y;
+    for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
+    for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
+    for (uint32_t i = threadIdx.x; i < 256u; i += THREADS) nr1[i] = i < G1 ? nrounds1[i] : 0u;
+    if (threadIdx.x == 0) {
+        spill_cnt[0] = 0;
+        spill_cnt[1] = 0;
+    }
+    __syncthreads();
+    const uint32_t units = (uint32_t)C1::kRep * G1;                      // units of this coarse bucket
+    const uint32_t u0 = blockIdx.x * upw, u1 = min(u0 + upw, units);
+    const uint32_t unit_cap = rounds_cap1 * (uint32_t)(S1 * 4);          // bytes
+    const uint32_t stream = (u1 > u0 ? u1 - u0 : 0u) * unit_cap;        // < 2^32: the host sizes the units so
+    // 16 bytes of the stream at byte position p (a multiple of 16), zeros where nothing was written
+    auto fetch = [&](uint64_t p64) -> uint4 {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (p64 < (uint64_t)stream) {
+            const uint32_t p = (uint32_t)p64;
+            const uint32_t ul = p / unit_cap;
+            const uint32_t off = p - ul * unit_cap;
+            const uint32_t u = u0 + ul, g1 = u % G1, rl = u / G1;
+            if (off / (uint32_t)(S1 * 4) < nr1[g1]) {
+                const uint64_t base = ((uint64_t)((coarse * C1::kRep + rl) * G1 + g1) * rounds_cap1) * S1;   // words
+                v = *reinterpret_cast<const uint4 *>(pool1 + base + off / 4);
+            }
+        }
+        return v;
+    };
+    auto step_pos = [&](uint64_t j, int st) -> uint64_t { return (((j * WAVES + (uint64_t)wave) * STEPS + (uint64_t)st) * 64 + (uint64_t)lane) * 16; };
+    uint4 raw[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) raw[st] = fetch(step_pos(0, st));
+    uint32_t round = 0;
+    uint32_t carry_row[CARRY], carry_item[CARRY];
+#pragma unroll
+    for (int c = 0; c < CARRY; ++c) carry_row[c] = carry_item[c] = 0;
+    constexpr int LPR = S / 4;
+    constexpr int NVEC = NB * LPR;
+    constexpr int FI = NVEC / THREADS;          // 16
+    uint4 rec[FI];
+    bool have_rec = false;
+    const uint32_t wg = coarse * gridDim.x + blockIdx.x;
+    auto store_rec = [&](int i) {
+        uint32_t v = threadIdx.x + (uint32_t)i * THREADS;
+        asm volatile("" : "+v"(v));
+        const uint32_t r = v / LPR, fvec = v % LPR;
+        const uint64_t at = ((uint64_t)((coarse * NB + r) * gridDim.x + blockIdx.x) * rounds_cap2 + (round - 1u)) * S;
+        *reinterpret_cast<uint4 *>(pool2 + at + 4 * fvec) = rec[i];
+    };
+    const uint64_t tile_bytes = (uint64_t)WAVES * STEPS * 1024;
+    for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
+        const bool more = j + 1 < tiles_per_block && (j + 1) * tile_bytes < (uint64_t)stream;
+        uint32_t *spill_n = &spill_cnt[j & 1];
+        quad_place_carried<K, CARRY, 2>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            if (have_rec) {
+#pragma unroll
+                for (int i = st; i < FI; i += STEPS) store_rec(i);
+            }
+            const uint4 v = raw[st];
+            if (more) raw[st] = fetch(step_pos(j + 1, st));
+            const uint32_t it[4] = {v.x, v.y, v.z, v.w};
+            uint32_t row[4], item[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t t = ((it[q] >> 4) & 8191u) >> 9;
+                row[q] = ((it[q] >> 17) & 511u) ^ C::smask(t);
+                item[q] = ((it[q] >> 26) << 17) | (it[q] & 0x1FFFFu);   // the fine bucket leaves the item
+            }
+            quad_place<K, false, 2>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
+        }
+        have_rec = false;
+        lds_barrier();
+        const uint32_t spilled = min(*spill_n, CAP);
+        if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;
+        quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t vi = threadIdx.x + (uint32_t)i * THREADS;
+            const uint32_t r = vi / LPR, fvec = vi % LPR;
+            const uint32_t n = pos[r];
+            uint4 v = *reinterpret_cast<const uint4 *>(&rows[r * S + 4 * fvec]);
+            const uint32_t s0 = (4u * fvec - C::rot(r)) & (uint32_t)(S - 1);
+            v.x = s0 + 0 < n ? v.x : 0u;
+            v.y = s0 + 1 < n ? v.y : 0u;
+            v.z = s0 + 2 < n ? v.z : 0u;
+            v.w = s0 + 3 < n ? v.w : 0u;
+            rec[i] = v;
+            if (fvec == 0) pos[r] = 0;
+        }
+        if (round >= rounds_cap2) {
+            if (threadIdx.x == 0) *error = 3u;
+        } else {
+            have_rec = true;
+            ++round;
+        }
+        lds_barrier();
+    }
+    if (have_rec) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) store_rec(i);
+    }
+    if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
+#pragma unroll
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
+        const QuadHot h = hot[i];
+        if (h.key && h.count) {
+            const uint32_t r = (uint32_t)(h.key >> 32), itm = (uint32_t)h.key;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((itm >> (3 - q)) & 1u) atomicAdd(&table[quad_kmer<K, 2>(r, itm, q, coarse)], (unsigned long long)h.count);
+        }
+    }
+}
+
 // Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
 // Same hot-key guard as part_hist_kernel: per form the wave counts the occurrences of its first lane's bin
 // with a ballot, those lanes add to private dummy words instead (64 adds to one LDS address serialise).
 template <int K>
 __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ nrounds,
-                                                         uint32_t G, uint32_t rounds_cap, unsigned long long *__restrict__ table)
+                                                         uint32_t G, uint32_t rounds_cap, unsigned long long *__restrict__ table,
+                                                         uint32_t *__restrict__ stage)
 {
     using C = QuadCfg<K>;
-    constexpr int L = C::kLowBits, BINS = C::kFormBins, S = C::kSlots;
+    // k = 13..16: blockIdx.y is the (scrambled) coarse bucket, blockIdx.x the fine row of level 2 (512 rows of 64 slots)
+    constexpr int L = C::kLowBits, BINS = C::kFormBins, S = C::kTwoLevel ? 64 : C::kSlots;
     __shared__ __attribute__((aligned(16))) uint32_t hist[4 * BINS + 64];
-    const uint32_t row = blockIdx.x;
+    const uint32_t row = blockIdx.x, coarse = blockIdx.y;
+    const uint32_t row_linear = coarse * (C::kTwoLevel ? 512u : 0u) + row;
+    nrounds += (size_t)coarse * G;
     for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -489,7 +676,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         }
     };
     for (uint32_t g = wave; g < G; g += 16) {   // wave-uniform
-        const uint4 *src = reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row * G + g) * rounds_cap) * S);
+        const uint4 *src = reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
         // four 16-byte loads per lane in flight; the next four are requested before these are counted
         auto fetch = [&](uint32_t at) -> uint4 {   // (a select between src[at] and a zero constant becomes a flat load of a selected address)
@@ -513,6 +700,15 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         }
     }
     __syncthreads();
+    if (stage) {
+        // two-level path: every table entry would receive four atomic adds (one per form, from four different
+        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are stored as they are instead -- one coalesced
+        // 128 KiB write per workgroup -- and quad2_combine_kernel gathers the four of every entry.
+        uint4 *dst = reinterpret_cast<uint4 *>(stage + (size_t)row_linear * (4 * BINS));
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(hist);
+        for (int i = threadIdx.x; i < BINS; i += blockDim.x) dst[i] = src4[i];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int sh = L - 6 + 2 * i;
@@ -521,10 +717,41 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             if (!c) continue;
             const uint32_t lopart = (uint32_t)local & ((1u << sh) - 1u);
             const uint32_t hipart = (uint32_t)local >> sh;
-            const uint32_t b = row ^ C::smask(C::kScrBits > 0 ? (lopart >> (sh - C::kScrBits)) : 0u);
-            const uint64_t idx = ((uint64_t)hipart << (C::kBucketBits + sh)) | ((uint64_t)b << sh) | lopart;
+            const uint32_t t = C::kScrBits > 0 ? (lopart >> (sh - C::kScrBits)) : 0u;
+            const uint32_t b = row ^ C::smask(t);
+            uint64_t idx;
+            if constexpr (C::kTwoLevel)
+                idx = ((uint64_t)hipart << (C::kCoarseBits + 9 + sh)) | ((uint64_t)(coarse ^ C::smask1(t)) << (9 + sh)) | ((uint64_t)b << sh) | lopart;
+            else
+                idx = ((uint64_t)hipart << (C::kBucketBits + sh)) | ((uint64_t)b << sh) | lopart;
             atomicAdd(&table[idx], (unsigned long long)c);
         }
+    }
+}
+
+// Q4 (k = 13..16): table[idx] += the four staged form counts of entry idx.  Form i of entry idx lives in the staged
+// histogram of (scrambled) bucket (coarse ^ smask1(t), fine ^ smask(t)) at local = hi << s | lo, s = 7 + 2i, where
+// lo = idx's low s bits, t = lo's top four bits, fine / coarse / hi the fields above.  Exclusive per entry: plain adds.
+template <int K>
+__global__ __launch_bounds__(256) void quad2_combine_kernel(const uint32_t *__restrict__ stage, unsigned long long *__restrict__ table)
+{
+    using C = QuadCfg<K>;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // four runs of 256 entries per workgroup (4^16 entries: the grid stays below 2^32 threads)
+        const uint64_t idx = ((uint64_t)blockIdx.x * 4 + e) * 256 + threadIdx.x;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sh = 7 + 2 * i;
+            const uint32_t lopart = (uint32_t)idx & ((1u << sh) - 1u);
+            const uint32_t fine = (uint32_t)(idx >> sh) & 511u;
+            const uint32_t coarse = (uint32_t)(idx >> (sh + 9)) & (uint32_t)(C::kCoarse - 1);
+            const uint32_t hipart = (uint32_t)(idx >> (sh + 9 + C::kCoarseBits));
+            const uint32_t t = lopart >> (sh - 4);
+            const uint32_t row_linear = (coarse ^ C::smask1(t)) * 512u + (fine ^ C::smask(t));
+            sum += stage[((size_t)row_linear * 4 + i) * 8192 + ((hipart << sh) | lopart)];
+        }
+        if (sum) table[idx] += (unsigned long long)sum;
     }
 }
 

@@ -31,6 +31,7 @@ def strategies(k):
         s.append('partition_quads')
     if 13 <= k <= 16:
         s.append('partition2')
+        s.append('partition2_quads')
     return s
 
 
