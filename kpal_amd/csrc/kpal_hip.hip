@@ -248,6 +248,14 @@ static int prof_collect(kpal_ctx *ctx)
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k); \
     }
 
+#define DISPATCH_K_8_16(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__)                               \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "quad partition needs 8 <= k <= 16 (k=%d)", k);             \
+    }
+
 #define DISPATCH_K_8_12(k, ...)                                                                   \
     switch (k) {                                                                                   \
         CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
@@ -616,8 +624,6 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
-// Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
-// one workgroup per bucket histograms.  pool[bucket][workgroup][round] holds one record per flush round.
 constexpr int kQuadsUseChunked = 2;   // launch_partition_quads (AUTO): the sample shows a feed for the chunked pipeline
 
 // Expected number of items per round that do not fit their row: sum over rows of E[max(X - slots, 0)], X ~ Poisson(mu).
@@ -640,6 +646,54 @@ static double quad_expected_overflow(const std::vector<double> &mu, int slots)
         total += acc;
     }
     return total;
+}
+
+// Tile size of a quad scatter from the row loads of a ~1/64 sample of the feed (quad_sample_kernel): the largest
+// candidate (wave-steps per wave per tile) whose expected overflow per round stays well inside the spill list.
+// Returns kQuadsUseChunked (AUTO only) when a few rows hold more than 1.5 % of all items.
+static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, const int *candidates, size_t n_candidates,
+                             int *steps_out)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    const uint32_t sample_steps = 4;                                       // per wave: 32 KiB per workgroup
+    const uint64_t want = std::max<uint64_t>(1, total_steps / (64ull * 8 * sample_steps));   // ~1/64 of the input
+    const uint32_t groups = (uint32_t)std::min<uint64_t>(want, 1024);
+    const uint64_t stride = std::max<uint64_t>(8 * sample_steps, total_steps / groups);
+    HIPCHK(hipMemsetAsync(load, 0, (size_t)buckets * sizeof(uint32_t), ctx->stream));
+    DISPATCH_K_8_16(ctx->k, LAUNCH(ctx, "quad_sample", (quad_sample_kernel<K>), dim3(groups), dim3(512), s, stride, sample_steps, load));
+    std::vector<uint32_t> h((size_t)buckets);
+    HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
+    // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
+    // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
+    std::vector<double> per_step((size_t)buckets);
+    for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
+    std::sort(per_step.begin(), per_step.end());
+    // When those hot rows hold more than 1.5 % of all items (reads that share an adapter / primer prefix, several
+    // per cent of low-complexity reads) the slow path of the scatter would run in nearly every placement step --
+    // measured 20-50x slower on a 20..40-base prefix shared by all reads.  The round-1 pipelines take such a feed
+    // in their stride (their buckets simply own more chunks), so AUTO hands the feed over; an explicitly chosen quad
+    // strategy stays (tests, A/B).
+    {
+        double all = 0.0, hot = 0.0;
+        const double median = per_step[(size_t)buckets / 2];
+        for (int b = 0; b < buckets; ++b) all += per_step[b];
+        for (int b = buckets - 32; b < buckets; ++b) hot += std::max(0.0, per_step[b] - median);
+        if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all) return kQuadsUseChunked;
+    }
+    per_step.resize((size_t)buckets - 32);
+    std::vector<double> mu(per_step.size());
+    *steps_out = candidates[n_candidates - 1];
+    for (size_t ci = 0; ci < n_candidates; ++ci) {
+        const int c = candidates[ci];
+        for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * 8 * c;
+        if (quad_expected_overflow(mu, slots) <= 700.0) {                  // list: 2048 entries
+            *steps_out = c;
+            break;
+        }
+    }
+    return KPAL_OK;
 }
 
 // Partition of quads into aligned records, k = 8..12 (quad_kernels.hpp): one workgroup per CU scatters,
@@ -666,43 +720,8 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     for (int c : candidates)
         if (c == steps_env) steps = c;
     if (!steps) {
-        const uint32_t sample_steps = 4;                                       // per wave: 32 KiB per workgroup
-        const uint64_t want = std::max<uint64_t>(1, total_steps / (64ull * 8 * sample_steps));   // ~1/64 of the input
-        const uint32_t groups = (uint32_t)std::min<uint64_t>(want, 1024);
-        const uint64_t stride = std::max<uint64_t>(8 * sample_steps, total_steps / groups);
-        HIPCHK(hipMemsetAsync(load, 0, (size_t)buckets * sizeof(uint32_t), ctx->stream));
-        DISPATCH_K_8_12(ctx->k, LAUNCH(ctx, "quad_sample", (quad_sample_kernel<K>), dim3(groups), dim3(512), s, stride, sample_steps, load));
-        std::vector<uint32_t> h((size_t)buckets);
-        HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
-        // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
-        // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
-        std::vector<double> per_step((size_t)buckets);
-        for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
-        std::sort(per_step.begin(), per_step.end());
-        // When those hot rows hold more than 1.5 % of all items (reads that share an adapter / primer prefix, several
-        // per cent of low-complexity reads) the slow path of the scatter would run in nearly every placement step --
-        // measured 20-50x slower on a 20..40-base prefix shared by all reads.  The chunked pipeline takes such a feed
-        // in its stride (its buckets simply own more chunks), so AUTO hands the feed over; an explicitly chosen quad
-        // strategy stays (tests, A/B).
-        {
-            double all = 0.0, hot = 0.0;
-            const double median = per_step[(size_t)buckets / 2];
-            for (int b = 0; b < buckets; ++b) all += per_step[b];
-            for (int b = buckets - 32; b < buckets; ++b) hot += std::max(0.0, per_step[b] - median);
-            if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all) return kQuadsUseChunked;
-        }
-        per_step.resize((size_t)buckets - 32);
-        std::vector<double> mu(per_step.size());
-        steps = candidates[sizeof(candidates) / sizeof(candidates[0]) - 1];
-        for (int c : candidates) {
-            for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * 8 * c;
-            if (quad_expected_overflow(mu, slots) <= 700.0) {                  // list: 2048 entries
-                steps = c;
-                break;
-            }
-        }
+        const int rc = quad_choose_steps(ctx, s, load, buckets, slots, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
+        if (rc != KPAL_OK) return rc;
     }
     const uint64_t tile_steps = 8ull * steps;
     const uint64_t tiles = (total_steps + tile_steps - 1) / tile_steps;
@@ -759,9 +778,14 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
         ctx->quad_error_word = error;
     }
     // level 1: 12 wave-steps per wave per tile bring 91 items per 128-slot row (22.8 per 32 at k = 16) for uniform
-    // k-mers; KPAL_QUAD_STEPS = 6 halves the tile (skewed composition; no sampling on this path yet)
+    // k-mers; the sampled row loads say whether THIS feed needs half the tile, or (AUTO) the round-1 pipeline
     static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
-    const int steps1 = steps_env == 6 ? 6 : 12;
+    int steps1 = steps_env == 6 ? 6 : (steps_env == 12 ? 12 : 0);
+    if (!steps1) {
+        static const int candidates[] = {12, 6};
+        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, candidates, 2, &steps1);
+        if (rc != KPAL_OK) return rc;
+    }
     const uint64_t tile_steps = 8ull * steps1;
     const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
@@ -925,7 +949,12 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
     else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
-    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS && n < ((size_t)64 << 20)) strat = KPAL_STRATEGY_PARTITION2;
+    // the two-level quad pipeline stages and combines 16 bytes per TABLE ENTRY whatever the feed holds (k = 15: 17 GB written,
+    // 34 GB combined): it wins once the feed is about half as large as the table (k = 15: 44 vs 59 ms on 15 GB, but 11.8 vs
+    // 8.7 ms on 1 GiB); below that the round-1 two-level pipeline stays
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS &&
+             n < std::max<size_t>((size_t)64 << 20, (size_t)(ctx->bins * 4)))
+        strat = KPAL_STRATEGY_PARTITION2;
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
@@ -969,7 +998,17 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
-        else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) CHK(launch_partition2_quads(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
+            const int rc = launch_partition2_quads(ctx, s);
+            if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the round-1 two-level pipeline
+                ctx->strategy = KPAL_STRATEGY_PARTITION2;
+                const int r2 = count_device_range(ctx, addr + off, len, halo + off);
+                ctx->strategy = KPAL_STRATEGY_AUTO;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
         else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
             const int rc = launch_partition_quads(ctx, s);
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size

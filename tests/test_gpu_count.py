@@ -481,6 +481,9 @@ def test_partition_pipelines_on_skewed_inputs(ctx):
             want = oracle.count_flat(buf, k, threads=8)
             for strat in ('partition_quads', 'partition_chunked', 'partition'):
                 np.testing.assert_array_equal(ctx.count_bytes(k, buf, strat), want, err_msg='%s k=%d %s' % (name, k, strat))
+        want = oracle.count_flat(buf, 13, threads=8)       # the two-level pipelines (level-1 rows, hot-item table, level 2)
+        for strat in ('partition2_quads', 'partition2'):
+            assert np.array_equal(ctx.count_bytes(13, buf, strat), want), '%s k=13 %s' % (name, strat)
 
 
 def _kmers_numpy(buf, k, read_len=150):
