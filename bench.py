@@ -88,10 +88,18 @@ def cpu_baseline(k, read_len, budget_reads):
     t0 = time.perf_counter()
     c1 = oracle.count_flat(buf, k, threads=1)
     t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    cn = oracle.count_flat(buf, k, threads=cores)
-    tn = time.perf_counter() - t0
-    assert int(c1.sum()) == int(cn.sum()) == budget_reads * (read_len - k + 1)
+    # all cores: one shared table, relaxed atomic adds; on a many-socket host fewer threads can be faster (cache-line
+    # ping-pong), so a few thread counts are timed and the best is reported with its own core count
+    tn, best_threads, tried = None, cores, {}
+    for threads in sorted(set([cores, min(cores, 64), min(cores, 16)]), reverse=True):
+        t0 = time.perf_counter()
+        cn = oracle.count_flat(buf, k, threads=threads)
+        t = time.perf_counter() - t0
+        tried[str(threads)] = t
+        assert int(cn.sum()) == budget_reads * (read_len - k + 1)
+        if tn is None or t < tn:
+            tn, best_threads = t, threads
+    assert int(c1.sum()) == budget_reads * (read_len - k + 1)
     bases = budget_reads * read_len
     # BASELINE config 1: 10 k reads, k = 9 through the interpreter loop
     reads1 = [bytes(r).decode() for r in oracle.synth_reads(1, 0, 10000, 150).reshape(-1, 151)[:, :150]]
@@ -102,9 +110,10 @@ def cpu_baseline(k, read_len, budget_reads):
     return {
         'value': bases / t1 / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
         'sample': '%d synthetic %d bp reads, k=%d, oracle/kpal_oracle.c (1 thread: %.2f s)' % (budget_reads, read_len, k, t1),
-        'all_cores': {'value': bases / tn / 1e9, 'cores': cores, 'seconds': tn,
-                      'per_thread_efficiency': (bases / tn) / (bases / t1) / cores,
-                      'note': 'one shared 4^k table, relaxed atomic adds (oracle/kpal_oracle.c)'},
+        'all_cores': {'value': bases / tn / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn,
+                      'per_thread_efficiency': (bases / tn) / (bases / t1) / best_threads,
+                      'seconds_by_threads': tried,
+                      'note': 'one shared 4^k table, relaxed atomic adds (oracle/kpal_oracle.c); best of the thread counts tried'},
         'python_reference_loop': {'value': 1.5e6 / tp / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'seconds': tp,
                                   'sample': 'BASELINE config 1 (10000 reads, k=9) through oracle/pyref.py, the statement-by-statement restatement of kpal/klib.py:149-170'},
     }

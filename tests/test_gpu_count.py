@@ -443,9 +443,14 @@ def test_two_level_k15_against_oracle(mode):
     skew[3 << 20:(3 << 20) + 300000] = np.resize(np.frombuffer(b'AC', dtype=np.uint8), 300000)
     try:
         for data in (buf, seq, skew):
+            want = oracle.count_flat(data, 15, threads=8)
             got = c2.count_bytes(15, data, 'partition2')
-            assert np.array_equal(got, oracle.count_flat(data, 15, threads=8))
+            assert np.array_equal(got, want)
             del got
+            if mode == '2':      # and the two-level quad pipeline (level-1 records, level-2 records, staged forms + combine)
+                got = c2.count_bytes(15, data, 'partition2_quads')
+                assert np.array_equal(got, want)
+                del got
     finally:
         c2.close()
 
