@@ -43,22 +43,54 @@ __host__ __device__ inline uint64_t revcomp(uint64_t x, int k)
     return y >> (64 - 2 * k);
 }
 
-// 4 ASCII bytes -> 8 bits of codes (first byte most significant) + 4 bad flags (same order).
+// 4 ASCII bytes -> the per-byte code field t (2 bits at the bottom of every byte) and the per-byte flag nz
+// (0x80 where the byte is not in the alphabet).
 // code = ((c >> 1) ^ (c >> 2)) & 3 maps A,C,G,T (either case) to 0,1,2,3 (kpal/klib.py:43-48);
 // a byte is in the alphabet iff looking its code up in "ACGT" (one v_perm_b32 for the four
-// bytes) gives the byte back with the case bit 0x20 ignored.  ~17 VALU ops per dword.
-__device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
+// bytes) gives the byte back with the case bit 0x20 ignored.
+__device__ __forceinline__ void classify4(uint32_t w, uint32_t &t, uint32_t &nz)
 {
-    const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
+    t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x54474341u /* "ACGT" */, t);
     const uint32_t x = (w & 0xDFDFDFDFu) ^ expect;
-    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 per non-matching byte
-    // byte 0 (lowest address) is the oldest base -> most significant digit.  The 24-bit multiply
-    // gathers the codes of bytes 0..2 into bits 21:16 (fields never overlap, so no carries).
-    const uint32_t g = __umul24(t, 0x100401u);
-    code8 = ((g >> 14) & 0xFCu) | (t >> 24);
-    const uint32_t h = __umul24(nz >> 7, 0x040201u);  // flags of bytes 0..2 -> bits 18:16
-    bad4 = ((h >> 15) & 0xEu) | (nz >> 31);
+    nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 per non-matching byte
+}
+
+// Byte 0 (lowest address) is the oldest base -> most significant digit.  Two shift-or steps bring the four
+// 2-bit codes of t together in the TOP byte (b0 b1 b2 b3; the fields never meet, the byte comes out clean):
+//   x = t << 10 | t   puts b0 next to b1 (bits 11:8) and b2 next to b3 (bits 27:24);  x << 20 | x  joins them.
+// (v_lshl_or_b32 spelled out: written as shifts and ORs the compiler turns each gather into a multiplication by
+// (1 + 2^10)(1 + 2^20), and a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+template <int SH>
+__device__ __forceinline__ uint32_t shl_or(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t codes_to_top_byte(uint32_t t)
+{
+    const uint32_t x = shl_or<10>(t, t);
+    return shl_or<20>(x, x);
+}
+
+// The same for the flags of m (one bit per byte at bit position 0 and / or 4 of the byte: the flags of TWO dwords
+// can ride together): the flags at position 0 come together in the low nibble of the top byte, those at position 4
+// in the high nibble.
+__device__ __forceinline__ uint32_t flags_to_top_byte(uint32_t m)
+{
+    const uint32_t x = shl_or<9>(m, m);
+    return shl_or<18>(x, x);
+}
+
+// (kept for callers that encode single dwords) 8 bits of codes + 4 bad flags, first byte most significant
+__device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
+{
+    uint32_t t, nz;
+    classify4(w, t, nz);
+    code8 = codes_to_top_byte(t) >> 24;
+    bad4 = flags_to_top_byte(nz >> 7) >> 24;
 }
 
 struct Chunk {
@@ -66,16 +98,23 @@ struct Chunk {
     uint32_t bad;    // 16 flags, base 0 in bit 15
 };
 
+// ~54 VALU: 8 per dword to classify, 2 per dword + three v_perm_b32 for the codes, 5 per PAIR of dwords (the flags of
+// dwords 0 / 2 ride at bit 4 of every byte, those of 1 / 3 at bit 0) + one v_perm_b32 for the flags.
 __device__ __forceinline__ Chunk encode16(uint4 v)
 {
-    uint32_t c0, c1, c2, c3, m0, m1, m2, m3;
-    encode4(v.x, c0, m0);
-    encode4(v.y, c1, m1);
-    encode4(v.z, c2, m2);
-    encode4(v.w, c3, m3);
+    uint32_t t0, t1, t2, t3, z0, z1, z2, z3;
+    classify4(v.x, t0, z0);
+    classify4(v.y, t1, z1);
+    classify4(v.z, t2, z2);
+    classify4(v.w, t3, z3);
+    const uint32_t c0 = codes_to_top_byte(t0), c1 = codes_to_top_byte(t1), c2 = codes_to_top_byte(t2), c3 = codes_to_top_byte(t3);
+    const uint32_t c01 = __builtin_amdgcn_perm(c0, c1, 0x07030000u);      // bytes 3, 2 = top bytes of c0, c1
+    const uint32_t c23 = __builtin_amdgcn_perm(c2, c3, 0x07030000u);
+    const uint32_t f01 = flags_to_top_byte((z0 >> 3) | (z1 >> 7));   // top byte = flags of dword 0 | dword 1
+    const uint32_t f23 = flags_to_top_byte((z2 >> 3) | (z3 >> 7));
     Chunk r;
-    r.codes = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
-    r.bad = (m0 << 12) | (m1 << 8) | (m2 << 4) | m3;
+    r.codes = __builtin_amdgcn_perm(c01, c23, 0x07060302u);
+    r.bad = __builtin_amdgcn_perm(f01, f23, 0x0c0c0703u);
     return r;
 }
 
@@ -189,15 +228,16 @@ __device__ __forceinline__ void wave_step(const Span &s, int64_t c, Chunk &carry
     if constexpr (EDGE) mask &= emit_from_mask(s, c);
 }
 
-// wave_step on data that was fetched earlier (software prefetch): `raw` = fetch_chunk(s, c).
+// wave_step on data that was fetched earlier (software prefetch): `raw` = fetch_chunk(s, c).  `edge` (wave-uniform)
+// = the step may touch the ends of the fed range; true for an interior step is harmless (the range logic is then
+// evaluated and changes nothing), so a caller may pass one flag for a whole run of steps.
 template <int K>
 __device__ __forceinline__ void encode_step(const Span &s, uint64_t step, const uint4 raw, Chunk &carry,
-                                            uint64_t &window, uint32_t &mask)
+                                            uint64_t &window, uint32_t &mask, bool edge)
 {
     const int lane = threadIdx.x & 63;
     const int64_t c = (int64_t)(step * 64 + lane);
     Chunk cur = encode16(raw);
-    const bool edge = !(step * 64 >= 1 && (step * 64 - 1) * 16 >= s.lo && (step * 64 + 64) * 16 <= s.hi && s.emit_from <= step * 64 * 16);
     if (edge) range_fix(s, c, cur);   // wave-uniform branch
     const uint32_t pc = from_left_lane(cur.codes, carry.codes);
     const uint32_t pb = from_left_lane(cur.bad, carry.bad);
@@ -206,6 +246,19 @@ __device__ __forceinline__ void encode_step(const Span &s, uint64_t step, const 
     window = ((uint64_t)pc << 32) | cur.codes;
     mask = emit_mask<K>(pb, cur.bad);
     if (edge) mask &= emit_from_mask(s, c);
+}
+
+// steps [step0, step1) and the chunk left of them lie inside the fed range and right of emit_from
+__device__ __forceinline__ bool interior_steps(const Span &s, uint64_t step0, uint64_t step1)
+{
+    return step0 * 64 >= 1 && (step0 * 64 - 1) * 16 >= s.lo && step1 * 64 * 16 <= s.hi && s.emit_from <= step0 * 64 * 16;
+}
+
+template <int K>
+__device__ __forceinline__ void encode_step(const Span &s, uint64_t step, const uint4 raw, Chunk &carry,
+                                            uint64_t &window, uint32_t &mask)
+{
+    encode_step<K>(s, step, raw, carry, window, mask, !interior_steps(s, step, step + 1));
 }
 
 // true iff chunks [c0 - 1, c1) are wholly inside [lo, hi) and every k-mer ending in [c0, c1) is emitted

@@ -625,6 +625,9 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
 }
 
 constexpr int kQuadsUseChunked = 2;   // launch_partition_quads (AUTO): the sample shows a feed for the chunked pipeline
+constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
+// a record store of the quad scatters is a scalar base + a 32-bit per-thread offset that spans 1/16 of the pool
+constexpr size_t kQuadPoolMax = (size_t)60 << 30;
 
 // Expected number of items per round that do not fit their row: sum over rows of E[max(X - slots, 0)], X ~ Poisson(mu).
 static double quad_expected_overflow(const std::vector<double> &mu, int slots)
@@ -719,6 +722,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     int steps = 0;
     for (int c : candidates)
         if (c == steps_env) steps = c;
+    if (steps_env == 14 || steps_env == 15 || steps_env == 16) steps = steps_env;   // (A/B only: larger tiles than the sample ever picks)
     if (!steps) {
         const int rc = quad_choose_steps(ctx, s, load, buckets, slots, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
         if (rc != KPAL_OK) return rc;
@@ -729,6 +733,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     const uint64_t tpb = (tiles + G - 1) / G;          // tiles (= flush rounds) per workgroup
     if (tpb > 0xFFFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
     const size_t pool_bytes = (size_t)kQuadRowWords * 4 * G * tpb;   // every round writes all rows: 128 KiB per workgroup
+    if (pool_bytes > kQuadPoolMax && s.nchunks > 64) return kSplitBatch;   // (heavily skewed 16 GiB piece: small tiles)
     CHK(ensure(ctx, ctx->keys, pool_bytes));
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
@@ -737,6 +742,9 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
            error, table)
     DISPATCH_K_8_12(ctx->k, {
         switch (steps) {
+        case 16: KPAL_QUAD_LAUNCH(16); break;
+        case 15: KPAL_QUAD_LAUNCH(15); break;
+        case 14: KPAL_QUAD_LAUNCH(14); break;
         case 13: KPAL_QUAD_LAUNCH(13); break;
         case 8: KPAL_QUAD_LAUNCH(8); break;
         case 6: KPAL_QUAD_LAUNCH(6); break;
@@ -791,14 +799,19 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
     const uint64_t tpb1 = (tiles1 + G1 - 1) / G1;
     if (tpb1 > 0xFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
-    CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * tpb1));
+    // capacity (stride) of a level-1 workgroup's run of records per row: rounded up so that a unit of level 2 is a whole
+    // number of KiB -- a wave-step of quad2_scatter_kernel then never straddles two units
+    const uint64_t per_kib = 1024 / (S1 * 4);                                   // records per KiB: 2 (8 at k = 16)
+    const uint64_t cap1 = (tpb1 + per_kib - 1) / per_kib * per_kib;
+    if ((size_t)kQuadRowWords * 4 * G1 * cap1 > kQuadPoolMax && s.nchunks > 64) return kSplitBatch;
+    CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * cap1));
     uint32_t *pool1 = (uint32_t *)ctx->residuals.p;
     // level 2: ~4 workgroups per CU in total; workgroup (g2, c) takes `upw` of the REP x G1 units of coarse bucket c
     const uint32_t units = REP * G1;
     uint32_t G2 = std::max<uint32_t>(1, std::min<uint32_t>(units, (uint32_t)ctx->num_cu * 4 / NB1));
     const uint32_t upw = (units + G2 - 1) / G2;
     G2 = (units + upw - 1) / upw;
-    const uint64_t unit_cap = tpb1 * S1 * 4;                                   // bytes
+    const uint64_t unit_cap = cap1 * S1 * 4;                                   // bytes
     if ((uint64_t)upw * unit_cap >= (1ull << 32)) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
     constexpr int kSteps2 = 16;
     const uint64_t tile2_bytes = 8ull * kSteps2 * 1024;
@@ -807,7 +820,7 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
     // the staged forms of the histogram stage (16 bytes per table entry: 17 GB at k = 15) reuse the level-1 pool's buffer:
     // level 2 has read it completely before the histogram kernel starts (same stream)
-    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * tpb1, (size_t)ctx->bins * 16)));
+    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 16)));
     pool1 = (uint32_t *)ctx->residuals.p;
     uint32_t *stage = pool1;
     uint32_t *pool2 = (uint32_t *)ctx->keys.p;
@@ -815,11 +828,11 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {
         if (steps1 == 6)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 6, 6>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)tpb1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 6, 6>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 12, 12>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)tpb1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 12, 12>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kSteps2>), dim3(G2, NB1), dim3(512), (const uint32_t *)pool1,
-               (const uint32_t *)nrounds1, G1, (uint32_t)tpb1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
+               (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
                G2, (uint32_t)tiles2, table, stage);
         LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 1024)), dim3(256), (const uint32_t *)stage, table);
@@ -827,7 +840,6 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
-constexpr int kSplitBatch = 1;   // launch_partition2: a coarse bucket would overflow its 32-bit offsets
 
 // Two-level partition, k = 13..16: coarse count/scan/scatter into 24-bit residuals, then the
 // one-level pipeline on every coarse bucket's residual stream (2-D launches over coarse buckets).
@@ -938,6 +950,17 @@ static int launch_partition2(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
+static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo);
+
+// A piece whose record pool would be too large (kSplitBatch): as two halves.
+static int count_device_halves(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo)
+{
+    const size_t half = (n / 2 + 15) & ~(size_t)15;
+    CHK(count_device_range(ctx, addr, half, halo));
+    if (n > half) CHK(count_device_range(ctx, addr + half, n - half, halo + half));
+    return KPAL_OK;
+}
+
 // Count all k-mers ending in [addr, addr+n) of a device buffer; `halo` bytes left of addr are
 // readable and belong to the same feed.
 static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo)
@@ -1005,6 +1028,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
                 const int r2 = count_device_range(ctx, addr + off, len, halo + off);
                 ctx->strategy = KPAL_STRATEGY_AUTO;
                 if (r2 != KPAL_OK) return r2;
+            } else if (rc == kSplitBatch) {
+                CHK(count_device_halves(ctx, addr + off, len, halo + off));
             } else if (rc != KPAL_OK) {
                 return rc;
             }
@@ -1016,6 +1041,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
                 const int r2 = count_device_range(ctx, addr + off, len, halo + off);
                 ctx->strategy = KPAL_STRATEGY_AUTO;
                 if (r2 != KPAL_OK) return r2;
+            } else if (rc == kSplitBatch) {
+                CHK(count_device_halves(ctx, addr + off, len, halo + off));
             } else if (rc != KPAL_OK) {
                 return rc;
             }

@@ -56,9 +56,6 @@ struct QuadCfg {
     static constexpr int kScrBits = (kLowBits - 6) < 4 ? (kLowBits - 6) : 4;   // bits of the low field that scramble the bucket
     static constexpr uint64_t kXMask = (1ull << (2 * K + 6)) - 1ull;            // the (K+3)-mer: at most 38 bits
     static constexpr uint32_t kLowMask = (1u << kLowBits) - 1u;
-    // rows are rotated by a multiple of four words so that rows filling in lock-step hit different banks
-    // while the flush still reads whole 16-byte vectors
-    __host__ __device__ static constexpr uint32_t rot(uint32_t row) { return (4u * (kSlots == 16 ? row >> 1 : row)) & (uint32_t)(kSlots - 1); }
     // bucket scrambling (see chunk_scramble): the top kScrBits of the low field pick one of 2^kScrBits masks
     __host__ __device__ static constexpr uint32_t smask(uint32_t t)
     {
@@ -190,23 +187,25 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
     }
 }
 
-// Returns the mask (bit q) of this lane's items that did not fit their row.
-template <int K, bool DIRECT = false, int LEVEL = 1>
+// Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
+// the row (the atomic returns the item's byte offset: one shift-add gives its LDS address).
+template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4>
 __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
-                                               const uint32_t (&row)[4], const uint32_t (&item)[4], unsigned long long *table,
+                                               const uint32_t (&row)[N], const uint32_t (&item)[N], unsigned long long *table,
                                                QuadHot *hot, uint32_t coarse = 0)
 {
     using C = typename std::conditional<LEVEL == 2, QuadCfg<11>, QuadCfg<K>>::type;   // level 2: 512 rows x 64 slots
-    uint32_t slot[4];
+    constexpr uint32_t RB = (uint32_t)C::kSlots * 4u;                                  // bytes per row
+    uint32_t off[N];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) slot[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 1u : 0u);
+    for (int q = 0; q < N; ++q) off[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 4u : 0u);
     uint32_t over = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < N; ++q) {
         const bool counted = (item[q] & 15u) != 0u;
-        const bool fits = slot[q] < (uint32_t)C::kSlots;
-        const uint32_t at = row[q] * C::kSlots + ((slot[q] + C::rot(row[q])) & (uint32_t)(C::kSlots - 1));
-        rows[(counted && fits) ? at : (uint32_t)kQuadRowWords] = item[q];     // not counted / full row: dummy word
+        const bool fits = off[q] < RB;
+        const uint32_t at = row[q] * RB + off[q];
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + ((counted && fits) ? at : (uint32_t)kQuadRowWords * 4u)) = item[q];   // not counted / full row: dummy word
         over |= (counted && !fits) ? (1u << q) : 0u;
     }
     if (__builtin_expect(__any(over != 0u), 0)) {   // wave-uniform
@@ -215,16 +214,27 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 #else
         constexpr bool direct = DIRECT;
 #endif
+        // one LDS atomic per call reserves the list entries of all the wave's overflowed items (a lane finds its own
+        // with ballots and lane counts)
+        uint32_t base = 0;
+        if constexpr (!direct) {
+            uint32_t total = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ov = (item[q] & 15u) && slot[q] >= (uint32_t)C::kSlots;
+            for (int q = 0; q < N; ++q) total += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((over >> q) & 1u));
+            uint32_t got = 0;
+            if ((threadIdx.x & 63u) == 0u) got = atomicAdd(spill_n, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        }
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const bool ov = (over >> q) & 1u;
             bool listed = false;
             if constexpr (!direct) {
-                if (ov) {
-                    const uint32_t at = atomicAdd(spill_n, 1u);
-                    listed = at < cap;
-                    if (listed) spill[at] = QuadSpill{row[q], item[q]};
-                }
+                const unsigned long long b = __builtin_amdgcn_ballot_w64(ov);
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                listed = ov && at < cap;
+                if (listed) spill[at] = QuadSpill{row[q], item[q]};
+                base += (uint32_t)__popcll(b);
             }
             // carried items that still do not fit, and whatever the list cannot hold: counted now
             if (__any(ov && !listed)) quad_items_direct<K, LEVEL>(ov && !listed, row[q], item[q], table, hot, coarse);
@@ -242,11 +252,11 @@ __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos
 {
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) {
-        const uint32_t r4[4] = {carry_row[c], 0u, 0u, 0u};
-        const uint32_t i4[4] = {carry_item[c], 0u, 0u, 0u};
+        const uint32_t r1[1] = {carry_row[c]};
+        const uint32_t i1[1] = {carry_item[c]};
         if (__any(carry_item[c] != 0u)) {
             // an item that does not fit even now has been counted: it is no longer carried
-            if (quad_place<K, true, LEVEL>(rows, pos, spill, spill_n, cap, r4, i4, table, hot, coarse) & 1u) carry_item[c] = 0;
+            if (quad_place<K, true, LEVEL, 1>(rows, pos, spill, spill_n, cap, r1, i1, table, hot, coarse) & 1u) carry_item[c] = 0;
         }
     }
 }
@@ -300,6 +310,20 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
         if (cnt[i]) atomicAdd(&load[i], cnt[i]);
 }
 
+// One wave-step of input: 16 bytes per lane of step `step` (wave-uniform).  Interior steps are one load from a
+// scalar base address + the lane's constant byte offset; a step that crosses the end of the buffer checks per lane.
+__device__ __forceinline__ uint4 fetch_wave_step(const Span &s, uint64_t step, uint32_t lane16)
+{
+    if ((step + 1) * 64 <= s.nchunks)   // wave-uniform
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s.base + step * 64) + lane16);
+    return fetch_chunk(s, (int64_t)(step * 64 + (lane16 >> 4)));
+}
+
+// The flush of both scatter kernels: the 128 KiB of rows leave LDS as 8192 16-byte vectors, FI per thread, and
+// are zeroed behind the read -- the rows of the next round start empty, so whatever lies beyond a row's last
+// item is the null padding of its record (no per-item compare against the row's fill); pos is cleared likewise.
+// (Written out in both kernels: as a function taking rec[] by reference the array was kept in scratch memory.)
+
 // Q1: ASCII -> records.  Tile j of workgroup g is tile j * G + g of the input (the grid reads one sliding
 // window); wave w takes its steps STEPS*w .. STEPS*w+STEPS-1.  A tile of WAVES x STEPS KiB brings
 // 0.119 x WAVES x STEPS items per 16-slot row at k = 12 (96 steps: 11.4, records 71 % full, 1.5 % of the items
@@ -308,8 +332,12 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
 // barrier.  The records are STORED during the placement of the next tile, a store instruction or two per
 // step, and each step's chunk of the next tile is requested as soon as this tile's has been encoded: the
 // CU's memory pipe (8-10 B/clk for loads + stores together, tools/store_probe2.hip) stays busy under the
-// LDS / VALU work instead of alternating with it.  WAVES = 8 (256 registers per lane; 16 records live) or 16 (128
-// registers; 8 records live).
+// LDS / VALU work instead of alternating with it.  WAVES = 8: two waves per SIMD with ~200 registers each
+// (16 record vectors + a tile of prefetched chunks live).
+//   The kernel issues ~2 VALU instructions per input byte and lane, so everything wave-uniform is kept scalar:
+// the wave index is read with readfirstlane (tile / step numbers, the edge tests of encode_step and the load
+// addresses become SALU work; a load is saddr + lane * 16), and a record store is a scalar base (row group, workgroup,
+// round) + one per-thread 32-bit offset fixed for the whole kernel.
 // pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots.
 template <int K, int WAVES, int STEPS, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
@@ -322,16 +350,18 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     constexpr int THREADS = WAVES * 64;
     constexpr int kQuadTileSteps = WAVES * STEPS;
     constexpr int CARRY = kQuadSpillCap / THREADS;      // carried items per thread
-    constexpr uint32_t CAP = CARRY * THREADS;           // spill list entries in use (2048; 1536 with 12 waves)
-    static_assert(CARRY >= 1 && STEPS % DEPTH == 0, "tile shape");
+    constexpr uint32_t CAP = CARRY * THREADS;           // spill list entries in use
+    static_assert(WAVES == 8 && STEPS % DEPTH == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
-    __shared__ uint32_t pos[NB];
+    __shared__ __attribute__((aligned(16))) uint32_t pos[NB];   // BYTES in use per row
     __shared__ QuadSpill spill[kQuadSpillCap];
     __shared__ uint32_t spill_cnt[2];           // appended-entries counter of even / odd tiles: the one of tile j is read by every
                                                 // thread after the placement barrier, so it may only be reset a barrier later --
                                                 // thread 0 resets the OTHER one (for tile j+1) during the flush of tile j
     __shared__ QuadHot hot[kQuadHotEntries];    // items of persistently over-full rows, counted here instead of in the table
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
     for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
     if (threadIdx.x == 0) {
@@ -349,40 +379,45 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     {
         const uint64_t f = tile_step(0);
 #pragma unroll
-        for (int st = 0; st < DEPTH; ++st) raw[st] = fetch_chunk(s, (int64_t)((f + st) * 64 + lane));
+        for (int st = 0; st < DEPTH; ++st) raw[st] = fetch_wave_step(s, f + st, lane16);
         rawh = fetch_chunk(s, (int64_t)(f * 64) - 1);
     }
     uint32_t round = 0;                         // records written per row so far
     uint32_t carry_row[CARRY], carry_item[CARRY];   // items carried over from the previous round (item 0 = none)
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) carry_row[c] = carry_item[c] = 0;
-    // the flush: FI store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores
+    // the flush: FI store instructions per wave, each writing 64 / (S/4) whole records with 16-byte stores;
     // thread t handles the 16-byte vectors t, t + THREADS, ... of the 8192 that make up the rows
     constexpr int LPR = S / 4;                  // lanes (vectors) per record
-    constexpr int NVEC = NB * LPR;
-    constexpr int FI = (NVEC + THREADS - 1) / THREADS;   // 8 (16 waves), 11 (12 waves), 16 (8 waves)
+    constexpr int FI = kQuadRowWords / 4 / THREADS;   // 16
+    static_assert(THREADS % LPR == 0, "a record is written by one wave");
     uint4 rec[FI];                              // the previous round's records, stored during this tile's placement
     bool have_rec = false;                      // block-uniform
+    // vector t + i * THREADS is vector t % LPR of row t / LPR + i * (THREADS / LPR): the thread's part of the address
+    // (32 bits: the host keeps a pool below 64 GiB) never changes, the rest is scalar
+    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap * (uint64_t)(S * 4);
+    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / LPR) * row_bytes) + (threadIdx.x % LPR) * 16u;
     auto store_rec = [&](int i) {
-        uint32_t v = threadIdx.x + (uint32_t)i * THREADS;
-        asm volatile("" : "+v"(v));             // the FI record addresses are recomputed per store (a few VALU), not hoisted
-                                                // out of the tile loop as 2 * FI live registers (see chunk_store_rows)
-        if (NVEC % THREADS != 0 && v >= (uint32_t)NVEC) return;
-        const uint32_t r = v / LPR, fvec = v % LPR;
-        const uint64_t at = ((uint64_t)(r * gridDim.x + blockIdx.x) * rounds_cap + (round - 1u)) * S;
+        uint32_t o = thread_off;
+        asm volatile("" : "+v"(o));             // (no FI hoisted 64-bit addresses)
+        const uint64_t sc = (uint64_t)(i * (THREADS / LPR)) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap + (round - 1u)) * (uint64_t)(S * 4);
 #if defined(KPAL_QUAD_NT)   // A/B builds: non-temporal record stores
-        __builtin_nontemporal_store(rec[i].x, pool + at + 4 * fvec);
-        __builtin_nontemporal_store(rec[i].y, pool + at + 4 * fvec + 1);
-        __builtin_nontemporal_store(rec[i].z, pool + at + 4 * fvec + 2);
-        __builtin_nontemporal_store(rec[i].w, pool + at + 4 * fvec + 3);
+        uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pool) + sc + o);
+        __builtin_nontemporal_store(rec[i].x, q);
+        __builtin_nontemporal_store(rec[i].y, q + 1);
+        __builtin_nontemporal_store(rec[i].z, q + 2);
+        __builtin_nontemporal_store(rec[i].w, q + 3);
 #else
-        *reinterpret_cast<uint4 *>(pool + at + 4 * fvec) = rec[i];
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool) + sc + o) = rec[i];
 #endif
     };
     for (uint64_t j = 0; tile_exists(j); ++j) {   // block-uniform
         const uint64_t first = tile_step(j);
         const bool more = tile_exists(j + 1);
         const uint64_t fnext = tile_step(j + 1);
+        // one range test per wave and tile instead of one per step (64-bit compares are VALU work)
+        const bool edge = !interior_steps(s, first, first + STEPS);
+        const bool next_inside = more && (fnext + STEPS) * 64 <= s.nchunks;
         uint32_t *spill_n = &spill_cnt[j & 1];
         // ---- place: carried items, then this tile's
         quad_place_carried<K, CARRY>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
@@ -397,12 +432,13 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             }
             uint64_t window;
             uint32_t mask;
-            encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask);
+            encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask, edge);
             {
-                uint32_t l = (uint32_t)lane;
-                asm volatile("" : "+v"(l));     // (same: no STEPS hoisted 64-bit load addresses)
-                if (st + DEPTH < STEPS) raw[st % DEPTH] = fetch_chunk(s, (int64_t)((first + st + DEPTH) * 64 + l));
-                else if (more) raw[st % DEPTH] = fetch_chunk(s, (int64_t)((fnext + (st + DEPTH - STEPS)) * 64 + l));
+                uint32_t l16 = lane16;
+                asm volatile("" : "+v"(l16));
+                if (st + DEPTH < STEPS) raw[st % DEPTH] = fetch_wave_step(s, first + st + DEPTH, l16);
+                else if (next_inside) raw[st % DEPTH] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s.base + (fnext + (st + DEPTH - STEPS)) * 64) + l16);
+                else if (more) raw[st % DEPTH] = fetch_chunk(s, (int64_t)((fnext + (st + DEPTH - STEPS)) * 64 + (l16 >> 4)));
             }
             uint32_t row[4], item[4];
 #pragma unroll
@@ -418,20 +454,19 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
         // ---- flush: every row becomes one record of S items (null padded), kept in registers
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
+        {
+            const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *rv = reinterpret_cast<uint4 *>(rows);
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const uint32_t vi = threadIdx.x + (uint32_t)i * THREADS;
-            if (NVEC % THREADS != 0 && vi >= (uint32_t)NVEC) continue;
-            const uint32_t r = vi / LPR, fvec = vi % LPR;
-            const uint32_t n = pos[r];
-            uint4 v = *reinterpret_cast<const uint4 *>(&rows[r * S + 4 * fvec]);
-            const uint32_t s0 = (4u * fvec - C::rot(r)) & (uint32_t)(S - 1);   // slot of the vector's first word
-            v.x = s0 + 0 < n ? v.x : 0u;
-            v.y = s0 + 1 < n ? v.y : 0u;
-            v.z = s0 + 2 < n ? v.z : 0u;
-            v.w = s0 + 3 < n ? v.w : 0u;
-            rec[i] = v;
-            if (fvec == 0) pos[r] = 0;
+            for (int i = 0; i < FI; ++i) {
+                const uint4 v = rv[threadIdx.x + (uint32_t)i * THREADS];
+                rec[i].x = v.x;
+                rec[i].y = v.y;
+                rec[i].z = v.z;
+                rec[i].w = v.w;
+                rv[threadIdx.x + (uint32_t)i * THREADS] = zero4;
+            }
+            for (int i = threadIdx.x * 4; i < NB; i += THREADS * 4) *reinterpret_cast<uint4 *>(&pos[i]) = zero4;
         }
         if (round >= rounds_cap) {               // cannot happen: one round per tile, rounds_cap = tiles per workgroup
             if (threadIdx.x == 0) *error = 2u;
@@ -495,13 +530,14 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
     constexpr int CARRY = kQuadSpillCap / THREADS;
     constexpr uint32_t CAP = CARRY * THREADS;
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
-    __shared__ uint32_t pos[NB];
+    __shared__ __attribute__((aligned(16))) uint32_t pos[NB];   // BYTES in use per row
     __shared__ QuadSpill spill[kQuadSpillCap];
     __shared__ uint32_t spill_cnt[2];
     __shared__ QuadHot hot[kQuadHotEntries];
     __shared__ uint32_t nr1[256];               // rounds written by every level-1 workgroup
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t coarse = blockIdx.y;
+    for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
     for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
     for (uint32_t i = threadIdx.x; i < 256u; i += THREADS) nr1[i] = i < G1 ? nrounds1[i] : 0u;
@@ -512,27 +548,50 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
     __syncthreads();
     const uint32_t units = (uint32_t)C1::kRep * G1;                      // units of this coarse bucket
     const uint32_t u0 = blockIdx.x * upw, u1 = min(u0 + upw, units);
-    const uint32_t unit_cap = rounds_cap1 * (uint32_t)(S1 * 4);          // bytes
+    const uint32_t unit_cap = rounds_cap1 * (uint32_t)(S1 * 4);          // bytes; a multiple of 1024 (the host rounds rounds_cap1)
     const uint32_t stream = (u1 > u0 ? u1 - u0 : 0u) * unit_cap;        // < 2^32: the host sizes the units so
-    // 16 bytes of the stream at byte position p (a multiple of 16), zeros where nothing was written
-    auto fetch = [&](uint64_t p64) -> uint4 {
+    // The wave-step at stream position p (a multiple of 1024) lies in ONE unit: its unit (level-1 workgroup g1, replica
+    // rl) and offset are wave-uniform and tracked incrementally -- one division per wave and tile, scalar adds per step --
+    // and a lane only compares its 16 bytes against the number of records that workgroup wrote (the rest of the unit was
+    // never written: null items).
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    uint64_t nx_p = 0;                          // next position to request
+    uint32_t nx_g1 = 0, nx_rl = 0, nx_off = 0;
+    auto seek = [&](uint64_t j) {               // to the first step of this wave in tile j
+        nx_p = ((j * WAVES + (uint64_t)wave) * STEPS) * 1024ull;
+        if (nx_p < (uint64_t)stream) {
+            const uint32_t ul = (uint32_t)nx_p / unit_cap;
+            nx_off = (uint32_t)nx_p - ul * unit_cap;
+            const uint32_t u = u0 + ul;
+            nx_rl = u / G1;
+            nx_g1 = u - nx_rl * G1;
+        }
+    };
+    auto fetch_next = [&]() -> uint4 {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (p64 < (uint64_t)stream) {
-            const uint32_t p = (uint32_t)p64;
-            const uint32_t ul = p / unit_cap;
-            const uint32_t off = p - ul * unit_cap;
-            const uint32_t u = u0 + ul, g1 = u % G1, rl = u / G1;
-            if (off / (uint32_t)(S1 * 4) < nr1[g1]) {
-                const uint64_t base = ((uint64_t)((coarse * C1::kRep + rl) * G1 + g1) * rounds_cap1) * S1;   // words
-                v = *reinterpret_cast<const uint4 *>(pool1 + base + off / 4);
+        if (nx_p < (uint64_t)stream) {          // wave-uniform
+            const uint32_t written = nr1[nx_g1] * (uint32_t)(S1 * 4);
+            if (nx_off + lane16 < written) {
+                const char *src = reinterpret_cast<const char *>(pool1) +
+                                  ((uint64_t)((coarse * C1::kRep + nx_rl) * G1 + nx_g1) * rounds_cap1) * (uint64_t)(S1 * 4) + nx_off;
+                v = *reinterpret_cast<const uint4 *>(src + lane16);
+            }
+            nx_p += 1024;
+            nx_off += 1024;
+            if (nx_off >= unit_cap) {
+                nx_off = 0;
+                if (++nx_g1 == G1) {
+                    nx_g1 = 0;
+                    ++nx_rl;
+                }
             }
         }
         return v;
     };
-    auto step_pos = [&](uint64_t j, int st) -> uint64_t { return (((j * WAVES + (uint64_t)wave) * STEPS + (uint64_t)st) * 64 + (uint64_t)lane) * 16; };
     uint4 raw[STEPS];
+    seek(0);
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) raw[st] = fetch(step_pos(0, st));
+    for (int st = 0; st < STEPS; ++st) raw[st] = fetch_next();
     uint32_t round = 0;
     uint32_t carry_row[CARRY], carry_item[CARRY];
 #pragma unroll
@@ -543,18 +602,21 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
     uint4 rec[FI];
     bool have_rec = false;
     const uint32_t wg = coarse * gridDim.x + blockIdx.x;
+    // (see quad_scatter_kernel: per-thread 32-bit offset + scalar base)
+    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap2 * (uint64_t)(S * 4);
+    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / LPR) * row_bytes) + (threadIdx.x % LPR) * 16u;
     auto store_rec = [&](int i) {
-        uint32_t v = threadIdx.x + (uint32_t)i * THREADS;
-        asm volatile("" : "+v"(v));
-        const uint32_t r = v / LPR, fvec = v % LPR;
-        const uint64_t at = ((uint64_t)((coarse * NB + r) * gridDim.x + blockIdx.x) * rounds_cap2 + (round - 1u)) * S;
-        *reinterpret_cast<uint4 *>(pool2 + at + 4 * fvec) = rec[i];
+        uint32_t o = thread_off;
+        asm volatile("" : "+v"(o));
+        const uint64_t sc = ((uint64_t)coarse * NB + (uint64_t)(i * (THREADS / LPR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)(S * 4);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool2) + sc + o) = rec[i];
     };
     const uint64_t tile_bytes = (uint64_t)WAVES * STEPS * 1024;
     for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
         const bool more = j + 1 < tiles_per_block && (j + 1) * tile_bytes < (uint64_t)stream;
         uint32_t *spill_n = &spill_cnt[j & 1];
         quad_place_carried<K, CARRY, 2>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
+        if (more) seek(j + 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             if (have_rec) {
@@ -562,7 +624,7 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
                 for (int i = st; i < FI; i += STEPS) store_rec(i);
             }
             const uint4 v = raw[st];
-            if (more) raw[st] = fetch(step_pos(j + 1, st));
+            if (more) raw[st] = fetch_next();
             const uint32_t it[4] = {v.x, v.y, v.z, v.w};
             uint32_t row[4], item[4];
 #pragma unroll
@@ -578,19 +640,19 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
         const uint32_t spilled = min(*spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
+        {
+            const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *rv = reinterpret_cast<uint4 *>(rows);
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const uint32_t vi = threadIdx.x + (uint32_t)i * THREADS;
-            const uint32_t r = vi / LPR, fvec = vi % LPR;
-            const uint32_t n = pos[r];
-            uint4 v = *reinterpret_cast<const uint4 *>(&rows[r * S + 4 * fvec]);
-            const uint32_t s0 = (4u * fvec - C::rot(r)) & (uint32_t)(S - 1);
-            v.x = s0 + 0 < n ? v.x : 0u;
-            v.y = s0 + 1 < n ? v.y : 0u;
-            v.z = s0 + 2 < n ? v.z : 0u;
-            v.w = s0 + 3 < n ? v.w : 0u;
-            rec[i] = v;
-            if (fvec == 0) pos[r] = 0;
+            for (int i = 0; i < FI; ++i) {
+                const uint4 v = rv[threadIdx.x + (uint32_t)i * THREADS];
+                rec[i].x = v.x;
+                rec[i].y = v.y;
+                rec[i].z = v.z;
+                rec[i].w = v.w;
+                rv[threadIdx.x + (uint32_t)i * THREADS] = zero4;
+            }
+            for (int i = threadIdx.x * 4; i < NB; i += THREADS * 4) *reinterpret_cast<uint4 *>(&pos[i]) = zero4;
         }
         if (round >= rounds_cap2) {
             if (threadIdx.x == 0) *error = 3u;

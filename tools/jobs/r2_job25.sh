@@ -1,0 +1,25 @@
+#!/bin/bash
+set -u
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r2_job25; mkdir -p "$OUT"
+( timeout 900 python -m pytest tests/test_gpu_count.py -m gpu -x -q > "$OUT/pytest_count.log" 2>&1; echo "pytest rc=$?" >> "$OUT/pytest_count.log" ); tail -3 "$OUT/pytest_count.log"
+show() { python3 - "$1" "$2" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[2], round(d['value'],1), 'Gbases/s', round(d['ms_per_step'],2), 'ms', {k:round(v,2) for k,v in d['roofline']['kernels_ms_per_step'].items()}, 'checksum', d.get('checksum_ok'))
+PY
+}
+export KPAL_HIP_LIBRARY=$ROOT/build_ab/libkpal_hip_base.so
+python3 bench.py --steps 10 --warmup 3 --no-cpu > "$OUT/bench_k12_base.json" 2>> "$OUT/bench.err"; show "$OUT/bench_k12_base.json" "base k12"
+unset KPAL_HIP_LIBRARY
+python3 bench.py --steps 10 --warmup 3 --no-cpu > "$OUT/bench_k12_new.json" 2>> "$OUT/bench.err"; show "$OUT/bench_k12_new.json" "new k12"
+for st in 12 14 15 16; do
+  KPAL_QUAD_STEPS=$st python3 bench.py --steps 10 --warmup 3 --no-cpu > "$OUT/bench_k12_new_s$st.json" 2>> "$OUT/bench.err"; show "$OUT/bench_k12_new_s$st.json" "new k12 steps=$st"
+done
+for k in 13 15; do
+  python3 bench.py --k $k --steps 4 --warmup 1 --no-cpu > "$OUT/bench_k${k}_new.json" 2>> "$OUT/bench.err"; show "$OUT/bench_k${k}_new.json" "new k$k"
+done
+export KPAL_HIP_LIBRARY=$ROOT/build_ab/libkpal_hip_base.so
+python3 tools/skewbench.py > "$OUT/skewbench_k12_base.log" 2>&1; echo base; grep -v amdgpu.ids "$OUT/skewbench_k12_base.log" | tail -6
+unset KPAL_HIP_LIBRARY
+python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1; echo new; grep -v amdgpu.ids "$OUT/skewbench_k12.log" | tail -6
+python3 tools/skewbench.py --k 13 > "$OUT/skewbench_k13.log" 2>&1; echo new k13; grep -v amdgpu.ids "$OUT/skewbench_k13.log" | tail -6

@@ -28,10 +28,11 @@ python3 "$ROOT/tools/pmc_counters.py" "rocprofv3 --pmc (two passes: LDS/VALU/VME
 # BASELINE config 4 (k = 15)
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_k15" -o k15 -- python3 "$ROOT/bench.py" --k 15 --steps 3 --warmup 1 --no-cpu > "$OUT/bench_k15_n1_under_rocprof.json" 2> "$OUT/stats_k15.err"
 find "$OUT/stats_k15" -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_k15_kernel_stats.csv" \;
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_k15" -o f -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_fetch_k15.err"
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_k15" -o w -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_write_k15.err"
-python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_k15" "$OUT/pmc_write_k15" 9060000000 \
-  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --reads 20000000 --k 15 --steps 2 --warmup 1 (one batch of 3.02 GB per step); gfx950 correction: FETCH_SIZE x2" coarse_scatter > "$OUT/pmc_hbm_traffic_k15.json"
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_k15" -o f -- python3 "$ROOT/bench.py" --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_fetch_k15.err"
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_k15" -o w -- python3 "$ROOT/bench.py" --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_write_k15.err"
+# (40 M reads = 6.04 GB per step: AUTO takes the two-level quad pipeline once the feed is larger than half the 8 GiB table)
+python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_k15" "$OUT/pmc_write_k15" 18120000000 \
+  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 (one batch of 6.04 GB per step); gfx950 correction: FETCH_SIZE x2" quad_scatter > "$OUT/pmc_hbm_traffic_k15.json"
 # BASELINE config 5 (64 profiles, k = 12)
 python3 "$ROOT/bench.py" --workload matrix --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_prod_bench.json" 2> "$OUT/matrix_prod.err"
 python3 "$ROOT/bench.py" --workload matrix --metric euclidean --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_euclidean_bench.json" 2> "$OUT/matrix_eucl.err"
