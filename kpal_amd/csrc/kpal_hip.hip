@@ -87,6 +87,8 @@ struct kpal_ctx {
     size_t batch_bytes = (size_t)1 << 30;
     bool batch_bytes_set = false;            // KPAL_BATCH_BYTES given (else the chunked path uses its own maximum)
     uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
+    size_t quad_pool_max = (size_t)30 << 30; // quad pipelines: largest record pool of one piece (a record store is a scalar base
+                                             // + a 32-bit per-thread offset that spans 1/8 of the pool); larger pieces are halved
     // partition workspace
     DevBuf keys, cntmat, offs, bucket_start, slice_start;
     DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
@@ -301,6 +303,10 @@ static int ctx_init(kpal_ctx *ctx, int device)
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;
+    }
+    if (const char *e = getenv("KPAL_QUAD_POOL_MAX")) {   // tests: exercise the piece-halving path of the quad pipelines
+        unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= ((size_t)1 << 20) && v < ((size_t)30 << 30)) ctx->quad_pool_max = (size_t)v;
     }
     return KPAL_OK;
 }
@@ -626,17 +632,29 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
 
 constexpr int kQuadsUseChunked = 2;   // launch_partition_quads (AUTO): the sample shows a feed for the chunked pipeline
 constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
-// a record store of the quad scatters is a scalar base + a 32-bit per-thread offset that spans 1/16 of the pool
-constexpr size_t kQuadPoolMax = (size_t)60 << 30;
 
-// Expected number of items per round that do not fit their row: sum over rows of E[max(X - slots, 0)], X ~ Poisson(mu).
-static double quad_expected_overflow(const std::vector<double> &mu, int slots)
+// Expected number of items in the spill list of a workgroup in the steady state.  A row is a queue: Poisson(mu) items
+// arrive per round, `slots` leave with the record, the rest is carried to the next round.  The single-round overflow
+// E[max(X - slots, 0)] underestimates the backlog of a well-filled row (carried items arrive again: at 83 % fill of a
+// 16-slot row the backlog is twice the overflow, at 95 % six times; a row whose load exceeds its slots grows without
+// bound until the list is full and the slow direct path takes over -- measured 2x slower on AT-rich input with tiles
+// chosen by the single-round figure).  backlog = overflow x r(fill, slots), r tabulated from a simulation of the queue
+// (tools/diag/spill_queue.py).
+static double quad_expected_backlog(const std::vector<double> &mu, int slots)
 {
+    static const double rho_grid[10] = {0.5, 0.6, 0.7, 0.75, 0.8, 0.85, 0.9, 0.925, 0.95, 0.975};
+    static const double ratio[4][10] = {
+        {1.02, 1.08, 1.25, 1.43, 1.70, 2.19, 3.21, 4.24, 6.34, 12.7},   // 16 slots
+        {1.00, 1.01, 1.08, 1.17, 1.33, 1.65, 2.34, 3.05, 4.52, 8.9},    // 32
+        {1.00, 1.00, 1.01, 1.04, 1.12, 1.30, 1.75, 2.24, 3.25, 6.35},   // 64
+        {1.00, 1.00, 1.00, 1.02, 1.02, 1.10, 1.36, 1.68, 2.37, 4.55}};  // 128
+    const int ti = slots <= 16 ? 0 : (slots <= 32 ? 1 : (slots <= 64 ? 2 : 3));
     double total = 0.0;
     for (double m : mu) {
         if (m <= 0.0) continue;
-        if (m > 4.0 * slots) {   // far above the capacity: no tail to speak of
-            total += m - slots;
+        const double rho = m / slots;
+        if (rho >= 0.995) {   // the row cannot keep up
+            total += 1e6;
             continue;
         }
         // E[max(X - c, 0)] = sum_{x > c} (x - c) p(x); p by recurrence from p(0) = exp(-m)
@@ -646,16 +664,27 @@ static double quad_expected_overflow(const std::vector<double> &mu, int slots)
             p *= m / x;
             if (x > slots) acc += (x - slots) * p;
         }
-        total += acc;
+        double r = 1.0;
+        if (rho >= rho_grid[9]) {
+            r = ratio[ti][9];
+            acc = std::max(acc * r, m / (2.0 * (slots - m)));   // heavy traffic
+            r = 1.0;
+        } else if (rho > rho_grid[0]) {
+            int j = 0;
+            while (rho > rho_grid[j + 1]) ++j;
+            const double f = (rho - rho_grid[j]) / (rho_grid[j + 1] - rho_grid[j]);
+            r = ratio[ti][j] + f * (ratio[ti][j + 1] - ratio[ti][j]);
+        }
+        total += acc * r;
     }
     return total;
 }
 
 // Tile size of a quad scatter from the row loads of a ~1/64 sample of the feed (quad_sample_kernel): the largest
-// candidate (wave-steps per wave per tile) whose expected overflow per round stays well inside the spill list.
+// candidate (wave-steps per wave per tile) whose expected steady-state backlog stays well inside the spill list.
 // Returns kQuadsUseChunked (AUTO only) when a few rows hold more than 1.5 % of all items.
-static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, const int *candidates, size_t n_candidates,
-                             int *steps_out)
+static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
+                             size_t n_candidates, int *steps_out)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     const uint32_t sample_steps = 4;                                       // per wave: 32 KiB per workgroup
@@ -690,8 +719,8 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
     *steps_out = candidates[n_candidates - 1];
     for (size_t ci = 0; ci < n_candidates; ++ci) {
         const int c = candidates[ci];
-        for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * 8 * c;
-        if (quad_expected_overflow(mu, slots) <= 700.0) {                  // list: 2048 entries
+        for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * waves * c;
+        if (quad_expected_backlog(mu, slots) <= 1100.0) {                  // list: 2048 entries
             *steps_out = c;
             break;
         }
@@ -714,44 +743,42 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         HIPCHK(hipMemsetAsync(error, 0, 4 * sizeof(uint32_t), ctx->stream));
         ctx->quad_error_word = error;
     }
-    // ---- tile size.  A tile of 8 waves x STEPS wave-steps brings ~0.119 x 8 x STEPS items per 16-slot row at k = 12 when
-    // the k-mers are uniform; the row loads of a 1/64 sample say what THIS input brings.  The largest STEPS whose expected
-    // overflow per round stays well inside the spill list is used (KPAL_QUAD_STEPS forces one: A/B timing, tests).
+    // ---- tile size.  A tile of 16 waves x STEPS wave-steps brings ~0.119 x 16 x STEPS items per 16-slot row at k = 12 when
+    // the k-mers are uniform (7 steps: 13.3 of 16, records 83 % full, ~3 % of the items spill to the list); the row loads of a
+    // 1/64 sample say what THIS input brings.  The largest STEPS whose expected overflow per round stays well inside the
+    // spill list is used (KPAL_QUAD_STEPS forces one: A/B timing, tests).  16 waves = four per SIMD with 128 registers each
+    // (8 record vectors + 7 prefetched chunks live): measured 3 % faster than 8 waves x 13 steps and the records are fuller.
     static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
-    static const int candidates[] = {13, 12, 8, 6, 4, 3, 2};
+    static const int candidates[] = {7, 6, 4, 3, 2, 1};
+    constexpr int waves = 16;
     int steps = 0;
     for (int c : candidates)
         if (c == steps_env) steps = c;
-    if (steps_env == 14 || steps_env == 15 || steps_env == 16) steps = steps_env;   // (A/B only: larger tiles than the sample ever picks)
     if (!steps) {
-        const int rc = quad_choose_steps(ctx, s, load, buckets, slots, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
+        const int rc = quad_choose_steps(ctx, s, load, buckets, slots, waves, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
         if (rc != KPAL_OK) return rc;
     }
-    const uint64_t tile_steps = 8ull * steps;
+    const uint64_t tile_steps = (uint64_t)waves * steps;
     const uint64_t tiles = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cu, tiles);
     const uint64_t tpb = (tiles + G - 1) / G;          // tiles (= flush rounds) per workgroup
     if (tpb > 0xFFFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
     const size_t pool_bytes = (size_t)kQuadRowWords * 4 * G * tpb;   // every round writes all rows: 128 KiB per workgroup
-    if (pool_bytes > kQuadPoolMax && s.nchunks > 64) return kSplitBatch;   // (heavily skewed 16 GiB piece: small tiles)
+    if (pool_bytes > ctx->quad_pool_max && s.nchunks > 64) return kSplitBatch;   // (heavily skewed 16 GiB piece: small tiles)
     CHK(ensure(ctx, ctx->keys, pool_bytes));
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
-#define KPAL_QUAD_LAUNCH(S)                                                                                                \
-    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, S, S>), dim3(G), dim3(512), s, tpb, pool, (uint32_t)tpb, nrounds, \
+#define KPAL_QUAD_LAUNCH(S)                                                                                                  \
+    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, S>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
            error, table)
     DISPATCH_K_8_12(ctx->k, {
         switch (steps) {
-        case 16: KPAL_QUAD_LAUNCH(16); break;
-        case 15: KPAL_QUAD_LAUNCH(15); break;
-        case 14: KPAL_QUAD_LAUNCH(14); break;
-        case 13: KPAL_QUAD_LAUNCH(13); break;
-        case 8: KPAL_QUAD_LAUNCH(8); break;
-        case 6: KPAL_QUAD_LAUNCH(6); break;
+        case 7: KPAL_QUAD_LAUNCH(7); break;
         case 4: KPAL_QUAD_LAUNCH(4); break;
         case 3: KPAL_QUAD_LAUNCH(3); break;
         case 2: KPAL_QUAD_LAUNCH(2); break;
-        default: KPAL_QUAD_LAUNCH(12); break;
+        case 1: KPAL_QUAD_LAUNCH(1); break;
+        default: KPAL_QUAD_LAUNCH(6); break;
         }
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
                (const uint32_t *)nrounds, G, (uint32_t)tpb, table, (uint32_t *)nullptr);
@@ -785,16 +812,18 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
         HIPCHK(hipMemsetAsync(error, 0, 4 * sizeof(uint32_t), ctx->stream));
         ctx->quad_error_word = error;
     }
-    // level 1: 12 wave-steps per wave per tile bring 91 items per 128-slot row (22.8 per 32 at k = 16) for uniform
-    // k-mers; the sampled row loads say whether THIS feed needs half the tile, or (AUTO) the round-1 pipeline
+    // level 1: 16 waves x 7 wave-steps per tile bring 107 items per 128-slot row (26.7 per 32 at k = 16) for uniform
+    // k-mers; the sampled row loads say whether THIS feed needs a smaller tile, or (AUTO) the round-1 pipeline
     static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
-    int steps1 = steps_env == 6 ? 6 : (steps_env == 12 ? 12 : 0);
+    static const int candidates[] = {7, 6, 3};
+    int steps1 = 0;
+    for (int c : candidates)
+        if (c == steps_env) steps1 = c;
     if (!steps1) {
-        static const int candidates[] = {12, 6};
-        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, candidates, 2, &steps1);
+        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 3, &steps1);
         if (rc != KPAL_OK) return rc;
     }
-    const uint64_t tile_steps = 8ull * steps1;
+    const uint64_t tile_steps = 16ull * steps1;
     const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
     const uint64_t tpb1 = (tiles1 + G1 - 1) / G1;
@@ -803,7 +832,7 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     // number of KiB -- a wave-step of quad2_scatter_kernel then never straddles two units
     const uint64_t per_kib = 1024 / (S1 * 4);                                   // records per KiB: 2 (8 at k = 16)
     const uint64_t cap1 = (tpb1 + per_kib - 1) / per_kib * per_kib;
-    if ((size_t)kQuadRowWords * 4 * G1 * cap1 > kQuadPoolMax && s.nchunks > 64) return kSplitBatch;
+    if ((size_t)kQuadRowWords * 4 * G1 * cap1 > ctx->quad_pool_max && s.nchunks > 64) return kSplitBatch;
     CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * cap1));
     uint32_t *pool1 = (uint32_t *)ctx->residuals.p;
     // level 2: ~4 workgroups per CU in total; workgroup (g2, c) takes `upw` of the REP x G1 units of coarse bucket c
@@ -813,29 +842,31 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     G2 = (units + upw - 1) / upw;
     const uint64_t unit_cap = cap1 * S1 * 4;                                   // bytes
     if ((uint64_t)upw * unit_cap >= (1ull << 32)) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
-    constexpr int kSteps2 = 16;
-    const uint64_t tile2_bytes = 8ull * kSteps2 * 1024;
+    constexpr int kWaves2 = 16, kSteps2 = 8;                                   // 128 KiB of level-1 records per tile
+    const uint64_t tile2_bytes = (uint64_t)kWaves2 * kSteps2 * 1024;
     const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
     CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
-    // the staged forms of the histogram stage (16 bytes per table entry: 17 GB at k = 15) reuse the level-1 pool's buffer:
+    // the staged forms of the histogram stage (four 16-bit counts per table entry: 8.6 GB at k = 15) reuse the level-1 pool's buffer:
     // level 2 has read it completely before the histogram kernel starts (same stream)
-    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 16)));
+    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 8)));
     pool1 = (uint32_t *)ctx->residuals.p;
     uint32_t *stage = pool1;
     uint32_t *pool2 = (uint32_t *)ctx->keys.p;
     uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {
-        if (steps1 == 6)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 6, 6>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        if (steps1 == 7)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        else if (steps1 == 6)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 8, 12, 12>), dim3(G1), dim3(512), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
-        LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kSteps2>), dim3(G2, NB1), dim3(512), (const uint32_t *)pool1,
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, kSteps2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1,
                (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
                G2, (uint32_t)tiles2, table, stage);
-        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 1024)), dim3(256), (const uint32_t *)stage, table);
+        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 1024)), dim3(256), (const uint16_t *)stage, table);
     });
     return KPAL_OK;
 }

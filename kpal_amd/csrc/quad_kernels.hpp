@@ -53,6 +53,13 @@ struct QuadCfg {
     static constexpr int kFormBins = 1 << kLowBits;
     static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16, 64; 128, 32
     static constexpr int kRecordBytes = kSlots * 4;
+    // 64-byte records (k = 12): rows 2j and 2j+1 share a 128-byte line of the pool -- pool[row / 2][workgroup][round][row % 2] --
+    // so that a flush writes whole lines (the two records of a line leave in the same store instruction)
+#if defined(KPAL_QUAD_NO_PAIR)   // A/B builds
+    static constexpr bool kPairRows = false;
+#else
+    static constexpr bool kPairRows = !kTwoLevel && kRecordBytes == 64;
+#endif
     static constexpr int kScrBits = (kLowBits - 6) < 4 ? (kLowBits - 6) : 4;   // bits of the low field that scramble the bucket
     static constexpr uint64_t kXMask = (1ull << (2 * K + 6)) - 1ull;            // the (K+3)-mer: at most 38 bits
     static constexpr uint32_t kLowMask = (1u << kLowBits) - 1u;
@@ -338,7 +345,8 @@ __device__ __forceinline__ uint4 fetch_wave_step(const Span &s, uint64_t step, u
 // the wave index is read with readfirstlane (tile / step numbers, the edge tests of encode_step and the load
 // addresses become SALU work; a load is saddr + lane * 16), and a record store is a scalar base (row group, workgroup,
 // round) + one per-thread 32-bit offset fixed for the whole kernel.
-// pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots.
+// pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots
+// (k = 12, kPairRows: (((row / 2) * G + g) * rounds_cap + round) * 32 + (row % 2) * 16).
 template <int K, int WAVES, int STEPS, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
                                                                   uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     constexpr int kQuadTileSteps = WAVES * STEPS;
     constexpr int CARRY = kQuadSpillCap / THREADS;      // carried items per thread
     constexpr uint32_t CAP = CARRY * THREADS;           // spill list entries in use
-    static_assert(WAVES == 8 && STEPS % DEPTH == 0, "tile shape");
+    static_assert((WAVES == 8 || WAVES == 16) && STEPS % DEPTH == 0, "tile shape");
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
     __shared__ __attribute__((aligned(16))) uint32_t pos[NB];   // BYTES in use per row
     __shared__ QuadSpill spill[kQuadSpillCap];
@@ -395,12 +403,15 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     bool have_rec = false;                      // block-uniform
     // vector t + i * THREADS is vector t % LPR of row t / LPR + i * (THREADS / LPR): the thread's part of the address
     // (32 bits: the host keeps a pool below 64 GiB) never changes, the rest is scalar
-    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap * (uint64_t)(S * 4);
-    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / LPR) * row_bytes) + (threadIdx.x % LPR) * 16u;
+    // (kPairRows: a "row" of the address arithmetic is a PAIR of rows with 128-byte records)
+    constexpr int PAIR = C::kPairRows ? 2 : 1;
+    static_assert((THREADS / LPR) % PAIR == 0, "row pairs are written by one instruction");
+    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap * (uint64_t)(S * 4 * PAIR);
+    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / (LPR * PAIR)) * row_bytes) + (threadIdx.x % (LPR * PAIR)) * 16u;
     auto store_rec = [&](int i) {
         uint32_t o = thread_off;
         asm volatile("" : "+v"(o));             // (no FI hoisted 64-bit addresses)
-        const uint64_t sc = (uint64_t)(i * (THREADS / LPR)) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap + (round - 1u)) * (uint64_t)(S * 4);
+        const uint64_t sc = (uint64_t)(i * (THREADS / (LPR * PAIR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap + (round - 1u)) * (uint64_t)(S * 4 * PAIR);
 #if defined(KPAL_QUAD_NT)   // A/B builds: non-temporal record stores
         uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(pool) + sc + o);
         __builtin_nontemporal_store(rec[i].x, q);
@@ -516,8 +527,8 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 // level-1 workgroup u % G1) is the run of nrounds1[u % G1] records that workgroup wrote for that row.  The units
 // are addressed as one stream of `unit_cap` bytes each (records never written read as null items): a wave-step is
 // 1 KiB of it, four items per lane -- the shape of the ASCII path, so the tile loop is the same.
-template <int K, int STEPS>
-__global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__restrict__ pool1, const uint32_t *__restrict__ nrounds1,
+template <int K, int WAVES, int STEPS>
+__global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_t *__restrict__ pool1, const uint32_t *__restrict__ nrounds1,
                                                             uint32_t G1, uint32_t rounds_cap1, uint32_t upw, uint32_t tiles_per_block,
                                                             uint32_t *__restrict__ pool2, uint32_t rounds_cap2,
                                                             uint32_t *__restrict__ nrounds2, uint32_t *__restrict__ error,
@@ -526,7 +537,8 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
     using C1 = QuadCfg<K>;
     using C = QuadCfg<11>;                      // rows of level 2: 512 x 64 slots, items of 23 bits
     constexpr int S = C::kSlots, NB = C::kBuckets, S1 = C1::kSlots;
-    constexpr int WAVES = 8, THREADS = 512;
+    constexpr int THREADS = WAVES * 64;
+    static_assert(WAVES == 8 || WAVES == 16, "tile shape");
     constexpr int CARRY = kQuadSpillCap / THREADS;
     constexpr uint32_t CAP = CARRY * THREADS;
     __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
@@ -681,6 +693,24 @@ __global__ __launch_bounds__(512) void quad2_scatter_kernel(const uint32_t *__re
     }
 }
 
+// Table entry of bin `local` of form i (the k-mer at position i of an item) in the histogram of scrambled row `row`
+// (of scrambled coarse bucket `coarse` on the two-level path): the bins of a form are table entries
+// hi << (B + s) | bucket << s | lo with s = L - 6 + 2i; the bucket is unscrambled with the top bits of lo.
+template <int K>
+__device__ __forceinline__ uint64_t quad_bin_index(uint32_t row, uint32_t coarse, int i, uint32_t local)
+{
+    using C = QuadCfg<K>;
+    const int sh = C::kLowBits - 6 + 2 * i;
+    const uint32_t lopart = local & ((1u << sh) - 1u);
+    const uint32_t hipart = local >> sh;
+    const uint32_t t = C::kScrBits > 0 ? (lopart >> (sh - C::kScrBits)) : 0u;
+    const uint32_t b = row ^ C::smask(t);
+    if constexpr (C::kTwoLevel)
+        return ((uint64_t)hipart << (C::kCoarseBits + 9 + sh)) | ((uint64_t)(coarse ^ C::smask1(t)) << (9 + sh)) | ((uint64_t)b << sh) | lopart;
+    else
+        return ((uint64_t)hipart << (C::kBucketBits + sh)) | ((uint64_t)b << sh) | lopart;
+}
+
 // Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
 // Same hot-key guard as part_hist_kernel: per form the wave counts the occurrences of its first lane's bin
 // with a ballot, those lanes add to private dummy words instead (64 adds to one LDS address serialise).
@@ -693,7 +723,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // k = 13..16: blockIdx.y is the (scrambled) coarse bucket, blockIdx.x the fine row of level 2 (512 rows of 64 slots)
     constexpr int L = C::kLowBits, BINS = C::kFormBins, S = C::kTwoLevel ? 64 : C::kSlots;
     __shared__ __attribute__((aligned(16))) uint32_t hist[4 * BINS + 64];
-    const uint32_t row = blockIdx.x, coarse = blockIdx.y;
+    // kPairRows: rows 2j and 2j+1 share every 128-byte line of their records.  Workgroups b and b + 8 are dispatched to
+    // the same XCD (round-robin over eight) at nearly the same time: they take such a pair, so the second reader of a
+    // line finds it in that XCD's L2 (or, drifting apart, in the memory-side cache).
+    const uint32_t row = C::kPairRows ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
+    const uint32_t coarse = blockIdx.y;
     const uint32_t row_linear = coarse * (C::kTwoLevel ? 512u : 0u) + row;
     nrounds += (size_t)coarse * G;
     for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
@@ -737,19 +771,27 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             if (q.w) add_item(q.w, std::false_type{});
         }
     };
-    for (uint32_t g = wave; g < G; g += 16) {   // wave-uniform
-        const uint4 *src = reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
+    // run g of the bucket = the records workgroup g of the scatter wrote for it.  With at least 16 runs a wave takes
+    // whole runs; with fewer (the two-level path at k = 15, 16: 4 runs, 1 run) 16 / G waves share a run, 256 vectors
+    // at a time each -- otherwise only G of the 16 waves would have loads in flight.
+    const uint32_t parts = G >= 16u ? 1u : 16u / G;            // waves per run
+    const uint32_t g_first = G >= 16u ? (uint32_t)wave : (uint32_t)wave % G;
+    const uint32_t part = G >= 16u ? 0u : (uint32_t)wave / G;
+    for (uint32_t g = g_first; g < G && part < parts; g += 16) {   // wave-uniform
+        const uint4 *src = C::kPairRows
+                               ? reinterpret_cast<const uint4 *>(pool + ((uint64_t)((row_linear >> 1) * G + g) * rounds_cap) * (2 * S) + (row_linear & 1u) * S)
+                               : reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
         // four 16-byte loads per lane in flight; the next four are requested before these are counted
         auto fetch = [&](uint32_t at) -> uint4 {   // (a select between src[at] and a zero constant becomes a flat load of a selected address)
             uint4 r = make_uint4(0u, 0u, 0u, 0u);
-            if (at < nvec) r = src[at];
+            if (at < nvec) r = src[C::kPairRows ? ((at >> 2) * 8u + (at & 3u)) : at];   // (pairs: the row's half of every 128-byte line)
             return r;
         };
-        uint32_t v = lane;
+        uint32_t v = part * 256u + lane;
         uint4 q0 = fetch(v), q1 = fetch(v + 64u), q2 = fetch(v + 128u), q3 = fetch(v + 192u);
         while (v < nvec) {
-            v += 256u;
+            v += parts * 256u;
             const uint4 n0 = fetch(v), n1 = fetch(v + 64u), n2 = fetch(v + 128u), n3 = fetch(v + 192u);
             add4(q0);
             add4(q1);
@@ -764,29 +806,33 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     __syncthreads();
     if (stage) {
         // two-level path: every table entry would receive four atomic adds (one per form, from four different
-        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are stored as they are instead -- one coalesced
-        // 128 KiB write per workgroup -- and quad2_combine_kernel gathers the four of every entry.
-        uint4 *dst = reinterpret_cast<uint4 *>(stage + (size_t)row_linear * (4 * BINS));
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(hist);
-        for (int i = threadIdx.x; i < BINS; i += blockDim.x) dst[i] = src4[i];
+        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are stored as they are instead, as 16-bit counts --
+        // one coalesced 64 KiB write per workgroup -- and quad2_combine_kernel gathers the four of every entry.  A
+        // count that does not fit 16 bits (a k-mer seen 65536 times in one batch within ONE of its four positions)
+        // goes to the table directly and is staged as zero.
+        uint16_t *dst = reinterpret_cast<uint16_t *>(stage) + (size_t)row_linear * (4 * BINS);
+        for (int i = threadIdx.x; i < 4 * BINS / 8; i += blockDim.x) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(&hist[8 * i]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(&hist[8 * i + 4]);
+            uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c[e] >> 16) {
+                        const uint32_t bin = 8u * (uint32_t)i + (uint32_t)e;
+                        atomicAdd(&table[quad_bin_index<K>(row, coarse, (int)(bin / BINS), bin % BINS)], (unsigned long long)c[e]);
+                        c[e] = 0;
+                    }
+            }
+            *reinterpret_cast<uint4 *>(dst + 8 * i) = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+        }
         return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int sh = L - 6 + 2 * i;
         for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
             const uint32_t c = hist[i * BINS + local];
-            if (!c) continue;
-            const uint32_t lopart = (uint32_t)local & ((1u << sh) - 1u);
-            const uint32_t hipart = (uint32_t)local >> sh;
-            const uint32_t t = C::kScrBits > 0 ? (lopart >> (sh - C::kScrBits)) : 0u;
-            const uint32_t b = row ^ C::smask(t);
-            uint64_t idx;
-            if constexpr (C::kTwoLevel)
-                idx = ((uint64_t)hipart << (C::kCoarseBits + 9 + sh)) | ((uint64_t)(coarse ^ C::smask1(t)) << (9 + sh)) | ((uint64_t)b << sh) | lopart;
-            else
-                idx = ((uint64_t)hipart << (C::kBucketBits + sh)) | ((uint64_t)b << sh) | lopart;
-            atomicAdd(&table[idx], (unsigned long long)c);
+            if (c) atomicAdd(&table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
         }
     }
 }
@@ -795,7 +841,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 // histogram of (scrambled) bucket (coarse ^ smask1(t), fine ^ smask(t)) at local = hi << s | lo, s = 7 + 2i, where
 // lo = idx's low s bits, t = lo's top four bits, fine / coarse / hi the fields above.  Exclusive per entry: plain adds.
 template <int K>
-__global__ __launch_bounds__(256) void quad2_combine_kernel(const uint32_t *__restrict__ stage, unsigned long long *__restrict__ table)
+__global__ __launch_bounds__(256) void quad2_combine_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
 {
     using C = QuadCfg<K>;
 #pragma unroll
@@ -811,7 +857,7 @@ __global__ __launch_bounds__(256) void quad2_combine_kernel(const uint32_t *__re
             const uint32_t hipart = (uint32_t)(idx >> (sh + 9 + C::kCoarseBits));
             const uint32_t t = lopart >> (sh - 4);
             const uint32_t row_linear = (coarse ^ C::smask1(t)) * 512u + (fine ^ C::smask(t));
-            sum += stage[((size_t)row_linear * 4 + i) * 8192 + ((hipart << sh) | lopart)];
+            sum += (uint32_t)stage[((size_t)row_linear * 4 + i) * 8192 + ((hipart << sh) | lopart)];
         }
         if (sum) table[idx] += (unsigned long long)sum;
     }

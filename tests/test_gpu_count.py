@@ -209,6 +209,23 @@ def test_two_level_batch_halving():
     c2.close()
 
 
+def test_quad_pipelines_halve_an_oversized_piece():
+    """A piece whose record pool would pass the limit of the quad scatters' 32-bit record offsets is counted as two
+    halves, recursively (forced here by lowering the limit to 4 MiB); halo across the seams of the halves."""
+    from kpal_amd import _native
+    os.environ['KPAL_QUAD_POOL_MAX'] = str(4 << 20)
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_QUAD_POOL_MAX']
+    buf = oracle.synth_reads(59, 0, 120000, 150, noisy=True)            # 18 MB: pool ~21 MiB -> several halvings
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    for k, strategy in ((12, 'partition_quads'), (9, 'partition_quads'), (13, 'partition2_quads'), (15, 'partition2_quads')):
+        for data in (buf, seq):
+            assert np.array_equal(c2.count_bytes(k, data, strategy), oracle.count_flat(data, k, threads=8)), (k, strategy)
+    c2.close()
+
+
 @pytest.mark.parametrize('mode', ['0', '1', '2'])
 def test_two_level_variants_of_level2(mode):
     """The three level-2 pipelines of the two-level path (KPAL_LEVEL2: 0 count + exact offsets, 1 chunked
