@@ -630,6 +630,7 @@ static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
     return KPAL_OK;
 }
 
+constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
 constexpr int kQuadsUseChunked = 2;   // launch_partition_quads (AUTO): the sample shows a feed for the chunked pipeline
 constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
 
@@ -699,6 +700,7 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
     const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
     // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
     // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
+    static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
     std::vector<double> per_step((size_t)buckets);
     for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
     std::sort(per_step.begin(), per_step.end());
@@ -712,7 +714,16 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
         const double median = per_step[(size_t)buckets / 2];
         for (int b = 0; b < buckets; ++b) all += per_step[b];
         for (int b = buckets - 32; b < buckets; ++b) hot += std::max(0.0, per_step[b] - median);
-        if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all) return kQuadsUseChunked;
+        // ... unless nearly all of that excess sits in one to three rows (a homopolymer run, a two-letter repeat): then a
+        // wave's hot items are all the same, one ballot round counts them into the workgroup's hot-item table, and the
+        // quad path is the faster one (homopolymer feed: 520 vs 230 Gbases/s).  A shared prefix spreads over a dozen rows.
+        double top3 = 0.0;
+        for (int b = buckets - 3; b < buckets; ++b) top3 += std::max(0.0, per_step[b] - median);
+        const bool concentrated = top3 >= 0.8 * hot;
+        if (verbose)
+            fprintf(stderr, "[kpal quad] sample: %.2f %% of the items are the excess of the 32 fullest rows, %.0f %% of it in three rows\n",
+                    all > 0.0 ? 100.0 * hot / all : 0.0, hot > 0.0 ? 100.0 * top3 / hot : 0.0);
+        if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all && !concentrated) return kQuadsUseChunked;
     }
     per_step.resize((size_t)buckets - 32);
     std::vector<double> mu(per_step.size());
@@ -720,7 +731,9 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
     for (size_t ci = 0; ci < n_candidates; ++ci) {
         const int c = candidates[ci];
         for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * waves * c;
-        if (quad_expected_backlog(mu, slots) <= 1100.0) {                  // list: 2048 entries
+        const double backlog = quad_expected_backlog(mu, slots);
+        if (verbose) fprintf(stderr, "[kpal quad] sample: %d steps per wave -> expected backlog %.0f items (fullest row %.1f of %d)\n", c, backlog, mu.back(), slots);
+        if (backlog <= kQuadBacklogMax) {                                  // list: 2048 entries
             *steps_out = c;
             break;
         }
