@@ -747,7 +747,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    const int buckets = ctx->k == 12 ? 2048 : 512, slots = kQuadRowWords / buckets;
+    const int buckets = ctx->k == 12 ? QuadCfg<12>::kBuckets : 512, slots = kQuadRowWords / buckets;   // ROWS of the scatter
     CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048) * sizeof(uint32_t)));
     uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
     uint32_t *error = nrounds + ctx->num_cu;
@@ -762,7 +762,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // spill list is used (KPAL_QUAD_STEPS forces one: A/B timing, tests).  16 waves = four per SIMD with 128 registers each
     // (8 record vectors + 7 prefetched chunks live): measured 3 % faster than 8 waves x 13 steps and the records are fuller.
     static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
-    static const int candidates[] = {7, 6, 4, 3, 2, 1};
+    static const int candidates[] = {8, 7, 6, 4, 3, 2, 1};
     constexpr int waves = 16;
     int steps = 0;
     for (int c : candidates)
@@ -786,6 +786,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
            error, table)
     DISPATCH_K_8_12(ctx->k, {
         switch (steps) {
+        case 8: KPAL_QUAD_LAUNCH(8); break;
         case 7: KPAL_QUAD_LAUNCH(7); break;
         case 4: KPAL_QUAD_LAUNCH(4); break;
         case 3: KPAL_QUAD_LAUNCH(3); break;
@@ -793,7 +794,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         case 1: KPAL_QUAD_LAUNCH(1); break;
         default: KPAL_QUAD_LAUNCH(6); break;
         }
-        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kBuckets), dim3(1024), (const uint32_t *)pool,
+        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kHistBuckets), dim3(1024), (const uint32_t *)pool,
                (const uint32_t *)nrounds, G, (uint32_t)tpb, table, (uint32_t *)nullptr);
     });
 #undef KPAL_QUAD_LAUNCH
@@ -828,12 +829,12 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     // level 1: 16 waves x 7 wave-steps per tile bring 107 items per 128-slot row (26.7 per 32 at k = 16) for uniform
     // k-mers; the sampled row loads say whether THIS feed needs a smaller tile, or (AUTO) the round-1 pipeline
     static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
-    static const int candidates[] = {7, 6, 3};
+    static const int candidates[] = {8, 7, 6, 3};
     int steps1 = 0;
     for (int c : candidates)
         if (c == steps_env) steps1 = c;
     if (!steps1) {
-        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 3, &steps1);
+        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 4, &steps1);
         if (rc != KPAL_OK) return rc;
     }
     const uint64_t tile_steps = 16ull * steps1;
@@ -869,7 +870,9 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {
-        if (steps1 == 7)
+        if (steps1 == 8)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        else if (steps1 == 7)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else if (steps1 == 6)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
@@ -879,7 +882,7 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
                (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
                G2, (uint32_t)tiles2, table, stage);
-        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 1024)), dim3(256), (const uint16_t *)stage, table);
+        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 2048)), dim3(256), (const uint16_t *)stage, table);
     });
     return KPAL_OK;
 }

@@ -48,6 +48,7 @@ struct QuadCfg {
     static constexpr int kCoarse = 1 << kCoarseBits;
     static constexpr int kRep = kTwoLevel ? (kCoarse >= 256 ? 1 : 256 / kCoarse) : 1;   // 16, 4, 1, 1
     static constexpr int kBucketBits = kTwoLevel ? 9 : (K == 12 ? 11 : 9);  // (fine) bucket bits of the histogram stage
+    static constexpr int kHistBuckets = 1 << kBucketBits;
     static constexpr int kBuckets = kTwoLevel ? kCoarse * kRep : (1 << kBucketBits);   // ROWS of the scatter
     static constexpr int kLowBits = kTwoLevel ? 13 : 2 * K - kBucketBits;   // L: 13, 13, 11, 9, 7 (k = 12 .. 8); 13
     static constexpr int kFormBins = 1 << kLowBits;
@@ -55,6 +56,9 @@ struct QuadCfg {
     static constexpr int kRecordBytes = kSlots * 4;
     // 64-byte records (k = 12): rows 2j and 2j+1 share a 128-byte line of the pool -- pool[row / 2][workgroup][round][row % 2] --
     // so that a flush writes whole lines (the two records of a line leave in the same store instruction)
+    // (Tried instead: 1024 rows of 32 slots with the dropped bucket bit kept in the item -- fuller records, 128-byte
+    // records by construction; the scatter gained nothing and the histogram, parsing every item twice, went from 4.0 to
+    // 6.0 ms.)
 #if defined(KPAL_QUAD_NO_PAIR)   // A/B builds
     static constexpr bool kPairRows = false;
 #else
@@ -69,7 +73,8 @@ struct QuadCfg {
         return kScrBits > 0 ? (((t << (kBucketBits - kScrBits)) | t) & (uint32_t)((1 << kBucketBits) - 1)) : 0u;
     }
     // the same for the coarse bucket of the two-level path
-    __host__ __device__ static constexpr uint32_t smask1(uint32_t t) { return ((t << (kCoarseBits - 4)) | t) & (uint32_t)(kCoarse - 1); }
+    // (XOR, not OR: at k = 14 the two copies of t overlap, and quad2_combine_kernel relies on smask1(a) ^ smask1(b) = smask1(a ^ b))
+    __host__ __device__ static constexpr uint32_t smask1(uint32_t t) { return (kCoarseBits > 4 ? ((t << (kCoarseBits - 4)) ^ t) : t) & (uint32_t)(kCoarse - 1); }
 };
 
 // item = hi6 << (L+4) | low << 4 | mask4 (mask bit 3 = oldest k-mer).  0 = null item.
@@ -840,21 +845,41 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 // Q4 (k = 13..16): table[idx] += the four staged form counts of entry idx.  Form i of entry idx lives in the staged
 // histogram of (scrambled) bucket (coarse ^ smask1(t), fine ^ smask(t)) at local = hi << s | lo, s = 7 + 2i, where
 // lo = idx's low s bits, t = lo's top four bits, fine / coarse / hi the fields above.  Exclusive per entry: plain adds.
+//   Read as they lie, the form-0 counts of consecutive entries come in pieces of 8 (16 bytes: t changes every eight
+// entries and sends the next piece to another bucket's histogram, megabytes away) -- 1.7 x the bytes at k = 15 (PMC), 4 x
+// the time at k = 16.  So a workgroup takes a set of entries that is CLOSED under the scrambling: for one hi field of
+// form 0 and one orbit {(c0 ^ smask1(m), f0 ^ smask(m)), m = 0..15} of (coarse, fine) pairs, the 16 runs of 128
+// entries.  Their form-0 counts are the 16 complete 128-bin runs of the orbit's histograms (run j, entry l sits in
+// member j ^ (l >> 3)): read coalesced into LDS, picked from there.  Forms 1..3 come in pieces of 64 bytes or more and
+// are read directly; the table is updated in runs of 1 KiB.
 template <int K>
 __global__ __launch_bounds__(256) void quad2_combine_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
 {
     using C = QuadCfg<K>;
+    constexpr int CB = C::kCoarseBits;
+    __shared__ __attribute__((aligned(16))) uint16_t form0[16][128];
+    const uint32_t g = blockIdx.x;
+    const uint32_t hi0 = g >> (CB + 5), c0 = (g >> 5) & (uint32_t)(C::kCoarse - 1), f0 = (g & 31u) << 4;   // the orbit's member with fine & 15 == 0
+    {
+        const uint32_t m = threadIdx.x >> 4, part = threadIdx.x & 15u;
+        const uint32_t row_linear = (c0 ^ C::smask1(m)) * 512u + (f0 ^ C::smask(m));
+        *reinterpret_cast<uint4 *>(&form0[m][8 * part]) =
+            *reinterpret_cast<const uint4 *>(stage + ((size_t)row_linear * 4 + 0) * 8192 + ((size_t)hi0 << 7) + 8 * part);
+    }
+    __syncthreads();
+    const uint32_t l = threadIdx.x & 127u;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {   // four runs of 256 entries per workgroup (4^16 entries: the grid stays below 2^32 threads)
-        const uint64_t idx = ((uint64_t)blockIdx.x * 4 + e) * 256 + threadIdx.x;
-        uint32_t sum = 0;
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t j = (threadIdx.x >> 7) + 2u * (uint32_t)r;
+        const uint64_t idx = ((uint64_t)hi0 << (16 + CB)) | ((uint64_t)(c0 ^ C::smask1(j)) << 16) | ((uint64_t)(f0 ^ C::smask(j)) << 7) | l;
+        uint32_t sum = form0[j ^ (l >> 3)][l];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 1; i < 4; ++i) {
             const int sh = 7 + 2 * i;
             const uint32_t lopart = (uint32_t)idx & ((1u << sh) - 1u);
             const uint32_t fine = (uint32_t)(idx >> sh) & 511u;
             const uint32_t coarse = (uint32_t)(idx >> (sh + 9)) & (uint32_t)(C::kCoarse - 1);
-            const uint32_t hipart = (uint32_t)(idx >> (sh + 9 + C::kCoarseBits));
+            const uint32_t hipart = (uint32_t)(idx >> (sh + 9 + CB));
             const uint32_t t = lopart >> (sh - 4);
             const uint32_t row_linear = (coarse ^ C::smask1(t)) * 512u + (fine ^ C::smask(t));
             sum += (uint32_t)stage[((size_t)row_linear * 4 + i) * 8192 + ((hipart << sh) | lopart)];
