@@ -685,24 +685,31 @@ static double quad_expected_backlog(const std::vector<double> &mu, int slots)
 // candidate (wave-steps per wave per tile) whose expected steady-state backlog stays well inside the spill list.
 // Returns kQuadsUseChunked (AUTO only) when a few rows hold more than 1.5 % of all items.
 static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
-                             size_t n_candidates, int *steps_out)
+                             size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr)
 {
+    const int extra = fine_per_step ? 512 : 0;   // (two-level path: the sample also returns the loads of the 512 fine rows)
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     const uint32_t sample_steps = 4;                                       // per wave: 32 KiB per workgroup
     const uint64_t want = std::max<uint64_t>(1, total_steps / (64ull * 8 * sample_steps));   // ~1/64 of the input
     const uint32_t groups = (uint32_t)std::min<uint64_t>(want, 1024);
     const uint64_t stride = std::max<uint64_t>(8 * sample_steps, total_steps / groups);
-    HIPCHK(hipMemsetAsync(load, 0, (size_t)buckets * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(load, 0, (size_t)(buckets + extra) * sizeof(uint32_t), ctx->stream));
     DISPATCH_K_8_16(ctx->k, LAUNCH(ctx, "quad_sample", (quad_sample_kernel<K>), dim3(groups), dim3(512), s, stride, sample_steps, load));
-    std::vector<uint32_t> h((size_t)buckets);
+    std::vector<uint32_t> h((size_t)(buckets + extra));
     HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
     // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
     // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
     static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
+    double budget = kQuadBacklogMax;
     std::vector<double> per_step((size_t)buckets);
     for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
+    if (fine_per_step) {
+        fine_per_step->resize(512);
+        for (int b = 0; b < 512; ++b) (*fine_per_step)[b] = h[(size_t)buckets + b] / sampled_steps;
+        std::sort(fine_per_step->begin(), fine_per_step->end());
+    }
     std::sort(per_step.begin(), per_step.end());
     // When those hot rows hold more than 1.5 % of all items (reads that share an adapter / primer prefix, several
     // per cent of low-complexity reads) the slow path of the scatter would run in nearly every placement step --
@@ -724,6 +731,9 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
             fprintf(stderr, "[kpal quad] sample: %.2f %% of the items are the excess of the 32 fullest rows, %.0f %% of it in three rows\n",
                     all > 0.0 ? 100.0 * hot / all : 0.0, hot > 0.0 ? 100.0 * top3 / hot : 0.0);
         if (ctx->strategy == KPAL_STRATEGY_AUTO && all > 0.0 && hot > 0.015 * all && !concentrated) return kQuadsUseChunked;
+        // hot rows fill the spill list first (their excess is carried every round before it is counted directly): the
+        // ordinary rows then get a quarter of the list (k = 13, 2 % low-complexity reads: level 1 0.55 instead of 2.9 ms)
+        if (all > 0.0 && hot > 0.003 * all) budget = kQuadBacklogMax / 4;
     }
     per_step.resize((size_t)buckets - 32);
     std::vector<double> mu(per_step.size());
@@ -733,7 +743,7 @@ static int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int b
         for (size_t b = 0; b < mu.size(); ++b) mu[b] = per_step[b] * waves * c;
         const double backlog = quad_expected_backlog(mu, slots);
         if (verbose) fprintf(stderr, "[kpal quad] sample: %d steps per wave -> expected backlog %.0f items (fullest row %.1f of %d)\n", c, backlog, mu.back(), slots);
-        if (backlog <= kQuadBacklogMax) {                                  // list: 2048 entries
+        if (backlog <= budget) {                                           // list: 2048 entries
             *steps_out = c;
             break;
         }
@@ -748,7 +758,7 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
     const int buckets = ctx->k == 12 ? QuadCfg<12>::kBuckets : 512, slots = kQuadRowWords / buckets;   // ROWS of the scatter
-    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048) * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048 + 512) * sizeof(uint32_t)));
     uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
     uint32_t *error = nrounds + ctx->num_cu;
     uint32_t *load = error + 4;
@@ -819,7 +829,7 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     const uint32_t NB1 = 1u << (2 * K - 22);
     const uint32_t REP = NB1 >= 256 ? 1u : 256u / NB1;
     const uint32_t S1 = (uint32_t)kQuadRowWords / (NB1 * REP);
-    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048) * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048 + 512) * sizeof(uint32_t)));
     uint32_t *nrounds1 = (uint32_t *)ctx->quad_meta.p;
     uint32_t *error = nrounds1 + ctx->num_cu;
     if (!ctx->quad_error_word) {
@@ -833,9 +843,12 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     int steps1 = 0;
     for (int c : candidates)
         if (c == steps_env) steps1 = c;
-    if (!steps1) {
-        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 4, &steps1);
+    std::vector<double> fine;                    // items per fine row of level 2 per wave-step of INPUT (sorted)
+    {
+        int chosen = 0;
+        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 4, &chosen, &fine);
         if (rc != KPAL_OK) return rc;
+        if (!steps1) steps1 = chosen;
     }
     const uint64_t tile_steps = 16ull * steps1;
     const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
@@ -856,8 +869,29 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     G2 = (units + upw - 1) / upw;
     const uint64_t unit_cap = cap1 * S1 * 4;                                   // bytes
     if ((uint64_t)upw * unit_cap >= (1ull << 32)) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
-    constexpr int kWaves2 = 16, kSteps2 = 8;                                   // 128 KiB of level-1 records per tile
-    const uint64_t tile2_bytes = (uint64_t)kWaves2 * kSteps2 * 1024;
+    // level-2 tile: 16 waves x steps2 KiB of level-1 records.  A wave-step of records holds 256 item slots, filled to
+    // f1 = (items of a level-1 tile) / 32768; a fine row (512 rows of 64 slots) receives its share of them.  Same queue
+    // model as level 1 (the 32 fullest fine rows are left to the spill list and the hot-item table).
+    constexpr int kWaves2 = 16;
+    static const int steps2_env = [] { const char *e = getenv("KPAL_QUAD_STEPS2"); return e ? atoi(e) : 0; }();
+    int steps2 = 2;
+    {
+        double all = 0.0;
+        for (double v : fine) all += v;
+        const double f1 = std::min(1.0, all * 16.0 * steps1 / (double)kQuadRowWords);
+        static const int candidates2[] = {8, 7, 6, 4, 3, 2};
+        std::vector<double> mu(fine.size() > 32 ? fine.size() - 32 : 0);
+        for (int c : candidates2) {
+            for (size_t b = 0; b < mu.size(); ++b) mu[b] = all > 0.0 ? fine[b] / all * (256.0 * f1) * kWaves2 * c : 0.0;
+            if (quad_expected_backlog(mu, 64) <= kQuadBacklogMax) {
+                steps2 = c;
+                break;
+            }
+        }
+        for (int c : candidates2)
+            if (c == steps2_env) steps2 = c;
+    }
+    const uint64_t tile2_bytes = (uint64_t)kWaves2 * steps2 * 1024;
     const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
     CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
@@ -869,6 +903,9 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     uint32_t *pool2 = (uint32_t *)ctx->keys.p;
     uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
+#define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
+    LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
+           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table)
     DISPATCH_K_13_16(ctx->k, {
         if (steps1 == 8)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
@@ -878,12 +915,20 @@ static int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
-        LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, kSteps2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1,
-               (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table);
+        switch (steps2) {
+        case 8: KPAL_QUAD2_LAUNCH(8); break;
+        case 7: KPAL_QUAD2_LAUNCH(7); break;
+        case 6: KPAL_QUAD2_LAUNCH(6); break;
+        case 4: KPAL_QUAD2_LAUNCH(4); break;
+        case 3: KPAL_QUAD2_LAUNCH(3); break;
+        default: KPAL_QUAD2_LAUNCH(2); break;
+        }
+
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
                G2, (uint32_t)tiles2, table, stage);
         LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 2048)), dim3(256), (const uint16_t *)stage, table);
     });
+#undef KPAL_QUAD2_LAUNCH
     return KPAL_OK;
 }
 

@@ -296,8 +296,10 @@ template <int K>
 __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t stride_steps, uint32_t steps, uint32_t *__restrict__ load)
 {
     using C = QuadCfg<K>;
-    __shared__ uint32_t cnt[C::kBuckets];
-    for (int i = threadIdx.x; i < C::kBuckets; i += blockDim.x) cnt[i] = 0;
+    // two-level path: load[kBuckets ..] also receives the loads of the 512 FINE rows of level 2 (over all coarse buckets)
+    constexpr int NFINE = C::kTwoLevel ? 512 : 0;
+    __shared__ uint32_t cnt[C::kBuckets + NFINE];
+    for (int i = threadIdx.x; i < C::kBuckets + NFINE; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const uint64_t total_steps = (s.nchunks + 63) / 64;
@@ -314,11 +316,15 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
                 uint32_t row, item;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, threadIdx.x & 63u, row, item);
                 atomicAdd(&cnt[row], (item & 15u) ? 1u : 0u);
+                if constexpr (C::kTwoLevel) {   // the row quad2_scatter_kernel gives the item
+                    const uint32_t fine_row = ((item >> 17) & 511u) ^ QuadCfg<11>::smask(((item >> 4) & 8191u) >> 9);
+                    atomicAdd(&cnt[C::kBuckets + fine_row], (item & 15u) ? 1u : 0u);
+                }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C::kBuckets; i += blockDim.x)
+    for (int i = threadIdx.x; i < C::kBuckets + NFINE; i += blockDim.x)
         if (cnt[i]) atomicAdd(&load[i], cnt[i]);
 }
 
