@@ -649,7 +649,7 @@ static double quad_expected_backlog(const std::vector<double> &mu, int slots)
         {1.00, 1.01, 1.08, 1.17, 1.33, 1.65, 2.34, 3.05, 4.52, 8.9},    // 32
         {1.00, 1.00, 1.01, 1.04, 1.12, 1.30, 1.75, 2.24, 3.25, 6.35},   // 64
         {1.00, 1.00, 1.00, 1.02, 1.02, 1.10, 1.36, 1.68, 2.37, 4.55}};  // 128
-    const int ti = slots <= 16 ? 0 : (slots <= 32 ? 1 : (slots <= 64 ? 2 : 3));
+    const int ti = slots <= 24 ? 0 : (slots <= 32 ? 1 : (slots <= 64 ? 2 : 3));   // (20 slots: the 16-slot row of the table, on the safe side)
     double total = 0.0;
     for (double m : mu) {
         if (m <= 0.0) continue;
@@ -757,7 +757,8 @@ static int launch_partition_quads(kpal_ctx *ctx, const Span &s)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
-    const int buckets = ctx->k == 12 ? QuadCfg<12>::kBuckets : 512, slots = kQuadRowWords / buckets;   // ROWS of the scatter
+    const int buckets = ctx->k == 12 ? QuadCfg<12>::kBuckets : 512;                                     // ROWS of the scatter
+    const int slots = ctx->k == 12 ? QuadCfg<12>::kItems : kQuadRowWords / buckets;                     // items a row holds
     CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048 + 512) * sizeof(uint32_t)));
     uint32_t *nrounds = (uint32_t *)ctx->quad_meta.p;
     uint32_t *error = nrounds + ctx->num_cu;

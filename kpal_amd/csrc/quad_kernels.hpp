@@ -54,6 +54,17 @@ struct QuadCfg {
     static constexpr int kFormBins = 1 << kLowBits;
     static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16, 64; 128, 32
     static constexpr int kRecordBytes = kSlots * 4;
+    // k = 12: an item needs 23 bits (hi6 | low13 | mask4), so it is stored in THREE bytes, five to a 16-byte vector
+    // (15 bytes + one of padding: no item straddles the vectors the flush and the histogram work with) -- a 64-byte
+    // record holds 20 items instead of 16, a tile of 128 wave-steps fills it to 74 %, and the record pool shrinks from
+    // 1.33 to 1.0 bytes per input byte (written once, read once).  The cost: three ds_write_b8 per item instead of one
+    // ds_write_b32 and two more address instructions.
+#if defined(KPAL_QUAD_ITEM4)   // A/B builds
+    static constexpr bool kItem3 = false;
+#else
+    static constexpr bool kItem3 = !kTwoLevel && K == 12;
+#endif
+    static constexpr int kItems = kItem3 ? (kSlots / 4) * 5 : kSlots;   // items a row / record holds
     // 64-byte records (k = 12): rows 2j and 2j+1 share a 128-byte line of the pool -- pool[row / 2][workgroup][round][row % 2] --
     // so that a flush writes whole lines (the two records of a line leave in the same store instruction)
     // (Tried instead: 1024 rows of 32 slots with the dropped bucket bit kept in the item -- fuller records, 128-byte
@@ -199,6 +210,15 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
     }
 }
 
+// a * C for a < 2^24 as one full-rate v_mul_u32_u24 (written as a product the compiler picks the quarter-rate v_mul_lo_u32)
+template <int C>
+__device__ __forceinline__ uint32_t mul24_const(uint32_t a)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "n"(C), "v"(a));
+    return r;
+}
+
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
 // the row (the atomic returns the item's byte offset: one shift-add gives its LDS address).
 template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4>
@@ -208,17 +228,29 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 {
     using C = typename std::conditional<LEVEL == 2, QuadCfg<11>, QuadCfg<K>>::type;   // level 2: 512 rows x 64 slots
     constexpr uint32_t RB = (uint32_t)C::kSlots * 4u;                                  // bytes per row
+    constexpr bool ITEM3 = LEVEL == 1 && C::kItem3;                                    // pos[] counts ITEMS, three bytes each
     uint32_t off[N];
 #pragma unroll
-    for (int q = 0; q < N; ++q) off[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 4u : 0u);
+    for (int q = 0; q < N; ++q) off[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? (ITEM3 ? 1u : 4u) : 0u);
     uint32_t over = 0;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         const bool counted = (item[q] & 15u) != 0u;
-        const bool fits = off[q] < RB;
-        const uint32_t at = row[q] * RB + off[q];
-        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + ((counted && fits) ? at : (uint32_t)kQuadRowWords * 4u)) = item[q];   // not counted / full row: dummy word
-        over |= (counted && !fits) ? (1u << q) : 0u;
+        if constexpr (ITEM3) {
+            const bool fits = off[q] < (uint32_t)C::kItems;
+            // item s lies at byte 3 s + s / 5 of its row (five items, then a byte of padding) = (205 s) >> 6 for s < 32
+            const uint32_t at = (counted && fits) ? row[q] * RB + (mul24_const<205>(off[q]) >> 6) : (uint32_t)kQuadRowWords * 4u;
+            uint8_t *p = reinterpret_cast<uint8_t *>(rows) + at;
+            p[0] = (uint8_t)item[q];
+            p[1] = (uint8_t)(item[q] >> 8);
+            p[2] = (uint8_t)(item[q] >> 16);
+            over |= (counted && !fits) ? (1u << q) : 0u;
+        } else {
+            const bool fits = off[q] < RB;
+            const uint32_t at = row[q] * RB + off[q];
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + ((counted && fits) ? at : (uint32_t)kQuadRowWords * 4u)) = item[q];   // not counted / full row: dummy word
+            over |= (counted && !fits) ? (1u << q) : 0u;
+        }
     }
     if (__builtin_expect(__any(over != 0u), 0)) {   // wave-uniform
 #if defined(KPAL_QUAD_NO_CARRY)   // bisecting builds only: spilled items straight into the table
@@ -749,12 +781,12 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // those lanes add to private dummy words -- 64 adds to one LDS address serialise.
     auto add_item = [&](uint32_t it, auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        const uint32_t low = (it >> 4) & C::kLowMask;
-        const uint32_t hi6 = it >> (L + 4);
+        // bin of k-mer i in its form: the low 6-2i bits of hi6 above the top L-6+2i bits of low -- with the item laid out
+        // hi6 | low | mask4 that is ONE bit-field of the item: L bits from bit 10 - 2i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t counted = (it >> (3 - i)) & 1u;
-            const uint32_t local = ((hi6 & ((1u << (6 - 2 * i)) - 1u)) << (L - 6 + 2 * i)) | (low >> (6 - 2 * i));
+            const uint32_t counted = __builtin_amdgcn_ubfe(it, 3 - i, 1);
+            const uint32_t local = __builtin_amdgcn_ubfe(it, 10 - 2 * i, L);
             if constexpr (GUARD) {
                 const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
                 const bool eq = counted && local == hot;
@@ -767,6 +799,28 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         }
     };
     auto add4 = [&](const uint4 q) {
+        if constexpr (C::kItem3) {   // five 3-byte items + a byte of padding
+            // (the bit-fields add_item reads lie below bit 23: what an alignbit leaves above the item does not matter;
+            // an item is null iff its mask nibble is zero)
+            const uint32_t i0 = q.x, i1 = __builtin_amdgcn_alignbit(q.y, q.x, 24), i2 = __builtin_amdgcn_alignbit(q.z, q.y, 16),
+                           i3 = q.z >> 8, i4 = q.w;
+            const uint32_t first = __builtin_amdgcn_readfirstlane(i0) & 0xFFFFFFu;
+            const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64((i0 & 0xFFFFFFu) == first)) >= 8;   // wave-uniform
+            if (__builtin_expect(skew, 0)) {
+                if (i0 & 15u) add_item(i0, std::true_type{});
+                if (i1 & 15u) add_item(i1, std::true_type{});
+                if (i2 & 15u) add_item(i2, std::true_type{});
+                if (i3 & 15u) add_item(i3, std::true_type{});
+                if (i4 & 15u) add_item(i4, std::true_type{});
+            } else {
+                if (i0 & 15u) add_item(i0, std::false_type{});
+                if (i1 & 15u) add_item(i1, std::false_type{});
+                if (i2 & 15u) add_item(i2, std::false_type{});
+                if (i3 & 15u) add_item(i3, std::false_type{});
+                if (i4 & 15u) add_item(i4, std::false_type{});
+            }
+            return;
+        }
         // low-complexity sequence repeats whole items across the lanes of a load
         const uint32_t first = __builtin_amdgcn_readfirstlane(q.x);
         const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64(q.x == first)) >= 8;   // wave-uniform

@@ -209,6 +209,29 @@ def test_two_level_batch_halving():
     c2.close()
 
 
+@pytest.mark.parametrize('steps', ['8', '7', '4', '2', '1'])
+def test_quad_tile_sizes_against_oracle(steps):
+    """Every tile size the quad scatters are compiled for (KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2: normally chosen per feed
+    from a sample of the row loads), one- and two-level, on uniform, AT-rich and low-complexity input: bit-exact."""
+    from kpal_amd import _native
+    os.environ['KPAL_QUAD_STEPS'] = steps
+    os.environ['KPAL_QUAD_STEPS2'] = {'1': '2', '2': '3'}.get(steps, steps)
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_QUAD_STEPS']
+        del os.environ['KPAL_QUAD_STEPS2']
+    rs = np.random.RandomState(int(steps))
+    uniform = oracle.synth_reads(61, 0, 40000, 150, noisy=True)
+    at_rich = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=5 << 20, p=[.4, .1, .1, .4])].copy()
+    at_rich[::151] = 10
+    at_rich[2 << 20:(2 << 20) + 300000] = ord('A')
+    for k, strategy in ((12, 'partition_quads'), (10, 'partition_quads'), (13, 'partition2_quads'), (14, 'partition2_quads')):
+        for data in (uniform, at_rich):
+            assert np.array_equal(c2.count_bytes(k, data, strategy), oracle.count_flat(data, k, threads=8)), (k, strategy, steps)
+    c2.close()
+
+
 def test_quad_pipelines_halve_an_oversized_piece():
     """A piece whose record pool would pass the limit of the quad scatters' 32-bit record offsets is counted as two
     halves, recursively (forced here by lowering the limit to 4 MiB); halo across the seams of the halves."""
