@@ -651,11 +651,17 @@ static double quad_expected_backlog(const std::vector<double> &mu, int slots)
         {1.00, 1.00, 1.00, 1.02, 1.02, 1.10, 1.36, 1.68, 2.37, 4.55}};  // 128
     const int ti = slots <= 24 ? 0 : (slots <= 32 ? 1 : (slots <= 64 ? 2 : 3));   // (20 slots: the 16-slot row of the table, on the safe side)
     double total = 0.0;
-    for (double m : mu) {
+    // mu is sorted: rows whose load lies within 1 % of each other are evaluated once, at their mid-point (this runs
+    // on the host inside every large feed: 2048 Poisson tails per candidate cost 0.6 ms of a 12 ms step)
+    for (size_t at = 0; at < mu.size();) {
+        size_t end = at + 1;
+        while (end < mu.size() && mu[end] <= mu[at] * 1.01) ++end;
+        const double m = 0.5 * (mu[at] + mu[end - 1]), weight = (double)(end - at);
+        at = end;
         if (m <= 0.0) continue;
         const double rho = m / slots;
         if (rho >= 0.995) {   // the row cannot keep up
-            total += 1e6;
+            total += 1e6 * weight;
             continue;
         }
         // E[max(X - c, 0)] = sum_{x > c} (x - c) p(x); p by recurrence from p(0) = exp(-m)
@@ -676,7 +682,7 @@ static double quad_expected_backlog(const std::vector<double> &mu, int slots)
             const double f = (rho - rho_grid[j]) / (rho_grid[j + 1] - rho_grid[j]);
             r = ratio[ti][j] + f * (ratio[ti][j + 1] - ratio[ti][j]);
         }
-        total += acc * r;
+        total += acc * r * weight;
     }
     return total;
 }
