@@ -174,9 +174,10 @@ def matrix_workload(args):
                     'memory_frac': mem_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': mem_bytes,
                     'avg_launch_ms': dom_ms}
     else:
-        # multiset term in the float path: sub, mul, rcp (quarter rate: 4 slots), 2 fma (Newton), mul, 2 fma (correction), add = 12 fp64 slots
-        # (the +1 adds and conversions are shared by the 16 terms of a register tile); euclidean int64: ~10 32-bit slots per term
-        slots = 12.0
+        # multiset term with staged reciprocals (matrix_accumulate_prod_rcp): sub, mul, fma = 3 fp64 slots, + per 16 terms of a
+        # register tile 8 int -> double conversions and ~22 integer instructions for the term-count bytes: ~5 slots per term
+        # (sum metric / int64 euclidean without the staged reciprocals: ~12)
+        slots = 5.0 if metric == 0 else 12.0
         roofline = {'bound': 'fp64-valu', 'kernel': dom, 'achieved': terms * slots / (dom_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_T,
                     'unit': 'Tinstr/s (fp64 lane-instructions; %.0f issue slots per term)' % slots,
                     'frac': terms * slots / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_T, 'traffic': None,
