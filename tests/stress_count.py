@@ -36,6 +36,8 @@ while time.time() < t_end:
     strategies = ['auto']
     if 8 <= k <= 12:
         strategies += ['partition', 'partition_chunked', 'partition_quads']
+    if k >= 13:
+        strategies += ['partition2', 'partition2_quads']
     for strat in strategies:
         if rs.rand() < 0.5:
             got = ctx.count_bytes(k, buf, strat)
