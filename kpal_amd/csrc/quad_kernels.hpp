@@ -1,6 +1,6 @@
-// quad_kernels.hpp -- radix partition of QUADS of overlapping k-mers into aligned records (k = 8..12, gfx950).
+// quad_kernels.hpp -- radix partition of QUADS of overlapping k-mers into aligned records (k = 8..16, gfx950).
 //
-// What bounds the chunked scatter of chunk_kernels.hpp (profiles/r2/): one range-checked
+// What bounded the chunked scatter of chunk_kernels.hpp (profiles/r2/): one range-checked
 // buffer_store_short per (bucket, tile) run of ~48 two-byte keys costs ~30 clk of the CU's store path
 // (SQ_INSTS_VMEM_WR: one store per 32 clk per CU over the whole kernel, LDS only 39 % busy), and the
 // path moves 8-10 B/clk/CU no matter how the bytes are cut -- provided they leave as whole ALIGNED
@@ -9,22 +9,27 @@
 //
 //   * ITEM = four overlapping k-mers.  The (K+3)-mer x ending at byte 4q+3 of a lane's 16-byte chunk
 //     holds the k-mers ending at bytes 4q .. 4q+3: k-mer i = x[2K+5-2i : 6-2i].  All four share the
-//     bits x[2K-1 : 6]; the top B of those are the BUCKET.  A 4-byte item keeps the rest: the six bits
-//     above the shared field, the L = 2K-B bits below the bucket, and a 4-bit mask of which of the four
+//     bits x[2K-1 : 6]; the top B of those are the BUCKET.  An item keeps the rest: the six bits above
+//     the shared field, the L = 2K-B bits below the bucket, and a 4-bit mask of which of the four
 //     k-mers count (read ends, N, lower case handled by the mask exactly like emit_mask): one slot
-//     allocation + one 4-byte LDS write per FOUR k-mers, ~1.05 B per k-mer instead of 2.
+//     allocation + one LDS write per FOUR k-mers, ~1 B per k-mer instead of 2.  4 bytes; at k = 12
+//     (23 bits) 3 bytes, five to a 16-byte vector.
 //   * RECORD = one bucket's items of one flush round, padded with null items (mask 0) to a fixed size
-//     (64 B at k = 12: 2048 buckets x 16 items; 256 B at k <= 11: 512 buckets x 64 items), written with
-//     16-byte stores to its own aligned place  pool[bucket][workgroup][round]  -- no cursors, no chunk
-//     allocation, no tables: the histogram stage reads pool[bucket] as one stream.
-//   * A row that overflows (Poisson tail, ~1.5 % of the items) spills into a small LDS list whose
-//     entries are placed again at the start of the next round.  Items that do not fit even then, or that
-//     the list cannot hold (a row that is over-full every round: homopolymers, satellite repeats), are
-//     counted on the spot: ballot-aggregated per wave into a 256-entry (row, item) hash table in LDS that is
-//     added to the count table once per workgroup.  No round is ever abandoned, no input is read twice.
+//     (256 B at k <= 11: 512 buckets x 64 items; 64 B at k = 12: 2048 buckets x 20 items, two buckets to a
+//     128-byte line), written with 16-byte stores to its own aligned place  pool[bucket][workgroup][round]
+//     -- no cursors, no chunk allocation, no tables: the histogram stage reads pool[bucket] as one stream.
+//   * A row that overflows (Poisson tail, 1-3 % of the items) spills into a small LDS list whose
+//     entries are placed again at the start of the next round; the host sizes the tile so that the
+//     steady-state backlog of that list stays small (kpal_hip.hip: quad_expected_backlog).  Items that do
+//     not fit even then, or that the list cannot hold (a row that is over-full every round: homopolymers,
+//     satellite repeats), are counted on the spot: ballot-aggregated per wave into a 256-entry (row, item)
+//     hash table in LDS that is added to the count table once per workgroup.  No round is ever abandoned,
+//     no input is read twice.
 //   * HISTOGRAM: one workgroup per bucket, four forms (one per k-mer position) of 2^L bins in LDS
 //     (128 KiB at k = 11, 12); the bins of form i are table entries (hi << (B+s)) | (bucket << s) | lo
 //     with s = L-6+2i; merged with global atomics (forms of different buckets interleave in the table).
+//   * k = 13..16: two levels of the same scatter (coarse, then fine bucket), the forms staged as 16-bit
+//     counts and combined per table entry (end of this file).
 //
 // Integer adds commute, every k-mer is in exactly one item with its mask bit set: bit-exact.
 #pragma once
@@ -54,11 +59,10 @@ struct QuadCfg {
     static constexpr int kFormBins = 1 << kLowBits;
     static constexpr int kSlots = kQuadRowWords / kBuckets;         // items per row / record: 16, 64; 128, 32
     static constexpr int kRecordBytes = kSlots * 4;
-    // k = 12: an item needs 23 bits (hi6 | low13 | mask4), so it is stored in THREE bytes, five to a 16-byte vector
-    // (15 bytes + one of padding: no item straddles the vectors the flush and the histogram work with) -- a 64-byte
-    // record holds 20 items instead of 16, a tile of 128 wave-steps fills it to 74 %, and the record pool shrinks from
-    // 1.33 to 1.0 bytes per input byte (written once, read once).  The cost: three ds_write_b8 per item instead of one
-    // ds_write_b32 and two more address instructions.
+    // k = 12: an item needs 23 bits (hi6 | low13 | mask4), so it is stored in THREE bytes, five to a 16-byte vector:
+    // four in the low three bytes of the vector's dwords, the fifth in the top bytes of the first three dwords -- a
+    // 64-byte record holds 20 items instead of 16, a tile of 128 wave-steps fills it to 74 %, and the record pool
+    // shrinks from 1.33 to 1.0 bytes per input byte (written once, read once).
 #if defined(KPAL_QUAD_ITEM4)   // A/B builds
     static constexpr bool kItem3 = false;
 #else
@@ -210,15 +214,6 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
     }
 }
 
-// a * C for a < 2^24 as one full-rate v_mul_u32_u24 (written as a product the compiler picks the quarter-rate v_mul_lo_u32)
-template <int C>
-__device__ __forceinline__ uint32_t mul24_const(uint32_t a)
-{
-    uint32_t r;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "n"(C), "v"(a));
-    return r;
-}
-
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
 // the row (the atomic returns the item's byte offset: one shift-add gives its LDS address).
 template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4>
@@ -228,28 +223,43 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 {
     using C = typename std::conditional<LEVEL == 2, QuadCfg<11>, QuadCfg<K>>::type;   // level 2: 512 rows x 64 slots
     constexpr uint32_t RB = (uint32_t)C::kSlots * 4u;                                  // bytes per row
-    constexpr bool ITEM3 = LEVEL == 1 && C::kItem3;                                    // pos[] counts ITEMS, three bytes each
+    constexpr bool ITEM3 = LEVEL == 1 && C::kItem3;                                    // three-byte items: 20 to a 64-byte row
+    uint32_t riders = 0;
     uint32_t off[N];
 #pragma unroll
-    for (int q = 0; q < N; ++q) off[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? (ITEM3 ? 1u : 4u) : 0u);
+    for (int q = 0; q < N; ++q) off[q] = atomicAdd(&pos[row[q]], (item[q] & 15u) ? 4u : 0u);
     uint32_t over = 0;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         const bool counted = (item[q] & 15u) != 0u;
         if constexpr (ITEM3) {
-            const bool fits = off[q] < (uint32_t)C::kItems;
-            // item s lies at byte 3 s + s / 5 of its row (five items, then a byte of padding) = (205 s) >> 6 for s < 32
-            const uint32_t at = (counted && fits) ? row[q] * RB + (mul24_const<205>(off[q]) >> 6) : (uint32_t)kQuadRowWords * 4u;
-            uint8_t *p = reinterpret_cast<uint8_t *>(rows) + at;
-            p[0] = (uint8_t)item[q];
-            p[1] = (uint8_t)(item[q] >> 8);
-            p[2] = (uint8_t)(item[q] >> 16);
-            over |= (counted && !fits) ? (1u << q) : 0u;
+            // slots 0..15: the low three bytes of dword s of the row; slots 16..19 ride in the top bytes (see below)
+            const bool normal = off[q] < RB;
+            const bool rider = !normal && off[q] < RB + RB / 4;
+            if (counted && normal) atomicOr(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + row[q] * RB + off[q]), item[q]);
+            riders |= (counted && rider) ? (1u << q) : 0u;
+            over |= (counted && !normal && !rider) ? (1u << q) : 0u;
         } else {
             const bool fits = off[q] < RB;
             const uint32_t at = row[q] * RB + off[q];
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + ((counted && fits) ? at : (uint32_t)kQuadRowWords * 4u)) = item[q];   // not counted / full row: dummy word
             over |= (counted && !fits) ? (1u << q) : 0u;
+        }
+    }
+    if constexpr (ITEM3) {
+        // Item 16 + r of a row rides in the top bytes of dwords 4r, 4r+1, 4r+2 (one byte each; a 23-bit item leaves the
+        // top byte of its own dword free).  Everything is OR-ed into rows that the flush left zeroed, so the order in which
+        // the lanes of different waves reach a dword does not matter.  ~15 % of the items at the usual fill: a few lanes
+        // per instruction, where three byte stores for EVERY item kept the LDS busy 63 % of the time on bank conflicts.
+        if (__any(riders != 0u)) {   // wave-uniform
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+                if ((riders >> q) & 1u) {
+                    uint32_t *p = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + row[q] * RB + (off[q] - RB) * 4u);
+                    atomicOr(p, item[q] << 24);
+                    atomicOr(p + 1, (item[q] << 16) & 0xFF000000u);
+                    atomicOr(p + 2, (item[q] << 8) & 0xFF000000u);
+                }
         }
     }
     if (__builtin_expect(__any(over != 0u), 0)) {   // wave-uniform
@@ -799,11 +809,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         }
     };
     auto add4 = [&](const uint4 q) {
-        if constexpr (C::kItem3) {   // five 3-byte items + a byte of padding
-            // (the bit-fields add_item reads lie below bit 23: what an alignbit leaves above the item does not matter;
-            // an item is null iff its mask nibble is zero)
-            const uint32_t i0 = q.x, i1 = __builtin_amdgcn_alignbit(q.y, q.x, 24), i2 = __builtin_amdgcn_alignbit(q.z, q.y, 16),
-                           i3 = q.z >> 8, i4 = q.w;
+        if constexpr (C::kItem3) {   // four 3-byte items + a fifth in the top bytes
+            // (the bit-fields add_item reads lie below bit 23: the rider's byte above an item does not matter; an item is
+            // null iff its mask nibble is zero)
+            const uint32_t i0 = q.x, i1 = q.y, i2 = q.z, i3 = q.w;
+            const uint32_t i4 = __builtin_amdgcn_perm(q.z, __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0703u), 0x0c070100u);   // the top bytes of x, y, z
             const uint32_t first = __builtin_amdgcn_readfirstlane(i0) & 0xFFFFFFu;
             const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64((i0 & 0xFFFFFFu) == first)) >= 8;   // wave-uniform
             if (__builtin_expect(skew, 0)) {
