@@ -345,7 +345,11 @@ def main():
                              'launches_per_step': launches / steps,
                              'algorithmic_bytes_per_launch': per_launch_bytes,
                              'pipeline_frac': alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(kern.items())}})
+                             'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(kern.items())},
+                             # the contract prices the path against HBM; what actually limits the quad kernels since round 2
+                             # (counters: profiles/r2/pmc_lds_quad.json)
+                             'limiter': ('VALU + LDS issue (scatter), LDS atomics (histogram): the kernels move their bytes at 4-5 TB/s'
+                                         if dom.startswith('quad') else None)})
         line = {
             'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': value, 'unit': 'Gbases/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
