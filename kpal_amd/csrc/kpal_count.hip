@@ -1,0 +1,727 @@
+// kpal_count.hip -- the counting front end of the C-ABI (begin / feed / feed_device / feed_fasta / records / finish),
+// strategy choice, piece sizes, H2D staging, and the launchers of the LDS-direct, global-atomic and round-1
+// partition pipelines.  The quad record pipelines live in kpal_quads.hip / kpal_quads2.hip.
+#include "kpal_host.hpp"
+
+#include "count_kernels.hpp"
+#include "partition_kernels.hpp"
+#include "chunk_kernels.hpp"
+#include "fasta_kernels.hpp"
+
+static_assert(sizeof(ChunkPool) <= sizeof(kpal_ctx::chunk_pool_sent), "kpal_ctx::chunk_pool_sent holds a ChunkPool");
+
+// ----------------------------------------------------------------------------------------------
+// counting
+// ----------------------------------------------------------------------------------------------
+KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    ctx->k = k;
+    ctx->bins = 1ULL << (2 * k);
+    CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
+    HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+    if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->quad_error_word) HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
+    ctx->chunk_error_armed = false;
+    ctx->counting = true;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2_QUADS)
+        return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
+    ctx->strategy = strategy;
+    return KPAL_OK;
+}
+
+static int resolve_strategy(kpal_ctx *ctx, int *out)
+{
+    int s = ctx->strategy;
+    const int k = ctx->k;
+    if (s == KPAL_STRATEGY_AUTO)
+        s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2_QUADS);
+    if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
+    if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED || s == KPAL_STRATEGY_PARTITION_QUADS) && (k < 8 || k > 12))
+        return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
+    if ((s == KPAL_STRATEGY_PARTITION2 || s == KPAL_STRATEGY_PARTITION2_QUADS) && (k < 13 || k > 16))
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
+    *out = s;
+    return KPAL_OK;
+}
+
+// Span for emitting the k-mers that end in [addr, addr+n), with `halo` readable bytes of the
+// same feed to the left of addr.
+static Span make_span(const uint8_t *addr, size_t n, size_t halo)
+{
+    const uintptr_t first = (uintptr_t)addr - halo;
+    const uintptr_t base = first & ~(uintptr_t)15;
+    Span s;
+    s.base = reinterpret_cast<const uint4 *>(base);
+    s.lo = first - base;
+    s.emit_from = s.lo + halo;
+    s.hi = s.emit_from + n;
+    s.nchunks = (s.hi + 15) / 16;
+    return s;
+}
+
+static int launch_global_atomic(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t steps = (s.nchunks + 63) / 64;
+    const uint64_t max_waves = (uint64_t)ctx->num_cu * 8 * 4;  // 8 blocks of 4 waves per CU
+    const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+    const uint64_t waves = (steps + spw - 1) / spw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_1_16(ctx->k, LAUNCH(ctx, "count_global_atomic", (count_global_atomic_kernel<K>), dim3(grid), dim3(256), s, spw, table));
+    return KPAL_OK;
+}
+
+static int launch_lds_direct(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t steps = (s.nchunks + 63) / 64;
+    const uint64_t max_waves = (uint64_t)ctx->num_cu * 2 * 8;  // 2 blocks of 8 waves per CU
+    const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+    const uint64_t waves = (steps + spw - 1) / spw;
+    const unsigned grid = (unsigned)((waves + 7) / 8);
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_1_7(ctx->k, LAUNCH(ctx, "count_lds_direct", (count_lds_direct_kernel<K>), dim3(grid), dim3(512), s, spw, table));
+    return KPAL_OK;
+}
+
+// One-level partition, k = 8..12 (partition_kernels.hpp: A1, A2, A3, B).
+static int launch_partition(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    // steps per block: a multiple of 24 (8 waves x 3 steps per tile), ~4 blocks per CU
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 4;
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + kStepsPerBlockQuantum - 1) / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+    const uint32_t G = (uint32_t)((total_steps + spb - 1) / spb);
+    const uint64_t max_keys = s.nchunks * 16;
+    CHK(ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64));
+    CHK(ensure(ctx, ctx->cntmat, (size_t)kNumBuckets * G * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs, (size_t)kNumBuckets * G * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->bucket_start, (size_t)(2 * kNumBuckets + 2) * sizeof(uint64_t)));
+    CHK(ensure(ctx, ctx->slice_start, (size_t)(kNumBuckets + 1) * sizeof(uint32_t)));
+    uint32_t *cntmat = (uint32_t *)ctx->cntmat.p;
+    uint32_t *offs = (uint32_t *)ctx->offs.p;
+    uint64_t *bstart = (uint64_t *)ctx->bucket_start.p;
+    uint64_t *btotal = bstart + kNumBuckets + 1;
+    uint32_t *sstart = (uint32_t *)ctx->slice_start.p;
+    uint16_t *keys = (uint16_t *)ctx->keys.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    const uint64_t *no_base = nullptr;
+    DISPATCH_K_8_12(ctx->k, {
+        LAUNCH(ctx, "part_count", (part_count_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, cntmat);
+        LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets), dim3(256), (const uint32_t *)cntmat, G, offs, btotal);
+        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)btotal,
+               (uint32_t)kNumBuckets, no_base, bstart, sstart);
+        LAUNCH(ctx, "part_scatter", (part_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb,
+               (const uint32_t *)offs, (const uint64_t *)bstart, keys);
+        // one workgroup per bucket (exclusive table slice -> plain read-modify-write merge, measured
+        // fastest); oversized buckets of skewed input are cut into slices by the bucket scan
+        LAUNCH(ctx, "part_hist", (part_hist_kernel<PartCfg<K>::kKeyBits>), dim3(kHistGridX), dim3(1024),
+               (const uint16_t *)keys, (const uint64_t *)bstart, (const uint32_t *)sstart, table);
+    });
+    return KPAL_OK;
+}
+
+// Workspace of one chunked scatter + histogram over Y coarse buckets (Y = 1: one-level path):
+// pool of 8 KiB key chunks, table rows, overflow lists, per-coarse-bucket meta words and the device
+// copy of the pool descriptor.  meta words per coarse bucket y: nlist[512] ovf_n[512] (all y first,
+// so one memset clears them), then ovf_count[Y] error, then ostart[Y][513] ocur[Y][512]
+// slice_start[Y][513], then the descriptor.
+struct ChunkLaunch {
+    ChunkPool p;
+    ChunkPool *dpool;
+    uint32_t *ostart, *ocur, *sstart;
+    uint32_t Y;
+};
+
+static int chunk_prepare(kpal_ctx *ctx, uint32_t Y, uint32_t G, uint64_t R, ChunkLaunch &cl)
+{
+    const uint64_t per_y = (uint64_t)G * R;
+    if (per_y >= (1ull << kChunkIdBits)) return set_err(KPAL_E_INVALID, "chunked partition: batch too large");
+    const uint64_t cap = per_y * Y;
+    CHK(ensure(ctx, ctx->keys, cap * kChunkKeys * sizeof(uint16_t)));
+    CHK(ensure(ctx, ctx->chunk_table, (size_t)Y * kNumBuckets * G * kChunkRow * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->chunk_ovf, cap * sizeof(uint2)));
+    CHK(ensure(ctx, ctx->chunk_sorted, cap * sizeof(uint32_t)));
+    const size_t clear_words = (size_t)Y * 2 * kNumBuckets + Y;   // nlist, ovf_n, ovf_count
+    const size_t pool_words = (sizeof(ChunkPool) + 3) / 4 + 8;
+    const size_t meta_words = clear_words + 1 + (size_t)Y * (2 * (kNumBuckets + 1) + kNumBuckets) + 4 + pool_words;
+    const bool fresh = ctx->chunk_meta.cap < meta_words * sizeof(uint32_t);
+    CHK(ensure(ctx, ctx->chunk_meta, meta_words * sizeof(uint32_t)));
+    uint32_t *meta = (uint32_t *)ctx->chunk_meta.p;
+    if (fresh || Y != ctx->chunk_meta_y) {
+        HIPCHK(hipMemsetAsync(meta, 0, meta_words * sizeof(uint32_t), ctx->stream));
+        ctx->chunk_meta_y = Y;
+        ctx->chunk_pool_dev = nullptr;
+    }
+    ChunkPool &p = cl.p;
+    memset(&p, 0, sizeof(p));   // padding too: the descriptor is compared bytewise below
+    p.keys = (uint16_t *)ctx->keys.p;
+    p.per_block = (uint32_t)R;
+    p.groups = G;
+    p.table = (uint32_t *)ctx->chunk_table.p;
+    p.nlist = meta;
+    p.ovf_n = meta + (size_t)Y * kNumBuckets;
+    p.ovf_count = meta + (size_t)Y * 2 * kNumBuckets;
+    p.error = meta + clear_words;
+    p.ovf = (uint2 *)ctx->chunk_ovf.p;
+    cl.ostart = meta + clear_words + 1;
+    cl.ocur = cl.ostart + (size_t)Y * (kNumBuckets + 1);
+    cl.sstart = cl.ocur + (size_t)Y * kNumBuckets;
+    cl.dpool = (ChunkPool *)(((uintptr_t)(cl.sstart + (size_t)Y * (kNumBuckets + 1)) + 15) & ~(uintptr_t)15);
+    cl.Y = Y;
+    ctx->chunk_error_word = p.error;
+    // the device copy changes only when a buffer was reallocated or the geometry changed: a
+    // synchronous copy then -- an asynchronous one would read this stack frame after it is gone
+    if (memcmp(&p, ctx->chunk_pool_sent, sizeof(ChunkPool)) != 0 || (void *)cl.dpool != ctx->chunk_pool_dev) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(cl.dpool, &p, sizeof(ChunkPool), hipMemcpyHostToDevice));
+        memcpy(ctx->chunk_pool_sent, &p, sizeof(ChunkPool));
+        ctx->chunk_pool_dev = cl.dpool;
+    }
+    ctx->chunk_error_armed = true;
+    // per batch: counts restart at 0; the error word is sticky until count_finish
+    HIPCHK(hipMemsetAsync(meta, 0, clear_words * sizeof(uint32_t), ctx->stream));
+    return KPAL_OK;
+}
+
+// The kernels after the scatter: slice plan, overflow grouping, histogram + merge.
+template <int KB>
+static int chunk_histogram(kpal_ctx *ctx, const ChunkLaunch &cl)
+{
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    LAUNCH(ctx, "chunk_plan", chunk_plan_kernel, dim3(cl.Y), dim3(kNumBuckets), (const uint32_t *)cl.p.nlist,
+           (const uint32_t *)cl.p.ovf_n, cl.ostart, cl.ocur, cl.sstart);
+    LAUNCH(ctx, "chunk_list", chunk_list_kernel, dim3(64, cl.Y), dim3(256), cl.p, (const uint32_t *)cl.ostart, cl.ocur,
+           (uint32_t *)ctx->chunk_sorted.p);
+    LAUNCH(ctx, "chunk_hist", (chunk_hist_kernel<KB>), dim3(kHistGridX, cl.Y), dim3(1024), cl.p, (const uint32_t *)cl.ostart,
+           (const uint32_t *)ctx->chunk_sorted.p, (const uint32_t *)cl.sstart, table);
+    return KPAL_OK;
+}
+
+// Chunked one-level partition, k = 8..12 (chunk_kernels.hpp): scatter into per-workgroup 8 KiB
+// chunks, record them in (bucket, workgroup) table rows, histogram every bucket's chunks.
+static int launch_partition_chunked(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    // one round of two resident workgroups per CU: every workgroup leaves a partly filled and an
+    // unused chunk per bucket behind, so fewer, longer workgroups than the exact-offset path
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 2;
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + kStepsPerBlockQuantum - 1) / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+    const uint32_t G = (uint32_t)((total_steps + spb - 1) / spb);
+    // chunks per workgroup, worst case: spb*1024/4096 full ones + a partly filled and a
+    // pre-assigned next one per bucket (+ slack)
+    // (the stride of the ranges is harmless except at exact powers of two: R = 2048 -> 16 MiB costs 10 %)
+    const uint64_t R = spb * 1024 / kChunkKeys + 2 * kNumBuckets + 64;
+    ChunkLaunch cl;
+    CHK(chunk_prepare(ctx, 1, G, R, cl));
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_8_12(ctx->k, {
+        LAUNCH(ctx, "chunk_scatter", (chunk_scatter_kernel<K>), dim3(G), dim3(kScatterThreads), s, spb, (const ChunkPool *)cl.dpool,
+               cl.p.keys, cl.p.per_block, table);
+        CHK(chunk_histogram<PartCfg<K>::kKeyBits>(ctx, cl));
+    });
+    return KPAL_OK;
+}
+
+
+
+// Two-level partition, k = 13..16: coarse count/scan/scatter into 24-bit residuals, then the
+// one-level pipeline on every coarse bucket's residual stream (2-D launches over coarse buckets).
+static int launch_partition2(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    const int NB1 = 1 << (2 * ctx->k - kResidualBits);
+    const uint64_t want_blocks = (uint64_t)ctx->num_cu * 8;   // measured: coarse_count 8 % faster than with 4 per CU, coarse_scatter indifferent
+    uint64_t spb = (total_steps + want_blocks - 1) / want_blocks;
+    spb = (spb + 7) / 8 * 8;   // 8 waves, one step per wave per tile
+    const uint32_t G1 = (uint32_t)((total_steps + spb - 1) / spb);
+    const uint64_t max_keys = s.nchunks * 16;
+    if (ensure(ctx, ctx->residuals, max_keys * sizeof(uint32_t) + 64) != KPAL_OK ||
+        (ctx->level2_mode == 0 && ensure(ctx, ctx->keys, max_keys * sizeof(uint16_t) + 64) != KPAL_OK)) {
+        if (max_keys <= ((uint64_t)1 << 30)) return KPAL_E_NOMEM;
+        return kSplitBatch;   // not enough HBM for a batch of this size: retry with half
+    }
+    CHK(ensure(ctx, ctx->cnt1, (size_t)NB1 * G1 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs1, (size_t)NB1 * G1 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->start1, (size_t)(2 * NB1 + 2) * sizeof(uint64_t)));
+    uint32_t *res = (uint32_t *)ctx->residuals.p;
+    uint32_t *cnt1 = (uint32_t *)ctx->cnt1.p;
+    uint32_t *offs1 = (uint32_t *)ctx->offs1.p;
+    uint64_t *start1 = (uint64_t *)ctx->start1.p;
+    uint64_t *total1 = start1 + NB1 + 1;
+    uint16_t *keys = (uint16_t *)ctx->keys.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    const uint64_t *no_base = nullptr;
+    DISPATCH_K_13_16(ctx->k, {
+        LAUNCH(ctx, "coarse_count", (coarse_count_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb, cnt1);
+        LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(NB1), dim3(256), (const uint32_t *)cnt1, G1, offs1, total1);
+        LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(1), dim3(kNumBuckets), (const uint64_t *)total1,
+               (uint32_t)NB1, no_base, start1, (uint32_t *)nullptr);
+    });
+    // coarse bucket sizes: they size the level-2 launches and guard the 32-bit in-bucket offsets
+    // (one small D2H + sync per batch)
+    std::vector<uint64_t> h1((size_t)NB1 + 1);
+    HIPCHK(hipMemcpyAsync(h1.data(), start1, h1.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint64_t maxn = 0;
+    for (int c = 0; c < NB1; ++c) maxn = std::max(maxn, h1[c + 1] - h1[c]);
+    if (maxn == 0) return KPAL_OK;
+    if (maxn > ctx->split_above && s.nchunks > 64) return kSplitBatch;   // skewed batch: the caller halves it
+    DISPATCH_K_13_16(ctx->k, {
+        LAUNCH(ctx, "coarse_scatter", (coarse_scatter_kernel<K>), dim3(G1), dim3(kCoarseThreads), s, spb,
+               (const uint32_t *)offs1, (const uint64_t *)start1, res);
+    });
+    if (ctx->level2_mode != 0) {
+        // level 2 as a chunked scatter (chunk_kernels.hpp): no counting pass over the residuals.
+        // Two resident workgroups per CU in total; every workgroup leaves ~1000 unused 8 KiB chunks.
+        const bool lines = ctx->level2_mode == 2;   // aligned-line staging: one 1024-thread workgroup per CU
+        // workgroups per coarse bucket: 8 per CU in total when the coarse buckets are equal (fewer, longer
+        // workgroups are 6 % faster); unequal buckets (AT-rich input) leave most workgroups of the small
+        // ones empty, so the granularity is doubled (AT-rich 1 GiB: 3.1 -> 2.2 ms)
+        const uint64_t total1 = h1[NB1] - h1[0];
+        const bool unequal = (double)maxn * NB1 > 1.25 * (double)total1;
+        uint64_t g2t = std::max<uint64_t>(2, (uint64_t)ctx->num_cu * (lines ? (unequal ? 16 : 8) : 2) / NB1);
+        g2t = std::min<uint64_t>(g2t, std::max<uint64_t>(2, 4096 / NB1));   // every workgroup reserves ~1000 chunks (9 MB) of pool address space
+        const uint64_t quantum = lines ? (uint64_t)kKeysPerBlockQuantum : (uint64_t)kScatterWaves * kScatterSteps * kMacroKeys;
+        uint64_t kpb2 = 0, R2 = 0;
+        uint32_t G2c = 0;
+        for (;; g2t = (g2t + 1) / 2) {   // few coarse buckets (k = 13): keep a coarse bucket's chunk ids below 2^20
+            kpb2 = (maxn + g2t - 1) / g2t;
+            kpb2 = (kpb2 + quantum - 1) / quantum * quantum;
+            if (kpb2 > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
+            G2c = (uint32_t)((maxn + kpb2 - 1) / kpb2);
+            R2 = kpb2 / kChunkKeys + 2 * kNumBuckets + 64;
+            if ((uint64_t)G2c * R2 < (1ull << kChunkIdBits) || g2t <= 2) break;
+        }
+        if ((uint64_t)G2c * R2 >= (1ull << kChunkIdBits) && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // one coarse bucket holds (almost) everything
+        ChunkLaunch cl;
+        const int rc = chunk_prepare(ctx, (uint32_t)NB1, G2c, R2, cl);
+        if (rc == KPAL_E_NOMEM && max_keys > ((uint64_t)1 << 30)) return kSplitBatch;   // retry with half the batch
+        if (rc != KPAL_OK) return rc;
+        if (lines)
+            LAUNCH(ctx, "chunk_key_lines", chunk_key_lines_kernel, dim3(G2c, NB1), dim3(kLineThreads), (const uint32_t *)res,
+                   (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
+        else
+            LAUNCH(ctx, "chunk_key_scatter", chunk_key_scatter_kernel, dim3(G2c, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+                   (const uint64_t *)start1, (uint32_t)kpb2, (const ChunkPool *)cl.dpool, cl.p.keys, cl.p.per_block, table);
+        return chunk_histogram<kResKeyBits>(ctx, cl);
+    }
+    const uint64_t g2_target = std::max<uint64_t>(8, (uint64_t)ctx->num_cu * 8 / NB1);
+    uint64_t kpb = (maxn + g2_target - 1) / g2_target;
+    kpb = (kpb + kKeysPerBlockQuantum - 1) / kKeysPerBlockQuantum * kKeysPerBlockQuantum;
+    if (kpb > 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "two-level partition: batch too large");
+    const uint32_t G2 = (uint32_t)((maxn + kpb - 1) / kpb);
+    const size_t rows2 = (size_t)NB1 * kNumBuckets;
+    CHK(ensure(ctx, ctx->cntmat, rows2 * G2 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->offs, rows2 * G2 * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->bucket_start, ((size_t)NB1 * (kNumBuckets + 1) + rows2) * sizeof(uint64_t)));
+    uint32_t *cntmat2 = (uint32_t *)ctx->cntmat.p;
+    uint32_t *offs2 = (uint32_t *)ctx->offs.p;
+    uint64_t *bstart2 = (uint64_t *)ctx->bucket_start.p;
+    uint64_t *total2 = bstart2 + (size_t)NB1 * (kNumBuckets + 1);
+    CHK(ensure(ctx, ctx->slice_start, (size_t)NB1 * (kNumBuckets + 1) * sizeof(uint32_t)));
+    uint32_t *sstart2 = (uint32_t *)ctx->slice_start.p;
+    LAUNCH(ctx, "key_count", key_count_kernel, dim3(G2, NB1), dim3(kScatterThreads), (const uint32_t *)res,
+           (const uint64_t *)start1, (uint32_t)kpb, cntmat2);
+    LAUNCH(ctx, "part_rowscan", part_rowscan_kernel, dim3(kNumBuckets, NB1), dim3(256), (const uint32_t *)cntmat2, G2, offs2, total2);
+    LAUNCH(ctx, "part_bucketscan", part_bucketscan_kernel, dim3(NB1), dim3(kNumBuckets), (const uint64_t *)total2,
+           (uint32_t)kNumBuckets, (const uint64_t *)start1, bstart2, sstart2);
+    LAUNCH(ctx, "key_scatter", key_scatter_kernel, dim3(G2, NB1), dim3(kLineThreads), (const uint32_t *)res,
+           (const uint64_t *)start1, (uint32_t)kpb, (const uint32_t *)offs2, (const uint64_t *)bstart2, keys);
+    LAUNCH(ctx, "part_hist", (part_hist_kernel<kResKeyBits>), dim3(kHistGridX, NB1), dim3(1024),
+           (const uint16_t *)keys, (const uint64_t *)bstart2, (const uint32_t *)sstart2, table);
+    return KPAL_OK;
+}
+
+static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo);
+
+// A piece whose record pool would be too large (kSplitBatch): as two halves.
+static int count_device_halves(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo)
+{
+    const size_t half = (n / 2 + 15) & ~(size_t)15;
+    CHK(count_device_range(ctx, addr, half, halo));
+    if (n > half) CHK(count_device_range(ctx, addr + half, n - half, halo + half));
+    return KPAL_OK;
+}
+
+// Count all k-mers ending in [addr, addr+n) of a device buffer; `halo` bytes left of addr are
+// readable and belong to the same feed.
+static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size_t halo)
+{
+    int strat = 0;
+    CHK(resolve_strategy(ctx, &strat));
+    // tiny feeds (single records, short reads lists): the partition pipelines cost a fixed
+    // 0.1 - 0.5 ms (launches, one merge of the whole table); a quarter million atomics do not
+    if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
+    // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
+    // the two-level quad pipeline stages and combines 16 bytes per TABLE ENTRY whatever the feed holds (k = 15: 17 GB written,
+    // 34 GB combined): it wins once the feed is about half as large as the table (k = 15: 44 vs 59 ms on 15 GB, but 11.8 vs
+    // 8.7 ms on 1 GiB); below that the round-1 two-level pipeline stays
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS &&
+             n < std::max<size_t>((size_t)64 << 20, (size_t)(ctx->bins * 4)))
+        strat = KPAL_STRATEGY_PARTITION2;
+    const size_t km1 = (size_t)ctx->k - 1;
+    size_t piece = n;
+    if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;
+    else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) {
+        // as large as the 20-bit chunk ids allow (G workgroups x R chunks each < 2^20, R = steps/4 + 1088 in
+        // launch_partition_chunked): every piece ends with a merge of the whole table and four launches.
+        // 1.86 GiB on 256 CUs; KPAL_BATCH_BYTES lowers it.
+        const uint64_t G = (uint64_t)ctx->num_cu * 2;
+        const uint64_t r_max = ((1ull << kChunkIdBits) - 1) / G;
+        const uint64_t fixed = 2 * kNumBuckets + 64;
+        uint64_t spb_max = r_max > fixed + 64 ? (r_max - fixed) * (kChunkKeys / 1024) : 64;
+        spb_max = spb_max > 3 * kStepsPerBlockQuantum ? spb_max - 2 * kStepsPerBlockQuantum : spb_max;   // margin: the halo may add a step
+        spb_max = spb_max / kStepsPerBlockQuantum * kStepsPerBlockQuantum;
+        const size_t cap = (size_t)(spb_max * G * 1024);
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
+    }
+    else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+        // the record pool takes 4/3 of the input bytes (up to 8 x that for heavily skewed input, whose tiles are
+        // smaller): pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
+    }
+    else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
+        // two record pools of ~4/3 of the input bytes each: pieces of up to 16 GiB
+        piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes * 16, (size_t)16 << 30) : (size_t)16 << 30;
+    }
+    else if (strat == KPAL_STRATEGY_PARTITION2) {
+        // every batch ends with a read-modify-write of the whole 4^k table (0.5 - 32 GiB): few, large
+        // batches.  In-bucket offsets are 32-bit: below 2^32 keys per batch always safe (k = 13 has
+        // only four coarse buckets); larger batches are checked per coarse bucket and halved if needed.
+        piece = ctx->k == 13 ? std::min<size_t>(ctx->batch_bytes * 4, (size_t)0xF0000000u)
+                             : std::min<size_t>(ctx->batch_bytes * 16, (size_t)16 << 30);
+    }
+    else if (strat == KPAL_STRATEGY_LDS_DIRECT) piece = (size_t)1 << 31;
+    piece &= ~(size_t)15;
+    if (piece == 0) piece = 16;
+    for (size_t off = 0; off < n; off += piece) {
+        const size_t len = std::min(piece, n - off);
+        const size_t h = std::min(km1, halo + off);
+        const Span s = make_span(addr + off, len, h);
+        if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
+        else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
+        else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
+            const int rc = launch_partition2_quads(ctx, s);
+            if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the round-1 two-level pipeline
+                ctx->strategy = KPAL_STRATEGY_PARTITION2;
+                const int r2 = count_device_range(ctx, addr + off, len, halo + off);
+                ctx->strategy = KPAL_STRATEGY_AUTO;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc == kSplitBatch) {
+                CHK(count_device_halves(ctx, addr + off, len, halo + off));
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
+        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+            const int rc = launch_partition_quads(ctx, s);
+            if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size
+                ctx->strategy = KPAL_STRATEGY_PARTITION_CHUNKED;
+                const int r2 = count_device_range(ctx, addr + off, len, halo + off);
+                ctx->strategy = KPAL_STRATEGY_AUTO;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc == kSplitBatch) {
+                CHK(count_device_halves(ctx, addr + off, len, halo + off));
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
+        else {
+            const int rc = launch_partition2(ctx, s);
+            if (rc == kSplitBatch) {   // rare: process this piece as two halves
+                const size_t half = (len / 2 + 15) & ~(size_t)15;
+                const size_t saved = ctx->batch_bytes;
+                ctx->batch_bytes = std::max<size_t>(half / (ctx->k == 13 ? 4 : 16), 16);
+                int r2 = count_device_range(ctx, addr + off, half, halo + off);
+                if (r2 == KPAL_OK && len > half) r2 = count_device_range(ctx, addr + off + half, len - half, halo + off + half);
+                ctx->batch_bytes = saved;
+                if (r2 != KPAL_OK) return r2;
+            } else if (rc != KPAL_OK) {
+                return rc;
+            }
+        }
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_device before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!dev_buf) return set_err(KPAL_E_INVALID, "dev_buf is NULL");
+    return count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
+}
+
+// Host copy into a pinned staging buffer on several cores: one core's memcpy (~10 GB/s) is what limits
+// a pageable-memory feed otherwise, the PCIe link takes ~5 times that.  KPAL_COPY_THREADS (default 4, 1 =
+// plain memcpy); pieces below 4 MiB are not worth the thread start.
+static void staged_memcpy(void *dst, const void *src, size_t n)
+{
+    static const int configured = [] {
+        const char *e = getenv("KPAL_COPY_THREADS");
+        int t = e ? atoi(e) : 4;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)t > hw) t = (int)hw;
+        return t < 1 ? 1 : (t > 32 ? 32 : t);
+    }();
+    const size_t min_part = (size_t)4 << 20;
+    int parts = (int)std::min<size_t>((size_t)configured, n / min_part);
+    if (parts <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> workers;
+    workers.reserve(parts - 1);
+    for (int i = 1; i < parts; ++i) {
+        const size_t off = (size_t)i * part;
+        if (off >= n) break;
+        const size_t len = std::min(part, n - off);
+        try {
+            workers.emplace_back([=] { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len); });
+        } catch (...) {   // no thread to be had: copy this part here (no exception may cross the C-ABI)
+            memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len);
+        }
+    }
+    memcpy(dst, src, std::min(part, n));
+    for (auto &w : workers) w.join();
+}
+
+static int ensure_pinned(kpal_ctx *ctx)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->pinned[i]) {
+            hipError_t e = hipHostMalloc(&ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStagePad, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+        }
+    }
+    return KPAL_OK;
+}
+
+// Pageable host memory -> device through the two pinned staging buffers: the memcpy into one
+// overlaps the DMA out of the other.  ctx->stream waits for the last piece.
+static int h2d_staged(kpal_ctx *ctx, uint8_t *dev_dst, const uint8_t *host_src, size_t n)
+{
+    CHK(ensure_pinned(ctx));
+    const size_t stage = kpal_ctx::kStage;
+    int slot = 0, last = -1;
+    for (size_t off = 0; off < n; off += stage, slot ^= 1) {
+        const size_t len = std::min(stage, n - off);
+        if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // its previous DMA is done
+        staged_memcpy(ctx->pinned[slot], host_src + off, len);
+        HIPCHK(hipMemcpyAsync(dev_dst + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        ctx->stage_used[slot] = true;
+        last = slot;
+    }
+    if (last >= 0) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[last], 0));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
+    const size_t km1 = (size_t)ctx->k - 1;
+    const size_t stage = kpal_ctx::kStage;
+    const size_t pad = kpal_ctx::kStagePad;  // room for the halo, keeps the payload 16-byte aligned
+    CHK(ensure_pinned(ctx));
+    for (int i = 0; i < 2; ++i) CHK(ensure(ctx, ctx->dstage[i], stage + pad));
+    int slot = 0;
+    for (size_t off = 0; off < nbytes; off += stage, slot ^= 1) {
+        const size_t len = std::min(stage, nbytes - off);
+        const size_t h = std::min(km1, off);
+        // the pinned/device slot is free once the H2D copy (pinned) and the kernels (device) that used it are done
+        if (ctx->stage_used[slot]) {
+            HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));
+            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[slot], 0));
+        }
+        uint8_t *hp = (uint8_t *)ctx->pinned[slot] + (pad - h);
+        staged_memcpy(hp, host_buf + off - h, len + h);
+        uint8_t *dp = (uint8_t *)ctx->dstage[slot].p + (pad - h);
+        HIPCHK(hipMemcpyAsync(dp, hp, len + h, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+        CHK(count_device_range(ctx, dp + h, len, h));
+        HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
+        ctx->stage_used[slot] = true;
+    }
+    return KPAL_OK;
+}
+
+// Position of the first header ('>' at a line start) in a FASTA buffer, or nbytes if none.
+static size_t fasta_first_header(const uint8_t *buf, size_t nbytes)
+{
+    size_t i = 0;
+    while (i < nbytes) {
+        if (buf[i] == '>') return i;
+        const void *nl = memchr(buf + i, '\n', nbytes - i);
+        const void *cr = memchr(buf + i, '\r', nbytes - i);
+        const uint8_t *e = (const uint8_t *)nl;
+        if (cr && (!e || (const uint8_t *)cr < e)) e = (const uint8_t *)cr;
+        if (!e) return nbytes;
+        i = (size_t)(e - buf) + 1;
+    }
+    return nbytes;
+}
+
+// FASTA text (host) -> flat stream on the device: ctx->fa_flat holds *n_flat bytes afterwards.
+static int fasta_flatten_to_device(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint64_t *n_flat)
+{
+    *n_flat = 0;
+    const size_t first = fasta_first_header(host_buf, nbytes);
+    if (first >= nbytes) return KPAL_OK;   // no record: nothing to count (klib.py:111 yields nothing)
+    const uint64_t n = nbytes - first;
+    const uint32_t nblocks = (uint32_t)((n + kFaBlockBytes - 1) / kFaBlockBytes);
+    CHK(ensure(ctx, ctx->fa_raw, n + 64));
+    CHK(ensure(ctx, ctx->fa_flat, n + 64));
+    const size_t meta = (size_t)nblocks * (8 + 8 + 4) + (size_t)(nblocks + 1) * 8 + 64;
+    CHK(ensure(ctx, ctx->fa_meta, meta));
+    uint8_t *raw = (uint8_t *)ctx->fa_raw.p;
+    uint8_t *flat = (uint8_t *)ctx->fa_flat.p;
+    long long *last_eol = (long long *)ctx->fa_meta.p;
+    long long *carry = last_eol + nblocks;
+    uint64_t *offs = (uint64_t *)(carry + nblocks);
+    uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
+    // fa_raw is free: the previous call synchronised after its last reader (fa_scatter)
+    CHK(h2d_staged(ctx, raw, host_buf + first, n));
+    LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, last_eol);
+    LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
+    LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, (const long long *)carry, kept);
+    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
+    LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n,
+           (const long long *)carry, (const uint64_t *)offs, flat);
+    HIPCHK(hipMemcpyAsync(n_flat, offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_fasta before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
+    uint64_t n_flat = 0;
+    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
+    if (n_flat == 0) return KPAL_OK;
+    return count_device_range(ctx, (const uint8_t *)ctx->fa_flat.p, (size_t)n_flat, 0);
+}
+
+KPAL_API int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out)
+{
+    CTX_ENTER(ctx);
+    if (!n_out || (nbytes && (!host_buf || !host_out))) return set_err(KPAL_E_INVALID, "NULL pointer");
+    *n_out = 0;
+    if (nbytes == 0) return KPAL_OK;
+    uint64_t n_flat = 0;
+    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
+    if (n_flat) {
+        HIPCHK(hipMemcpyAsync(host_out, ctx->fa_flat.p, n_flat, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n_flat;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
+                                size_t n_records, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    if (n_records == 0) return KPAL_OK;
+    if (!host_starts || !host_out || (nbytes && !host_flat)) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (n_records >= 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "too many records in one batch");
+    if (host_starts[0] != 0 || host_starts[n_records] != nbytes) return set_err(KPAL_E_INVALID, "starts must run from 0 to nbytes");
+    for (size_t r = 0; r < n_records; ++r)
+        if (host_starts[r] > host_starts[r + 1]) return set_err(KPAL_E_INVALID, "starts must be ascending");
+    const uint64_t bins = 1ULL << (2 * k);
+    const size_t out_bytes = n_records * bins * sizeof(int64_t);
+    CHK(ensure(ctx, ctx->scratch[0], out_bytes));
+    CHK(ensure(ctx, ctx->scratch[1], nbytes + 64));
+    CHK(ensure(ctx, ctx->scratch[2], (n_records + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(ctx->scratch[0].p, 0, out_bytes, ctx->stream));
+    if (nbytes) {
+        HIPCHK(hipMemcpyAsync(ctx->scratch[1].p, host_flat, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[2].p, host_starts, (n_records + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        const Span s = make_span((const uint8_t *)ctx->scratch[1].p, nbytes, 0);
+        const uint64_t steps = (s.nchunks + 63) / 64;
+        const uint64_t max_waves = (uint64_t)ctx->num_cu * 8 * 4;
+        const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+        const uint64_t waves = (steps + spw - 1) / spw;
+        const unsigned grid = (unsigned)((waves + 3) / 4);
+        DISPATCH_K_1_16(k, LAUNCH(ctx, "count_records", (count_records_kernel<K>), dim3(grid), dim3(256), s, spw,
+                                  (const uint64_t *)ctx->scratch[2].p, (uint32_t)n_records, (unsigned long long *)ctx->scratch[0].p));
+    }
+    HIPCHK(hipMemcpyAsync(host_out, ctx->scratch[0].p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
+    uint32_t pool_error = 0, quad_error = 0;
+    if (ctx->chunk_error_armed)
+        HIPCHK(hipMemcpyAsync(&pool_error, ctx->chunk_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->quad_error_word)
+        HIPCHK(hipMemcpyAsync(&quad_error, ctx->quad_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    // (a double-buffered pinned staging path was measured slower than the runtime's pageable copy)
+    if (host_out)
+        HIPCHK(hipMemcpyAsync(host_out, ctx->table.p, ctx->bins * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (pool_error) {
+        HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
+        return set_err(KPAL_E_HIP, "chunked partition: the chunk pool ran out (internal sizing error %u); counts are invalid", pool_error);
+    }
+    if (quad_error) {
+        HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
+        return set_err(KPAL_E_HIP, "quad partition: internal sizing error %u; counts are invalid", quad_error);
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "no count table (call kpal_count_begin)");
+    if (dev_table) *dev_table = ctx->table.p;
+    if (n_bins) *n_bins = ctx->bins;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_synth_reads_device(kpal_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                     int read_len, int noisy, void *dev_out)
+{
+    CTX_ENTER(ctx);
+    if (read_len < 1) return set_err(KPAL_E_INVALID, "read_len must be >= 1");
+    if (n_reads == 0) return KPAL_OK;
+    if (!dev_out || ((uintptr_t)dev_out & 15)) return set_err(KPAL_E_INVALID, "dev_out must be a 16-byte aligned device pointer");
+    const uint64_t total = n_reads * (uint64_t)(read_len + 1);
+    const uint64_t nvec = (total + 15) / 16;
+    const unsigned grid = (unsigned)std::min<uint64_t>((nvec + 255) / 256, (uint64_t)ctx->num_cu * 16);
+    LAUNCH(ctx, "synth_reads", synth_reads_kernel, dim3(grid), dim3(256), seed, first_read, n_reads,
+           (uint32_t)read_len, noisy, (uint8_t *)dev_out);
+    return KPAL_OK;
+}
+

@@ -275,4 +275,21 @@ __device__ __forceinline__ uint32_t kmer_at(uint64_t window, int j)
     return (uint32_t)((window >> (2 * (15 - j))) & M);
 }
 
+// One wave-step at absolute step index `step` (interior fast path chosen per wave).
+template <int K>
+__device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &carry, uint64_t &window, uint32_t &mask)
+{
+    const int lane = threadIdx.x & 63;
+    if (interior_range(s, step * 64, step * 64 + 64)) wave_step<K, false>(s, (int64_t)(step * 64 + lane), carry, window, mask);
+    else wave_step<K, true>(s, (int64_t)(step * 64 + lane), carry, window, mask);
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// vector-memory counter, so line stores issued in a flush phase stay in flight while the next
+// tile is placed.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 }  // namespace kpal

@@ -1,0 +1,224 @@
+// kpal_host.hpp -- host side shared by the translation units of libkpal_hip.so: errors, the context,
+// workspace buffers, per-kernel HIP-event timing, the launch / dispatch macros and the few host functions
+// one unit calls in another.  (kpal_ctx.hip: context + profiling API; kpal_count.hip: counting front end and the
+// round-1 pipelines; kpal_quads.hip / kpal_quads2.hip: the quad record pipelines; kpal_vec.hip: balance, split,
+// distances, matrices, options, summaries; kpal_multi.hip: multi-GPU entry points over RCCL.)
+#pragma once
+#include "../../include/kpal_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#include "kpal_device.hpp"
+
+#define KPAL_API extern "C" __attribute__((visibility("default")))
+
+using namespace kpal;
+
+// ----------------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------------
+int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return set_err(e_ == hipErrorOutOfMemory ? KPAL_E_NOMEM : KPAL_E_HIP, "%s failed: %s (%s:%d)", \
+                           #expr, hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define CHK(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != KPAL_OK) return rc_; \
+    } while (0)
+
+
+// ----------------------------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfRec {
+    int name;
+    hipEvent_t a, b;
+};
+
+struct kpal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+    int num_cu = 256;
+    // counting state
+    int k = 0;
+    int strategy = KPAL_STRATEGY_AUTO;
+    bool counting = false;
+    DevBuf table;  // int64[4^k]
+    uint64_t bins = 0;
+    size_t batch_bytes = (size_t)1 << 30;
+    bool batch_bytes_set = false;            // KPAL_BATCH_BYTES given (else the chunked path uses its own maximum)
+    uint64_t split_above = 0xFFFFFFFFull;   // two-level path: largest coarse bucket one batch may hold (32-bit offsets)
+    size_t quad_pool_max = (size_t)30 << 30; // quad pipelines: largest record pool of one piece (a record store is a scalar base
+                                             // + a 32-bit per-thread offset that spans 1/8 of the pool); larger pieces are halved
+    // partition workspace
+    DevBuf keys, cntmat, offs, bucket_start, slice_start;
+    DevBuf chunk_meta, chunk_table, chunk_ovf, chunk_sorted;   // chunked one-level path
+    DevBuf quad_meta, quad_meta2;            // quad path: rounds per workgroup, error word; level-2 rounds (k >= 13)
+    uint32_t *quad_error_word = nullptr;
+    bool chunk_error_armed = false;
+    int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
+    alignas(16) unsigned char chunk_pool_sent[96] = {};   // (ChunkPool) what the device copy of the pool descriptor holds
+    void *chunk_pool_dev = nullptr;
+    uint32_t chunk_meta_y = 0;               // coarse-bucket count the meta layout was cleared for
+    uint32_t *chunk_error_word = nullptr;
+    DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..16)
+    DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
+    // host-feed staging
+    static constexpr size_t kStage = (size_t)64 << 20;
+    static constexpr size_t kStagePad = 64;
+    void *pinned[2] = {nullptr, nullptr};
+    DevBuf dstage[2];
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    // scratch for vector ops
+    DevBuf scratch[4];
+    DevBuf partials, result;
+    DevBuf opt_l, opt_r, opt_levels, opt_profiles;   // ProfileDistance option pipeline
+    // profiling
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<uint64_t> prof_launches;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    uint64_t prof_dropped = 0;               // launches whose timing events could not be recorded
+};
+
+
+int ensure(kpal_ctx *ctx, DevBuf &b, size_t bytes);
+int prof_name_id(kpal_ctx *ctx, const char *name);
+hipEvent_t prof_event(kpal_ctx *ctx);
+int prof_collect(kpal_ctx *ctx);
+
+struct ProfScope {
+    kpal_ctx *ctx;
+    ProfRec rec;
+    bool on;
+    ProfScope(kpal_ctx *c, const char *name) : ctx(c), on(c->prof)
+    {
+        if (on) {
+            rec.name = prof_name_id(c, name);
+            rec.a = prof_event(c);
+            rec.b = prof_event(c);
+            // a launch that cannot be timed is still launched: the pair is dropped, the failure is counted
+            if (!rec.a || !rec.b || hipEventRecord(rec.a, c->stream) != hipSuccess) drop();
+        }
+    }
+    void drop()
+    {
+        on = false;
+        ++ctx->prof_dropped;
+        if (rec.a) ctx->ev_pool.push_back(rec.a);
+        if (rec.b) ctx->ev_pool.push_back(rec.b);
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            if (hipEventRecord(rec.b, ctx->stream) == hipSuccess) ctx->prof_pending.push_back(rec);
+            else drop();
+        }
+    }
+};
+
+#define LAUNCH(ctx, name, kernel, grid, block, ...)                                       \
+    do {                                                                                  \
+        {                                                                                 \
+            ProfScope ps_(ctx, name);                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);       \
+        }                                                                                 \
+        HIPCHK(hipGetLastError());                                                        \
+    } while (0)
+
+#define CASE_K(N, ...)           \
+    case N: {                    \
+        constexpr int K = N;     \
+        __VA_ARGS__;             \
+    } break;
+
+#define DISPATCH_K_1_16(k, ...)                                                                            \
+    switch (k) {                                                                                            \
+        CASE_K(1, __VA_ARGS__) CASE_K(2, __VA_ARGS__) CASE_K(3, __VA_ARGS__) CASE_K(4, __VA_ARGS__) CASE_K(5, __VA_ARGS__) CASE_K(6, __VA_ARGS__)     \
+        CASE_K(7, __VA_ARGS__) CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__) \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__)                                 \
+    default:                                                                                                \
+        return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);                           \
+    }
+
+#define DISPATCH_K_1_7(k, ...)                                                                         \
+    switch (k) {                                                                                        \
+        CASE_K(1, __VA_ARGS__) CASE_K(2, __VA_ARGS__) CASE_K(3, __VA_ARGS__) CASE_K(4, __VA_ARGS__) CASE_K(5, __VA_ARGS__) CASE_K(6, __VA_ARGS__) \
+        CASE_K(7, __VA_ARGS__)                                                                                 \
+    default:                                                                                            \
+        return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);                   \
+    }
+
+#define DISPATCH_K_13_16(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__) \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k); \
+    }
+
+#define DISPATCH_K_8_16(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
+        CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__)                               \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "quad partition needs 8 <= k <= 16 (k=%d)", k);             \
+    }
+
+#define DISPATCH_K_8_12(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);         \
+    }
+
+#define CTX_ENTER(ctx)                                            \
+    if (!(ctx)) return set_err(KPAL_E_INVALID, "ctx is NULL");    \
+    HIPCHK(hipSetDevice((ctx)->device))
+
+
+inline unsigned stream_grid(kpal_ctx *ctx, uint64_t n_items, unsigned block = 256)
+{
+    const uint64_t want = (n_items + block - 1) / block;
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->num_cu * 8));
+}
+
+// ----------------------------------------------------------------------------------------------
+// host functions shared between the units
+// ----------------------------------------------------------------------------------------------
+constexpr int kQuadsUseChunked = 2;   // launch_partition*_quads (AUTO): the sample shows a feed for the round-1 pipeline
+constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
+int launch_partition_quads(kpal_ctx *ctx, const Span &s);                 // kpal_quads.hip
+int launch_partition2_quads(kpal_ctx *ctx, const Span &s);                // kpal_quads2.hip
+int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
+                      size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr);   // kpal_quads.hip
+double quad_expected_backlog(const std::vector<double> &mu, int slots);   // kpal_quads.hip
+constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
+int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out);   // kpal_vec.hip

@@ -1,0 +1,117 @@
+// kpal_quads2.hip -- launch planning of the two-level quad record pipeline, k = 13..16 (quad_kernels.hpp, second half).
+#include "kpal_host.hpp"
+
+#include "quad_kernels.hpp"
+
+// Two-level partition of quads, k = 13..16 (quad_kernels.hpp, end): level-1 records by coarse bucket, level-2 records
+// by (coarse, fine) bucket, histogram per (coarse, fine) bucket.
+int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
+{
+    const uint64_t total_steps = (s.nchunks + 63) / 64;
+    if (total_steps == 0) return KPAL_OK;
+    const int K = ctx->k;
+    const uint32_t NB1 = 1u << (2 * K - 22);
+    const uint32_t REP = NB1 >= 256 ? 1u : 256u / NB1;
+    const uint32_t S1 = (uint32_t)kQuadRowWords / (NB1 * REP);
+    CHK(ensure(ctx, ctx->quad_meta, ((size_t)ctx->num_cu + 4 + 2048 + 512) * sizeof(uint32_t)));
+    uint32_t *nrounds1 = (uint32_t *)ctx->quad_meta.p;
+    uint32_t *error = nrounds1 + ctx->num_cu;
+    if (!ctx->quad_error_word) {
+        HIPCHK(hipMemsetAsync(error, 0, 4 * sizeof(uint32_t), ctx->stream));
+        ctx->quad_error_word = error;
+    }
+    // level 1: 16 waves x 7 wave-steps per tile bring 107 items per 128-slot row (26.7 per 32 at k = 16) for uniform
+    // k-mers; the sampled row loads say whether THIS feed needs a smaller tile, or (AUTO) the round-1 pipeline
+    static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
+    static const int candidates[] = {8, 7, 6, 3};
+    int steps1 = 0;
+    for (int c : candidates)
+        if (c == steps_env) steps1 = c;
+    std::vector<double> fine;                    // items per fine row of level 2 per wave-step of INPUT (sorted)
+    {
+        int chosen = 0;
+        const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 4, &chosen, &fine);
+        if (rc != KPAL_OK) return rc;
+        if (!steps1) steps1 = chosen;
+    }
+    const uint64_t tile_steps = 16ull * steps1;
+    const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
+    const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
+    const uint64_t tpb1 = (tiles1 + G1 - 1) / G1;
+    if (tpb1 > 0xFFFFull) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
+    // capacity (stride) of a level-1 workgroup's run of records per row: rounded up so that a unit of level 2 is a whole
+    // number of KiB -- a wave-step of quad2_scatter_kernel then never straddles two units
+    const uint64_t per_kib = 1024 / (S1 * 4);                                   // records per KiB: 2 (8 at k = 16)
+    const uint64_t cap1 = (tpb1 + per_kib - 1) / per_kib * per_kib;
+    if ((size_t)kQuadRowWords * 4 * G1 * cap1 > ctx->quad_pool_max && s.nchunks > 64) return kSplitBatch;
+    CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * cap1));
+    uint32_t *pool1 = (uint32_t *)ctx->residuals.p;
+    // level 2: ~4 workgroups per CU in total; workgroup (g2, c) takes `upw` of the REP x G1 units of coarse bucket c
+    const uint32_t units = REP * G1;
+    uint32_t G2 = std::max<uint32_t>(1, std::min<uint32_t>(units, (uint32_t)ctx->num_cu * 4 / NB1));
+    const uint32_t upw = (units + G2 - 1) / G2;
+    G2 = (units + upw - 1) / upw;
+    const uint64_t unit_cap = cap1 * S1 * 4;                                   // bytes
+    if ((uint64_t)upw * unit_cap >= (1ull << 32)) return set_err(KPAL_E_INVALID, "quad partition: batch too large");
+    // level-2 tile: 16 waves x steps2 KiB of level-1 records.  A wave-step of records holds 256 item slots, filled to
+    // f1 = (items of a level-1 tile) / 32768; a fine row (512 rows of 64 slots) receives its share of them.  Same queue
+    // model as level 1 (the 32 fullest fine rows are left to the spill list and the hot-item table).
+    constexpr int kWaves2 = 16;
+    static const int steps2_env = [] { const char *e = getenv("KPAL_QUAD_STEPS2"); return e ? atoi(e) : 0; }();
+    int steps2 = 2;
+    {
+        double all = 0.0;
+        for (double v : fine) all += v;
+        const double f1 = std::min(1.0, all * 16.0 * steps1 / (double)kQuadRowWords);
+        static const int candidates2[] = {8, 7, 6, 4, 3, 2};
+        std::vector<double> mu(fine.size() > 32 ? fine.size() - 32 : 0);
+        for (int c : candidates2) {
+            for (size_t b = 0; b < mu.size(); ++b) mu[b] = all > 0.0 ? fine[b] / all * (256.0 * f1) * kWaves2 * c : 0.0;
+            if (quad_expected_backlog(mu, 64) <= kQuadBacklogMax) {
+                steps2 = c;
+                break;
+            }
+        }
+        for (int c : candidates2)
+            if (c == steps2_env) steps2 = c;
+    }
+    const uint64_t tile2_bytes = (uint64_t)kWaves2 * steps2 * 1024;
+    const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
+    CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));
+    CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
+    // the staged forms of the histogram stage (four 16-bit counts per table entry: 8.6 GB at k = 15) reuse the level-1 pool's buffer:
+    // level 2 has read it completely before the histogram kernel starts (same stream)
+    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 8)));
+    pool1 = (uint32_t *)ctx->residuals.p;
+    uint32_t *stage = pool1;
+    uint32_t *pool2 = (uint32_t *)ctx->keys.p;
+    uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+#define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
+    LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
+           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table)
+    DISPATCH_K_13_16(ctx->k, {
+        if (steps1 == 8)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        else if (steps1 == 7)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        else if (steps1 == 6)
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        else
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        switch (steps2) {
+        case 8: KPAL_QUAD2_LAUNCH(8); break;
+        case 7: KPAL_QUAD2_LAUNCH(7); break;
+        case 6: KPAL_QUAD2_LAUNCH(6); break;
+        case 4: KPAL_QUAD2_LAUNCH(4); break;
+        case 3: KPAL_QUAD2_LAUNCH(3); break;
+        default: KPAL_QUAD2_LAUNCH(2); break;
+        }
+
+        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
+               G2, (uint32_t)tiles2, table, stage);
+        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 2048)), dim3(256), (const uint16_t *)stage, table);
+    });
+#undef KPAL_QUAD2_LAUNCH
+    return KPAL_OK;
+}

@@ -37,14 +37,7 @@ struct PartCfg {
     static constexpr uint32_t kKeyMask = (1u << kKeyBits) - 1u;
 };
 
-// One wave-step at absolute step index `step` (interior fast path chosen per wave).
-template <int K>
-__device__ __forceinline__ void part_step(const Span &s, uint64_t step, Chunk &carry, uint64_t &window, uint32_t &mask)
-{
-    const int lane = threadIdx.x & 63;
-    if (interior_range(s, step * 64, step * 64 + 64)) wave_step<K, false>(s, (int64_t)(step * 64 + lane), carry, window, mask);
-    else wave_step<K, true>(s, (int64_t)(step * 64 + lane), carry, window, mask);
-}
+// (part_step<K>: kpal_device.hpp)
 
 // ------------------------------------------------------------------------------------------
 // LDS staging of the ASCII scatter kernel (per-tile rows, one run per bucket per tile).
@@ -395,13 +388,7 @@ __device__ __forceinline__ void flush_lines(unsigned char *rows, uint32_t *pos, 
     }
 }
 
-// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
-// vector-memory counter, so line stores issued in a flush phase stay in flight while the next
-// tile is placed.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// (lds_barrier: kpal_device.hpp)
 
 // A3: scatter of an ASCII span.  Per tile (3 steps per wave, 24 KiB per workgroup): place, barrier,
 // copy-out, barrier.  Bound by the global store-run rate (one ~88-byte run per bucket per tile).

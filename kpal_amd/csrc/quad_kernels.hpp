@@ -35,7 +35,7 @@
 #pragma once
 #include <type_traits>
 
-#include "chunk_kernels.hpp"
+#include "kpal_device.hpp"
 
 namespace kpal {
 

@@ -3,7 +3,7 @@
 
 A row with `c` slots receives Poisson(rho * c) items per round, `c` leave with the record, the rest is carried to the
 next round: q' = max(0, q + X - c).  Prints mean(q) / E[max(X - c, 0)] -- the table `ratio` in
-kpal_amd/csrc/kpal_hip.hip (quad_expected_backlog), which the host uses to pick the tile size of a feed."""
+kpal_amd/csrc/kpal_quads.hip (quad_expected_backlog), which the host uses to pick the tile size of a feed."""
 from math import exp
 import numpy as np
 

@@ -1,5 +1,6 @@
 """Per-kernel register / spill / LDS summary from hipcc's -Rpass-analysis=kernel-resource-usage remarks.
-Usage: python tools/resusage.py [name-substring ...]   (compiles kpal_amd/csrc/kpal_hip.hip, no GPU needed)"""
+Usage: python tools/resusage.py UNIT [name-substring ...] [-DMACRO ...]
+(compiles kpal_amd/csrc/UNIT.hip -- kpal_quads, kpal_quads2, kpal_count, kpal_vec --, no GPU needed)"""
 import re
 import subprocess
 import sys
@@ -10,10 +11,10 @@ import __graft_entry__ as g
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ['hipcc'] + list(g.HIPCC_FLAGS) + ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', '/dev/null',
-                                         os.path.join(root, 'kpal_amd/csrc/kpal_hip.hip')] + \
-      [a for a in sys.argv[1:] if a.startswith('-D')]
+                                         os.path.join(root, 'kpal_amd/csrc/%s.hip' % sys.argv[1])] + \
+      [a for a in sys.argv[2:] if a.startswith('-D')]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
-want = [a for a in sys.argv[1:] if not a.startswith('-D')]
+want = [a for a in sys.argv[2:] if not a.startswith('-D')]
 cur = None
 rows = {}
 for line in out.splitlines():
