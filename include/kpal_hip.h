@@ -97,6 +97,11 @@ int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, ui
 int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
                        size_t n_records, int64_t *host_out);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
+/* Diagnostics (tests, A/B timing): the pipeline the last piece of the last feed actually took (a KPAL_STRATEGY_* value: AUTO
+ * resolves per feed size and input composition) and the tile sizes of the quad scatters (wave-steps per wave and tile of level 1 /
+ * level 2; 0 where not applicable).  The environment variables KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2, read when the context is
+ * created, force those tile sizes. */
+int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int *steps2);
 int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
 
 /* Deterministic synthetic reads (same bytes as oracle/kpal_oracle.c

@@ -69,6 +69,7 @@ SIGNATURES = {
     'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_count_last_plan': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_int, ctypes.c_int, _vp]),
     'kpal_balance': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
@@ -278,6 +279,13 @@ class Context(object):
         n = ctypes.c_uint64(0)
         _check(self._L.kpal_count_table(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def count_last_plan(self):
+        """-> (strategy name, steps1, steps2): the pipeline and quad tile sizes the last piece of the last feed took."""
+        st, s1, s2 = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _check(self._L.kpal_count_last_plan(self._h, ctypes.byref(st), ctypes.byref(s1), ctypes.byref(s2)))
+        names = {v: n for n, v in STRATEGY.items()}
+        return names.get(st.value, str(st.value)), s1.value, s2.value
 
     def count_table_view(self):
         ptr, n = self.count_table()

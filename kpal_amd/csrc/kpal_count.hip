@@ -24,6 +24,8 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
     if (ctx->quad_error_word) HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
     ctx->chunk_error_armed = false;
+    ctx->cached_steps1 = ctx->cached_steps2 = 0;
+    ctx->plan_strategy = ctx->plan_steps1 = ctx->plan_steps2 = 0;
     ctx->counting = true;
     return KPAL_OK;
 }
@@ -412,6 +414,10 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         const size_t len = std::min(piece, n - off);
         const size_t h = std::min(km1, halo + off);
         const Span s = make_span(addr + off, len, h);
+        if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS) {
+            ctx->plan_strategy = strat;
+            ctx->plan_steps1 = ctx->plan_steps2 = 0;
+        }
         if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
@@ -698,6 +704,15 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
         HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
         return set_err(KPAL_E_HIP, "quad partition: internal sizing error %u; counts are invalid", quad_error);
     }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int *steps2)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (strategy) *strategy = ctx->plan_strategy;
+    if (steps1) *steps1 = ctx->plan_steps1;
+    if (steps2) *steps2 = ctx->plan_steps2;
     return KPAL_OK;
 }
 

@@ -110,6 +110,9 @@ static int ctx_init(kpal_ctx *ctx, int device)
         }
     }
     if (const char *e = getenv("KPAL_LEVEL2")) ctx->level2_mode = atoi(e);
+    if (const char *e = getenv("KPAL_QUAD_STEPS")) ctx->quad_steps_forced = atoi(e);
+    if (const char *e = getenv("KPAL_QUAD_STEPS2")) ctx->quad_steps2_forced = atoi(e);
+    if (const char *e = getenv("KPAL_QUAD_VERBOSE")) ctx->quad_verbose = atoi(e) != 0;
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;

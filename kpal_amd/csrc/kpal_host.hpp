@@ -80,6 +80,15 @@ struct kpal_ctx {
     DevBuf quad_meta, quad_meta2;            // quad path: rounds per workgroup, error word; level-2 rounds (k >= 13)
     uint32_t *quad_error_word = nullptr;
     bool chunk_error_armed = false;
+    int quad_steps_forced = 0, quad_steps2_forced = 0;   // KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2 at context creation (tests, A/B): tile sizes of the quad scatters
+    bool quad_verbose = false;               // KPAL_QUAD_VERBOSE
+    // what the last piece of the last feed took (kpal_count_last_plan): strategy, wave-steps per wave and tile of level 1 / level 2
+    int plan_strategy = 0, plan_steps1 = 0, plan_steps2 = 0;
+    // tile sizes chosen from the sample of an earlier feed of this count (kpal_count_begin clears them): a file streamed in
+    // many feeds is sampled once per 16 feeds, not once per feed (the sample costs a D2H copy + a host synchronisation)
+    int cached_steps1 = 0, cached_steps2 = 0;
+    uint32_t cached_uses = 0;
+    size_t cached_bytes = 0;
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     alignas(16) unsigned char chunk_pool_sent[96] = {};   // (ChunkPool) what the device copy of the pool descriptor holds
     void *chunk_pool_dev = nullptr;

@@ -77,7 +77,7 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
     const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
     // the 32 fullest rows are left out: a handful of very hot rows (poly-A, an adapter shared by every read) cannot be
     // helped by smaller tiles -- their items are counted in the workgroup's hot-item table instead
-    static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
+    const bool verbose = ctx->quad_verbose;
     double budget = kQuadBacklogMax;
     std::vector<double> per_step((size_t)buckets);
     for (int b = 0; b < buckets; ++b) per_step[b] = h[b] / sampled_steps;   // items per row per wave-step
@@ -148,16 +148,27 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // 1/64 sample say what THIS input brings.  The largest STEPS whose expected overflow per round stays well inside the
     // spill list is used (KPAL_QUAD_STEPS forces one: A/B timing, tests).  16 waves = four per SIMD with 128 registers each
     // (8 record vectors + 7 prefetched chunks live): measured 3 % faster than 8 waves x 13 steps and the records are fuller.
-    static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
     static const int candidates[] = {8, 7, 6, 4, 3, 2, 1};
     constexpr int waves = 16;
     int steps = 0;
     for (int c : candidates)
-        if (c == steps_env) steps = c;
+        if (c == ctx->quad_steps_forced) steps = c;
+    // a later feed of the same count of about the same size reuses the tile size of the sampled one (re-sampled every 16 feeds)
+    const size_t feed_bytes = (size_t)(s.hi - s.emit_from);
+    if (!steps && ctx->cached_steps1 && ctx->cached_uses < 16 && feed_bytes <= 2 * ctx->cached_bytes && 2 * feed_bytes >= ctx->cached_bytes) {
+        steps = ctx->cached_steps1;
+        ++ctx->cached_uses;
+    }
     if (!steps) {
         const int rc = quad_choose_steps(ctx, s, load, buckets, slots, waves, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
         if (rc != KPAL_OK) return rc;
+        ctx->cached_steps1 = steps;
+        ctx->cached_uses = 0;
+        ctx->cached_bytes = feed_bytes;
     }
+    ctx->plan_strategy = KPAL_STRATEGY_PARTITION_QUADS;
+    ctx->plan_steps1 = steps;
+    ctx->plan_steps2 = 0;
     const uint64_t tile_steps = (uint64_t)waves * steps;
     const uint64_t tiles = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ctx->num_cu, tiles);
@@ -185,8 +196,7 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
                (const uint32_t *)nrounds, G, (uint32_t)tpb, table, (uint32_t *)nullptr);
     });
 #undef KPAL_QUAD_LAUNCH
-    static const bool verbose = [] { const char *e = getenv("KPAL_QUAD_VERBOSE"); return e && atoi(e) != 0; }();
-    if (verbose) {   // diagnostics: tile size chosen, tiles abandoned to the direct path
+    if (ctx->quad_verbose) {   // diagnostics: tile size chosen, tiles abandoned to the direct path
         uint32_t st[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(st, error, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

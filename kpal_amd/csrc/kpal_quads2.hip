@@ -22,13 +22,19 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     }
     // level 1: 16 waves x 7 wave-steps per tile bring 107 items per 128-slot row (26.7 per 32 at k = 16) for uniform
     // k-mers; the sampled row loads say whether THIS feed needs a smaller tile, or (AUTO) the round-1 pipeline
-    static const int steps_env = [] { const char *e = getenv("KPAL_QUAD_STEPS"); return e ? atoi(e) : 0; }();
     static const int candidates[] = {8, 7, 6, 3};
     int steps1 = 0;
     for (int c : candidates)
-        if (c == steps_env) steps1 = c;
+        if (c == ctx->quad_steps_forced) steps1 = c;
     std::vector<double> fine;                    // items per fine row of level 2 per wave-step of INPUT (sorted)
-    {
+    // a later feed of the same count of about the same size reuses the tile sizes of the sampled one (re-sampled every 16 feeds)
+    const size_t feed_bytes = (size_t)(s.hi - s.emit_from);
+    const bool cached = ctx->cached_steps1 && ctx->cached_steps2 && ctx->cached_uses < 16 && feed_bytes <= 2 * ctx->cached_bytes &&
+                        2 * feed_bytes >= ctx->cached_bytes;
+    if (cached) {
+        if (!steps1) steps1 = ctx->cached_steps1;
+        ++ctx->cached_uses;
+    } else {
         int chosen = 0;
         const int rc = quad_choose_steps(ctx, s, error + 4, (int)(NB1 * REP), (int)S1, 16, candidates, 4, &chosen, &fine);
         if (rc != KPAL_OK) return rc;
@@ -57,9 +63,10 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     // f1 = (items of a level-1 tile) / 32768; a fine row (512 rows of 64 slots) receives its share of them.  Same queue
     // model as level 1 (the 32 fullest fine rows are left to the spill list and the hot-item table).
     constexpr int kWaves2 = 16;
-    static const int steps2_env = [] { const char *e = getenv("KPAL_QUAD_STEPS2"); return e ? atoi(e) : 0; }();
     int steps2 = 2;
-    {
+    if (cached) {
+        steps2 = ctx->cached_steps2;
+    } else {
         double all = 0.0;
         for (double v : fine) all += v;
         const double f1 = std::min(1.0, all * 16.0 * steps1 / (double)kQuadRowWords);
@@ -72,9 +79,16 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
                 break;
             }
         }
-        for (int c : candidates2)
-            if (c == steps2_env) steps2 = c;
+        ctx->cached_steps1 = steps1;
+        ctx->cached_steps2 = steps2;
+        ctx->cached_uses = 0;
+        ctx->cached_bytes = feed_bytes;
     }
+    for (int c : {8, 7, 6, 4, 3, 2})
+        if (c == ctx->quad_steps2_forced) steps2 = c;
+    ctx->plan_strategy = KPAL_STRATEGY_PARTITION2_QUADS;
+    ctx->plan_steps1 = steps1;
+    ctx->plan_steps2 = steps2;
     const uint64_t tile2_bytes = (uint64_t)kWaves2 * steps2 * 1024;
     const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
     CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));

@@ -240,6 +240,8 @@ static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof,
     Partial *pp = (Partial *)ctx->partials.p;
     Partial *res_d = (Partial *)ctx->result.p;
     const int2 *dt = (const int2 *)ctx->scratch[3].p;
+    // a diagonal block writes only its 10 tiles with gj <= gi; the reduction below runs over all 16: the other six read zeros
+    HIPCHK(hipMemsetAsync(pp, 0, part_d * sizeof(Partial), ctx->stream));
     LAUNCH(ctx, "gram_mfma", (gram_mfma_kernel<true>), dim3(gx_d, nd), dim3(256), prof, P, n, dt, pp);
     LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(nd * 4096), dim3(256), (const Partial *)pp, gx_d, res_d);
     if (no) {

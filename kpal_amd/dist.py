@@ -73,12 +73,18 @@ class TableReducer(object):
                 bound by the per-link rate) -- whenever the LARGEST per-rank bin times the number of ranks
                 fits 31 bits (one scalar all-reduce(MAX) decides, identically on every rank); otherwise
                 that step falls back to int64.  Integer sums: bit-exact either way.
-    ``overlap`` False (default): reduce, then balance, inside the step.  True: the table is copied to a
-                second buffer and reduced asynchronously while the NEXT step counts into the table; the
+    ``overlap`` False (default): reduce, then balance, inside the step.  True: the table is copied to one of
+                TWO side buffers and reduced asynchronously while the NEXT step counts into the table; the
                 reduce of step i is waited for (and balanced) at the start of step i+1's reduce, the last
-                one by ``drain()``.  Costs one extra table of HBM.
+                one by ``drain()``.  The buffers alternate: the balanced result of step i (``result()``,
+                balanced asynchronously on the context's stream) stays untouched while step i+1's table is
+                copied into the other one, and is only overwritten by step i+2's copy -- after the
+                ``sync()`` that opens ``reduce_step`` i+2 has waited for that balance.  ``result()`` is valid
+                from ``drain()`` / the next ``reduce_step`` until the ``reduce_step`` after that.
+                Costs two extra tables of HBM.
 
-    Both options default off until a multi-GPU scaling run has validated them (SCALE_r*.json)."""
+    (bench.py's default multi-GPU path is the in-library RCCL reduce, ``Context.comm_*``; this class is the
+    torch.distributed variant and the one the gloo CPU tests drive.)"""
 
     def __init__(self, table, sync=None, balance=None, mode='int64', overlap=False, dst=0, group=None):
         if mode not in ('int64', 'u32'):
@@ -90,7 +96,8 @@ class TableReducer(object):
         self.overlap = bool(overlap)
         self.dst = dst
         self.group = group
-        self._buf = None          # overlap / u32: the buffer the merged counts end up in
+        self._bufs = [None, None]  # overlap / u32: side buffers the merged counts end up in (alternating)
+        self._turn = 0
         self._pending = None      # (work, tensor32 or None)
         self._result = table
         self.steps_u32 = 0
@@ -118,6 +125,14 @@ class TableReducer(object):
         hi, neg_lo = int(m[0]), int(m[1])
         return neg_lo <= 0 and hi * world < 2 ** 31
 
+    def _side_buffer(self):
+        """The side buffer whose previous content (the result of two steps ago) may be overwritten."""
+        import torch
+        self._turn ^= 1
+        if self._bufs[self._turn] is None:
+            self._bufs[self._turn] = torch.empty_like(self.table)
+        return self._bufs[self._turn]
+
     def _start(self):
         """Launch the collective for the current table; returns (work or None, source tensor, is32)."""
         import torch
@@ -128,10 +143,8 @@ class TableReducer(object):
             src = self.table.to(torch.int32)
             self.steps_u32 += 1
         elif self.overlap:
-            if self._buf is None:
-                self._buf = torch.empty_like(self.table)
-            self._buf.copy_(self.table)
-            src = self._buf
+            src = self._side_buffer()
+            src.copy_(self.table)
             self.steps_int64 += 1
         else:
             src = self.table
@@ -147,11 +160,10 @@ class TableReducer(object):
         if work is not None:
             work.wait()
         if use32:
-            if self._buf is None:
-                self._buf = torch.empty_like(self.table)
+            buf = self._side_buffer()
             if rank == self.dst:
-                self._buf.copy_(src)          # int32 -> int64
-            self._result = self._buf
+                buf.copy_(src)                # int32 -> int64
+            self._result = buf
         else:
             self._result = src
         self._torch_sync()                     # the context's stream may touch the result now

@@ -609,38 +609,73 @@ static void *count_worker(void *arg)
     return NULL;
 }
 
+typedef struct {
+    int64_t **hists;
+    int64_t *counts;
+    int T;
+    size_t lo, hi;
+} merge_job;
+
+static void *merge_worker(void *arg)
+{
+    merge_job *m = (merge_job *)arg;
+    for (int t = 0; t < m->T; t++)
+        for (size_t i = m->lo; i < m->hi; i++) m->counts[i] += m->hists[t][i];
+    return NULL;
+}
+
 ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, int threads, int64_t *counts)
 {
     if (k < 1 || k > 31 || threads < 1) return -1;
     const size_t bins = (size_t)1 << (2 * k);
-    int T = threads > 256 ? 256 : threads;
+    const int T = threads > 256 ? 256 : threads;
     const int shared = bins * sizeof(int64_t) > ((size_t)1 << 20);
+    int rc = 0;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    char *joinable = (char *)calloc(T, 1);
     count_job *jobs = (count_job *)malloc(sizeof(count_job) * T);
+    merge_job *merges = (merge_job *)malloc(sizeof(merge_job) * T);
     int64_t **hists = (int64_t **)calloc(T, sizeof(int64_t *));
-    if (!th || !jobs || !hists) return -2;
-    for (int t = 0; t < T; t++) {
-        if (!shared) {
-            hists[t] = (int64_t *)calloc(bins, sizeof(int64_t));
-            if (!hists[t]) return -2;
-        }
-        jobs[t].buf = buf;
-        jobs[t].begin = n * (size_t)t / T;
-        jobs[t].end = n * (size_t)(t + 1) / T;
-        jobs[t].k = k;
-        jobs[t].hist = shared ? counts : hists[t];
-        jobs[t].shared = shared;
-        pthread_create(&th[t], NULL, count_worker, &jobs[t]);
+    /* every buffer exists before the first thread starts: a failed allocation never leaves a thread running */
+    if (!th || !joinable || !jobs || !merges || !hists) rc = -2;
+    for (int t = 0; rc == 0 && !shared && t < T; t++) {
+        hists[t] = (int64_t *)calloc(bins, sizeof(int64_t));
+        if (!hists[t]) rc = -2;
     }
-    for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
-    if (!shared) {
+    if (rc == 0) {
         for (int t = 0; t < T; t++) {
-            for (size_t i = 0; i < bins; i++) counts[i] += hists[t][i];
-            free(hists[t]);
+            jobs[t].buf = buf;
+            jobs[t].begin = n * (size_t)t / T;
+            jobs[t].end = n * (size_t)(t + 1) / T;
+            jobs[t].k = k;
+            jobs[t].hist = shared ? counts : hists[t];
+            jobs[t].shared = shared;
+            joinable[t] = pthread_create(&th[t], NULL, count_worker, &jobs[t]) == 0;
+            if (!joinable[t]) count_worker(&jobs[t]);   /* no thread to be had: this piece on the calling thread */
         }
+        for (int t = 0; t < T; t++)
+            if (joinable[t]) pthread_join(th[t], NULL);
     }
+    if (rc == 0 && !shared) {
+        /* private histograms (k <= 8): merged in parallel, thread t sums bins [lo, hi) of all of them */
+        for (int t = 0; t < T; t++) {
+            merges[t].hists = hists;
+            merges[t].counts = counts;
+            merges[t].T = T;
+            merges[t].lo = bins * (size_t)t / T;
+            merges[t].hi = bins * (size_t)(t + 1) / T;
+            joinable[t] = pthread_create(&th[t], NULL, merge_worker, &merges[t]) == 0;
+            if (!joinable[t]) merge_worker(&merges[t]);
+        }
+        for (int t = 0; t < T; t++)
+            if (joinable[t]) pthread_join(th[t], NULL);
+    }
+    if (hists)
+        for (int t = 0; t < T; t++) free(hists[t]);
     free(hists);
+    free(merges);
     free(jobs);
+    free(joinable);
     free(th);
-    return 0;
+    return rc;
 }

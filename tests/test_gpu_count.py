@@ -209,13 +209,15 @@ def test_two_level_batch_halving():
     c2.close()
 
 
-@pytest.mark.parametrize('steps', ['8', '7', '4', '2', '1'])
+@pytest.mark.parametrize('steps', ['8', '7', '6', '4', '3', '2', '1'])
 def test_quad_tile_sizes_against_oracle(steps):
-    """Every tile size the quad scatters are compiled for (KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2: normally chosen per feed
-    from a sample of the row loads), one- and two-level, on uniform, AT-rich and low-complexity input: bit-exact."""
+    """Every tile size the quad scatters are compiled for (KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2, read when the context is
+    created; normally chosen per feed from a sample of the row loads), one- and two-level, on uniform and AT-rich input with a
+    homopolymer stretch: bit-exact, and kpal_count_last_plan confirms that the forced size is the one that ran."""
     from kpal_amd import _native
+    steps2 = {'1': '2'}.get(steps, steps)
     os.environ['KPAL_QUAD_STEPS'] = steps
-    os.environ['KPAL_QUAD_STEPS2'] = {'1': '2', '2': '3'}.get(steps, steps)
+    os.environ['KPAL_QUAD_STEPS2'] = steps2
     try:
         c2 = _native.Context(_native.default_device())
     finally:
@@ -226,9 +228,16 @@ def test_quad_tile_sizes_against_oracle(steps):
     at_rich = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=5 << 20, p=[.4, .1, .1, .4])].copy()
     at_rich[::151] = 10
     at_rich[2 << 20:(2 << 20) + 300000] = ord('A')
+    level1_sizes = {'partition_quads': (8, 7, 6, 4, 3, 2, 1), 'partition2_quads': (8, 7, 6, 3)}
     for k, strategy in ((12, 'partition_quads'), (10, 'partition_quads'), (13, 'partition2_quads'), (14, 'partition2_quads')):
         for data in (uniform, at_rich):
             assert np.array_equal(c2.count_bytes(k, data, strategy), oracle.count_flat(data, k, threads=8)), (k, strategy, steps)
+            name, s1, s2 = c2.count_last_plan()
+            assert name == strategy
+            if int(steps) in level1_sizes[strategy]:
+                assert s1 == int(steps), (strategy, steps, s1)
+            if strategy == 'partition2_quads':
+                assert s2 == int(steps2), (strategy, steps2, s2)
     c2.close()
 
 
@@ -348,8 +357,10 @@ def test_skewed_input_homopolymer(ctx):
 
 @pytest.mark.parametrize('k,n_reads', [(12, 100_000_000), (9, 20_000_000)])
 def test_full_size_properties_k12(ctx, k, n_reads):
-    """BASELINE config 2 at full size (100 M x 150 bp, k = 12): exact total, linearity over
-    shards, and agreement with the threaded oracle on a 2 M-read prefix."""
+    """BASELINE config 2 at full size (100 M x 150 bp, k = 12; and 20 M reads at k = 9) through AUTO (the quad pipeline,
+    asserted): exact total, linearity over two shards, the chunked pipeline bin for bin at full size, the global-atomic kernel
+    on a 10 M-read prefix, balance of every bin against the oracle -- and the WHOLE input (15.1 GB at k = 12) downloaded and
+    counted by the all-cores CPU oracle, every bin compared."""
     from kpal_amd import dist
     nbytes = n_reads * 151
     d = ctx.alloc(nbytes)
@@ -357,6 +368,7 @@ def test_full_size_properties_k12(ctx, k, n_reads):
         ctx.synth_reads_device(2, 0, n_reads, 150, d)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
+        assert ctx.count_last_plan()[0] == 'partition_quads'
         full = ctx.count_finish()
         assert full.sum() == n_reads * (150 - k + 1)
         assert full.min() >= 0
@@ -369,8 +381,8 @@ def test_full_size_properties_k12(ctx, k, n_reads):
             ctx.count_feed_device(d + f * 151, n * 151)
             parts.append(ctx.count_finish())
         np.testing.assert_array_equal(parts[0] + parts[1], full)
-        # the two partition pipelines agree bin for bin at full size (key indices beyond 2^31)
-        for strat in ('partition', 'partition_chunked', 'partition_quads'):
+        # the chunked round-1 pipeline agrees bin for bin at full size (key indices beyond 2^31)
+        for strat in ('partition_chunked',):
             ctx.count_begin(k, strat)
             ctx.count_feed_device(d, nbytes)
             np.testing.assert_array_equal(ctx.count_finish(), full, err_msg=strat)
@@ -381,12 +393,13 @@ def test_full_size_properties_k12(ctx, k, n_reads):
         ctx.count_begin(k)
         ctx.count_feed_device(d, 10_000_000 * 151)
         np.testing.assert_array_equal(ctx.count_finish(), a)
-        # oracle on a 2 M-read prefix
-        pre = np.empty(2_000_000 * 151, dtype=np.uint8)
-        ctx.d2h(pre, d)
-        ctx.count_begin(k)
-        ctx.count_feed_device(d, pre.size)
-        np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(pre, k, threads=8))
+        # the oracle on the WHOLE input: all reads downloaded, counted on the host cores (shared table, 16 threads)
+        host = np.empty(nbytes, dtype=np.uint8)
+        ctx.d2h(host, d)
+        want = oracle.count_flat(host, k, threads=16)
+        del host
+        np.testing.assert_array_equal(full, want)
+        del want
         # balance on the device table doubles the total (klib.py:285-298)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
@@ -402,10 +415,13 @@ def test_full_size_properties_k12(ctx, k, n_reads):
 
 
 def test_full_size_k15(ctx):
-    """BASELINE config 4 at its stated size (k = 15, 100 M x 150 bp reads, seed 4, 8 GiB table) through
-    AUTO (two-level path: coarse_scatter<15> -> chunk_key_lines -> chunk_hist at 64 coarse buckets):
-    exact total, linearity over two shards (compared on the device), bin for bin against the oracle on
-    a 2 M-read prefix and against the global-atomic kernel on a 10 M-read prefix."""
+    """BASELINE config 4 at its stated size (k = 15, 100 M x 150 bp reads, seed 4, 8 GiB table).  AUTO takes the two-level
+    QUAD pipeline here (quad_scatter<15> -> quad2_scatter -> quad_hist -> quad2_finalize; asserted through
+    kpal_count_last_plan) -- the pipeline bench.py --k 15 measures.  Checked at 100 M reads: exact total, no negative bin, and
+    the whole 8 GiB table bin for bin against the round-1 two-level pipeline ('partition2': coarse_scatter -> chunk_key_lines
+    -> chunk_hist, independent kernels and data layout) run on the same buffer by a second context, compared on the device;
+    linearity over two half-shards.  With the quad pipeline FORCED on prefixes AUTO would hand to 'partition2': bin for bin
+    against the global-atomic kernel (10 M reads) and against the CPU oracle (2 M reads)."""
     torch = pytest.importorskip('torch')
     from kpal_amd import _native, dist
     k, n_reads = 15, 100_000_000
@@ -416,16 +432,26 @@ def test_full_size_k15(ctx):
         ctx.synth_reads_device(4, 0, n_reads, 150, d)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
+        assert ctx.count_last_plan()[0] == 'partition2_quads'
         ctx.count_finish(to_host=False)
         ctx.sync()
         full = dist.table_as_tensor(ctx)
         assert full.numel() == 4 ** k
         assert int(full.sum()) == n_reads * (150 - k + 1)
         assert int(full.min()) >= 0
-        # linearity: the two half-shards counted by a second context add up to the same table
+        # the same 100 M reads through the round-1 two-level pipeline: every one of the 4^15 bins
+        other.count_begin(k, 'partition2')
+        other.count_feed_device(d, nbytes)
+        assert other.count_last_plan()[0] == 'partition2'
+        other.count_finish(to_host=False)
+        other.sync()
+        assert torch.equal(dist.table_as_tensor(other), full)
+        torch.cuda.synchronize()
+        # linearity: the two half-shards counted by the second context (quad pipeline) add up to the same table
         half = n_reads // 2
         other.count_begin(k)
         other.count_feed_device(d, half * 151)
+        assert other.count_last_plan()[0] == 'partition2_quads'
         other.count_finish(to_host=False)
         other.sync()
         acc = dist.table_as_tensor(other).clone()
@@ -438,10 +464,11 @@ def test_full_size_k15(ctx):
         assert torch.equal(acc, full)
         del acc
         torch.cuda.synchronize()
-        # bin for bin with the global-atomic kernel on a 10 M-read prefix (both tables stay on the device)
+        # the quad pipeline, forced, bin for bin with the global-atomic kernel on a 10 M-read prefix (both tables stay on the device)
         pre10 = 10_000_000 * 151
-        ctx.count_begin(k)
+        ctx.count_begin(k, 'partition2_quads')
         ctx.count_feed_device(d, pre10)
+        assert ctx.count_last_plan()[0] == 'partition2_quads'
         ctx.count_finish(to_host=False)
         other.count_begin(k, 'global_atomic')
         other.count_feed_device(d, pre10)
@@ -450,10 +477,10 @@ def test_full_size_k15(ctx):
         other.sync()
         assert torch.equal(dist.table_as_tensor(ctx), dist.table_as_tensor(other))
         torch.cuda.synchronize()
-        # bin for bin with the oracle on a 2 M-read prefix
+        # the quad pipeline, forced, bin for bin with the oracle on a 2 M-read prefix
         pre = np.empty(2_000_000 * 151, dtype=np.uint8)
         ctx.d2h(pre, d)
-        ctx.count_begin(k)
+        ctx.count_begin(k, 'partition2_quads')
         ctx.count_feed_device(d, pre.size)
         got = ctx.count_finish()
         want = oracle.count_flat(pre, k, threads=8)

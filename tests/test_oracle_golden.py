@@ -210,3 +210,30 @@ def test_g10_summaries_merge_shrink(golden_summaries):
     for m in g['merges']:
         l, r = z['g10_%d' % m['left']], z['g10_%d' % m['right_reversed']][::-1]
         np.testing.assert_array_equal(oracle.merge(l, r, m['merger']), z[m['key']], err_msg=m['key'])
+
+
+@pytest.mark.parametrize('target', ['sanitize_asan', 'sanitize_tsan'])
+def test_oracle_sanitized(target, tmp_path):
+    """the CPU restatement under AddressSanitizer + UBSan, and its N-thread count (private
+    histograms + parallel merge; shared table with relaxed atomic adds) under ThreadSanitizer (oracle/Makefile targets
+    sanitize_asan / sanitize_tsan, driver oracle/sanitize_driver.c).  CPU only: sanitizers are not available on the GPU pool."""
+    import shutil
+    import subprocess
+    odir = os.path.dirname(os.path.abspath(oracle.__file__))
+    exe = str(tmp_path / target)
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    flags = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined'] if target == 'sanitize_asan' else ['-fsanitize=thread']
+    build = subprocess.run(['gcc', '-O1', '-g', '-std=c11', '-fno-omit-frame-pointer'] + flags +
+                           ['-o', exe, os.path.join(odir, 'sanitize_driver.c'), os.path.join(odir, 'kpal_oracle.c'), '-lm', '-lpthread'],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if build.returncode != 0 and b'sanitize' in build.stdout.lower() and (b'cannot find' in build.stdout or b'not supported' in build.stdout):
+        pytest.skip('sanitizer runtime not installed: %s' % build.stdout.decode()[-300:])
+    assert build.returncode == 0, build.stdout.decode()[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1', TSAN_OPTIONS='halt_on_error=1 exitcode=66')
+    env.pop('LD_PRELOAD', None)
+    run = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = run.stdout.decode()
+    if run.returncode != 0 and 'unexpected memory mapping' in out:
+        pytest.skip('ThreadSanitizer cannot map its shadow here (ASLR setting of the container)')
+    assert run.returncode == 0 and 'SANITIZE_OK' in out, out[-3000:]
