@@ -1,25 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- Gbases/s of k-mer counting (k=12, 150 bp synthetic reads) on N MI355X.
 
-Default workload (BASELINE.json metric, config 2 / 3): a "step" is one pass of the hot path over this
-rank's resident batch of synthetic reads: zero the 4^k table, count every k-mer
-(kpal_count_feed_device), [N>1: one RCCL reduce of the count tables to rank 0], balance the table
-(Profile.balance).  Inputs are generated on the device before the timed region (HBM-resident); weak
-scaling: every rank holds --reads reads.
+Default workload (BASELINE.json metric, config 2 / 3): a "step" is one pass of the hot path over this rank's resident
+batch of synthetic reads: zero the 4^k table, count every k-mer (kpal_count_feed_device), [N>1: ONE RCCL reduce of the
+count tables to rank 0 -- ncclReduce(int64, sum) issued by libkpal_hip.so on its own HIP streams], balance the (merged)
+table (Profile.balance).  Inputs are generated on the device before the timed region (HBM-resident); weak scaling:
+every rank holds --reads reads.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--k 12]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
---workload matrix (BASELINE config 5, one GPU): 64 profiles at k = 12 (profile p = 2 M reads, seed 100+p)
-resident in HBM, a step = one kdistlib.distance_matrix value computation (kpal_distance_matrix_device).
+--gpus N > 1 started as a plain command spawns the N ranks itself (python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>) BEFORE anything touches the GPU, relays rank
+0's JSON line and exits with the ranks' status; started under torch.distributed.run (RANK / WORLD_SIZE set) it is a rank.
 
-Rank 0 prints ONE JSON line (see DESIGN.md section 5 for the field definitions).
+The default one-GPU run appends to its JSON line, after the headline measurement, `extra`: BASELINE config 4 (k = 15,
+same 100 M reads), config 5 (64-profile distance matrix at k = 12, multiset prod and euclidean), each with its own
+ms_per_step / roofline / parity flag, and `end_to_end` (host-resident input: H2D, kernels, D2H of the table) for
+config 2.  --no-extra skips them; --workload matrix runs config 5 alone as the headline.
+
+Rank 0 prints ONE JSON line (DESIGN.md section 5 defines the fields).
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 FP64_VALU_PEAK_T = 39.3    # fp64 vector lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (78.6 TFLOP/s with FMA = half the guide's 157.3 TF fp32 vector rate)
 FP64_MFMA_PEAK_T = 78.6    # fp64 matrix TFLOP/s (v_mfma_f64_16x16x4_f64: 2048 flop per 64 SIMD-cycles x 1024 SIMDs x 2.4 GHz)
-PROFILE_DIR = os.path.join(ROOT, 'profiles', 'r2')
+PROFILE_DIR = os.path.join(ROOT, 'profiles', 'r3')
 
 
 def source_sha():
@@ -45,36 +51,90 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, k, input_bytes_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, gfx950 correction applied), scaled to this run's input bytes per launch.  PMC counters
-    cannot be read from inside the bench process, so this is a PROFILE of the same command, not a
-    measurement of this run: it is only reported when the profile was taken from the same kernel
-    sources (src_sha), else None with a note."""
-    info = {'traffic': None, 'traffic_source': None, 'traffic_profile_head': None, 'traffic_profile_src_sha': None}
-    path = os.path.join(PROFILE_DIR, 'pmc_hbm_traffic%s.json' % ('' if k == 12 else '_k%d' % k))
+# ----------------------------------------------------------------------------------------------------------------------
+# committed counter profiles (rocprofv3 --pmc passes of this command, tools/profile_round.sh)
+# ----------------------------------------------------------------------------------------------------------------------
+def _load_profile(name):
     try:
-        with open(path) as fh:
-            prof = json.load(fh)
+        with open(os.path.join(PROFILE_DIR, name)) as fh:
+            return json.load(fh)
     except (OSError, ValueError):
-        info['traffic_source'] = 'no committed counter profile for k=%d' % k
+        return None
+
+
+def _kernel_row(prof, kernel, k):
+    """The row of `kernel` (bench's short name, e.g. quad_scatter) in a per-kernel profile."""
+    for name, rec in prof['kernels'].items():
+        if ('::%s_kernel' % kernel) in name and (('<%d' % k) in name or '<' not in name):
+            return rec
+    return None
+
+
+def pmc_traffic(kernels, dom, k, input_bytes_per_step):
+    """HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction applied), scaled to
+    this run's input bytes: `traffic` per launch of the dominant kernel, `traffic_step` = the sum over the kernels of a
+    step.  PMC counters cannot be read from inside the bench process, so this is a PROFILE of the same command, not a
+    measurement of this run: it is only reported when the profile was taken from the same kernel sources (src_sha)."""
+    info = {'traffic': None, 'traffic_step': None, 'traffic_source': None, 'traffic_profile_src_sha': None}
+    fname = 'pmc_hbm_traffic%s.json' % ('' if k == 12 else '_k%d' % k)
+    prof = _load_profile(fname)
+    if prof is None:
+        info['traffic_source'] = 'no committed counter profile profiles/r3/%s' % fname
         return info
-    info['traffic_profile_head'] = prof.get('head')
     info['traffic_profile_src_sha'] = prof.get('src_sha')
     here = source_sha()
     if prof.get('src_sha') != here:
-        info['traffic_source'] = '%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (
-            os.path.relpath(path, ROOT), prof.get('src_sha'), here)
+        info['traffic_source'] = 'profiles/r3/%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (fname, prof.get('src_sha'), here)
         return info
-    for name, rec in prof['kernels'].items():
-        if ('::%s_kernel' % kernel) in name and ('<%d' % k) in name:
-            info['traffic'] = rec['hbm_bytes_per_dispatch_corrected'] * input_bytes_per_launch / prof['input_bytes_per_launch_avg']
-            info['traffic_source'] = '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, scaled per launch)' % os.path.relpath(path, ROOT)
-            return info
-    info['traffic_source'] = '%s has no row for %s' % (os.path.relpath(path, ROOT), kernel)
+    scale = input_bytes_per_step / prof['input_bytes_per_launch_avg']
+    per_kernel, total = {}, 0.0
+    for name in kernels:
+        row = _kernel_row(prof, name, k)
+        if row is None:
+            continue
+        # bytes that scale with the input (pools) and bytes that do not (tables) are not separated by the counters: the profile
+        # is taken at --reads 20 M (k = 12) / 40 M (k = 15) and scaled linearly -- table terms are over-scaled, noted in DESIGN
+        per_kernel[name] = row['hbm_bytes_per_dispatch_corrected'] * row['dispatches'] / max(prof['launches'], 1) * scale
+        total += per_kernel[name]
+    if dom in per_kernel:
+        launches_per_step = kernels[dom][1]
+        info['traffic'] = per_kernel[dom] / max(launches_per_step, 1)
+    info['traffic_step'] = total
+    info['traffic_by_kernel_per_step'] = per_kernel
+    info['traffic_source'] = ('profiles/r3/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, '
+                              'scaled by input bytes)' % fname)
     return info
 
 
+def pmc_limiter(dom, k):
+    """What limits the dominant kernel according to the committed SQ counter pass (pmc_lds_quad.json, same kernel sources): the
+    busiest of the VALU, the LDS and -- from the traffic pass -- the HBM interface."""
+    prof = _load_profile('pmc_lds_quad.json' if k == 12 else 'pmc_lds_quad_k%d.json' % k)
+    if prof is None or prof.get('src_sha') != source_sha():
+        return None
+    row = _kernel_row(prof, dom, k)
+    if not row or not row.get('SQ_BUSY_CYCLES'):
+        return None
+    # SQ_BUSY_CYCLES is summed over the 32 shader engines: / 32 = the kernel's duration in cycles; SQ_LDS_IDX_ACTIVE is summed
+    # over the 256 CUs (tools/profile_numbers.py uses the same normalisation); wave-level shares are taken against SQ_WAVE_CYCLES
+    cyc = row['SQ_BUSY_CYCLES'] / 32.0
+    waves = row.get('SQ_WAVE_CYCLES') or 0.0
+    out = {'source': 'profiles/r3/pmc_lds_quad%s.json' % ('' if k == 12 else '_k%d' % k)}
+    if waves:
+        out['valu_issue_share_of_wave_cycles'] = row.get('SQ_ACTIVE_INST_VALU', 0.0) / waves
+        out['waiting_share_of_wave_cycles'] = row.get('SQ_WAIT_ANY', 0.0) / waves
+    if row.get('SQ_LDS_IDX_ACTIVE') and cyc:
+        out['lds_busy_share'] = row['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc
+        out['lds_bank_conflict_share_of_lds_busy'] = row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE']
+    busiest = max((('LDS', out.get('lds_busy_share') or 0.0), ('VALU issue (x waves per SIMD)', (out.get('valu_issue_share_of_wave_cycles') or 0.0) * 4.0)),
+                  key=lambda t: t[1])
+    out['busiest_unit'] = busiest[0]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle port; reported next to the GPU number, never the target)
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(k, read_len, budget_reads):
     """CPU figures next to the GPU number (reported baselines, never the target):
     the oracle's C port (kpal/klib.py:149-170 restated) on a bounded sample of the same workload with 1
@@ -119,94 +179,335 @@ def cpu_baseline(k, read_len, budget_reads):
     }
 
 
-def matrix_workload(args):
-    """BASELINE config 5 on one GPU: value = Gterms/s of the 64 x 64 lower triangle (2016 pairs x 4^12 bins)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: the 64-profile distance matrix
+# ----------------------------------------------------------------------------------------------------------------------
+def matrix_profiles(ctx, k, P, profile_reads, keep_host=8):
+    """P profiles (profile p = count of `profile_reads` synthetic reads, seed 100 + p) resident in HBM as int64[P][4^k]; the first
+    `keep_host` also on the host for the oracle spot check."""
     import numpy as np
-    from kpal_amd import _native
-    import oracle
-    ctx = _native.Context(0)
-    k, P, n = args.k, args.profiles, 4 ** args.k
-    metric = {'prod': 0, 'sum': 1, 'euclidean': 2}[args.metric]
-    nbytes = args.profile_reads * 151
+    n = 4 ** k
+    nbytes = profile_reads * 151
     d = ctx.alloc(nbytes)
     dprof = ctx.alloc(P * n * 8)
     host = []
     for p in range(P):
-        ctx.synth_reads_device(100 + p, 0, args.profile_reads, 150, d)
+        ctx.synth_reads_device(100 + p, 0, profile_reads, 150, d)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
         ctx.count_finish(to_host=False)
         ptr, _ = ctx.count_table()
-        if p < 8:
+        ctx.d2d(dprof + p * n * 8, ptr, n * 8)
+        if p < keep_host:
             c = np.empty(n, dtype=np.int64)
             ctx.d2h(c, ptr)
             host.append(c)
-            ctx.h2d(dprof + p * n * 8, c)
-        else:
-            c = np.empty(n, dtype=np.int64)
-            ctx.d2h(c, ptr)
-            ctx.h2d(dprof + p * n * 8, c)
+    ctx.sync()
     ctx.free(d)
-    for _ in range(args.warmup):
-        vals = ctx.distance_matrix_device(P, k, dprof, metric, args.balance)
+    return dprof, host
+
+
+def matrix_measure(ctx, k, P, dprof, host, metric_name, balance, steps, warmup, check):
+    """One kdistlib.distance_matrix value computation per step (kpal_distance_matrix_device) -> result dict."""
+    import numpy as np
+    n = 4 ** k
+    metric = {'prod': 0, 'sum': 1, 'euclidean': 2}[metric_name]
+    vals = None
+    for _ in range(warmup):
+        vals = ctx.distance_matrix_device(P, k, dprof, metric, balance)
     ctx.prof_enable(True)
     ctx.prof_reset()
     ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        vals = ctx.distance_matrix_device(P, k, dprof, metric, args.balance)
+    for _ in range(steps):
+        vals = ctx.distance_matrix_device(P, k, dprof, metric, balance)
     ctx.sync()
     elapsed = time.perf_counter() - t0
     prof = {n_: v for n_, v in ctx.prof_get().items() if v[1] > 0}
     ctx.prof_enable(False)
-    steps = max(args.steps, 1)
+    steps = max(steps, 1)
     pairs = P * (P - 1) // 2
     terms = pairs * n
     ms = elapsed / steps * 1e3
     dom = max(prof, key=lambda n_: prof[n_][0])
     dom_ms = prof[dom][0] / prof[dom][1]
-    mem_bytes = 8 * P * n * (2 if args.balance else 1)
-    if metric == 2 and dom.startswith('gram'):
+    mem_bytes = 8 * P * n * (2 if balance else 1)
+    if dom.startswith('gram'):
         # 10 of the 16 tile pairs of a 64-profile block are computed; 2 flop per multiply-add
-        flops = 2.0 * n * sum(10 * 256 for _ in range((P + 63) // 64)) + 2.0 * n * 16 * 256 * ((P + 63) // 64) * ((P + 63) // 64 - 1) / 2
+        nb = (P + 63) // 64
+        flops = 2.0 * n * (10 * 256 * nb + 16 * 256 * nb * (nb - 1) / 2)
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': flops / (dom_ms * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_T, 'unit': 'TFLOP/s',
                     'frac': flops / (dom_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_T, 'traffic': None,
                     'memory_frac': mem_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': mem_bytes,
                     'avg_launch_ms': dom_ms}
     else:
-        # multiset term with staged reciprocals (matrix_accumulate_prod_rcp): sub, mul, fma = 3 fp64 slots, + per 16 terms of a
-        # register tile 8 int -> double conversions and ~22 integer instructions for the term-count bytes: ~5 slots per term
-        # (sum metric / int64 euclidean without the staged reciprocals: ~12)
-        slots = 5.0 if metric == 0 else 12.0
+        # the NECESSARY fp64 work of a multiset term (metrics.py:118-123): |l - r|, the product (l + 1)(r + 1) and the division = 3
+        # lane operations for prod (sum: add instead of the product); the kernel's own instruction count is higher (conversions, term
+        # counts) and is not what the fraction is priced on
+        slots = 3.0
         roofline = {'bound': 'fp64-valu', 'kernel': dom, 'achieved': terms * slots / (dom_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_T,
-                    'unit': 'Tinstr/s (fp64 lane-instructions; %.0f issue slots per term)' % slots,
+                    'unit': 'Tinstr/s (fp64 lane operations; %.0f necessary per term)' % slots,
                     'frac': terms * slots / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_T, 'traffic': None,
                     'memory_frac': mem_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': mem_bytes,
                     'avg_launch_ms': dom_ms}
     roofline['kernels_ms_per_step'] = {n_: v[0] / steps for n_, v in sorted(prof.items())}
-    line = {
-        'metric': 'Gterms/s distance matrix (%d profiles k=%d, %s%s)' % (P, k, args.metric, ' balanced' if args.balance else ''),
-        'value': terms / (elapsed / steps) / 1e9, 'unit': 'Gterms/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f64' if metric != 2 else 'int64/f64-mfma', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE config 5: %d profiles k=%d (%d synthetic 150bp reads each, seed 100+p) resident in HBM, kdistlib.distance_matrix %s%s' % (
-            P, k, args.profile_reads, args.metric, ' +balance' if args.balance else ''), 'pairs': pairs},
-        'roofline': roofline,
+    out = {
+        'metric': 'Gterms/s distance matrix (%d profiles k=%d, %s%s)' % (P, k, metric_name, ' balanced' if balance else ''),
+        'value': terms / (elapsed / steps) / 1e9, 'unit': 'Gterms/s', 'ms_per_step': ms, 'steps': steps, 'pairs': pairs,
+        'dtype': 'f64' if metric != 2 else 'int64/f64-mfma', 'roofline': roofline,
     }
-    # parity spot-check + CPU baseline on an 8-profile subset
-    if not args.no_cpu:
+    if check and host:
+        import oracle
+        m = len(host)
         t0 = time.perf_counter()
-        want = oracle.distance_matrix_values(host, k, args.balance, args.metric)
+        want = oracle.distance_matrix_values(host, k, balance, metric_name)
         tc = time.perf_counter() - t0
-        sub = np.array([vals[i * (i - 1) // 2 + j] for i in range(1, 8) for j in range(i)])
+        sub = np.array([vals[i * (i - 1) // 2 + j] for i in range(1, m) for j in range(i)])
         rel = float(np.max(np.abs(sub - want) / np.maximum(np.abs(want), 1e-300)))
-        line['parity_max_rel_vs_oracle_28_pairs'] = rel
-        line['checksum_ok'] = bool(rel <= 1e-9)
-        line['cpu_baseline'] = {'value': 28 * n / tc / 1e9, 'unit': 'Gterms/s', 'cores': 1, 'kind': 'port',
-                                'sample': 'oracle distance_matrix on the first 8 profiles (28 pairs, %.2f s)' % tc}
+        out['parity_max_rel_vs_oracle'] = rel
+        out['parity_pairs'] = len(want)
+        out['checksum_ok'] = bool(rel == 0.0) if metric == 2 else bool(rel <= 1e-9)
+        out['cpu_baseline'] = {'value': len(want) * n / tc / 1e9, 'unit': 'Gterms/s', 'cores': 1, 'kind': 'port',
+                               'sample': 'oracle distance_matrix on the first %d profiles (%d pairs, %.2f s)' % (m, len(want), tc)}
+    return out
+
+
+def matrix_workload(args):
+    """BASELINE config 5 on one GPU as the headline: value = Gterms/s of the 64 x 64 lower triangle (2016 pairs x 4^12 bins)."""
+    from kpal_amd import _native
+    ctx = _native.Context(0)
+    dprof, host = matrix_profiles(ctx, args.k, args.profiles, args.profile_reads, keep_host=0 if args.no_cpu else 8)
+    r = matrix_measure(ctx, args.k, args.profiles, dprof, host, args.metric, args.balance, args.steps, args.warmup, check=not args.no_cpu)
+    line = {
+        'metric': r['metric'], 'value': r['value'], 'unit': r['unit'], 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': r['dtype'], 'data': 'synthetic',
+        'config': {'workload': 'BASELINE config 5: %d profiles k=%d (%d synthetic 150bp reads each, seed 100+p) resident in HBM, kdistlib.distance_matrix %s%s' % (
+            args.profiles, args.k, args.profile_reads, args.metric, ' +balance' if args.balance else ''), 'pairs': r['pairs']},
+        'roofline': r['roofline'], 'src_sha': source_sha(),
+    }
+    for key in ('parity_max_rel_vs_oracle', 'parity_pairs', 'checksum_ok', 'cpu_baseline'):
+        if key in r:
+            line[key] = r[key]
     print(json.dumps(line), flush=True)
     ctx.free(dprof)
     ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# counting
+# ----------------------------------------------------------------------------------------------------------------------
+def count_roofline(kern, k, n_bytes_step, bins, steps, ms_per_step, fused_balance):
+    """Roofline object of a counting step from the per-kernel HIP-event times (`kern`: name -> (total ms, launches)).
+
+    Algorithmic bytes: count = B_in + 8 * 4^k (every input byte read once, the table written once), balance =
+    16 * 4^k.  A multi-kernel pipeline moves more; each kernel is priced on the share of those bytes that IT moves and no
+    other kernel does -- the scatter that reads the input: B_in; the kernel that writes the finished table: 8 * 4^k; a
+    stand-alone balance: 16 * 4^k; intermediate kernels: nothing -- and the step on all of them."""
+    if not kern:
+        return None
+    share = {}
+    for name in kern:
+        if name == 'quad_scatter' or name in ('chunk_scatter', 'part_scatter', 'coarse_scatter', 'count_lds_direct', 'count_global_atomic'):
+            share[name] = float(n_bytes_step)
+        elif name in ('quad_hist', 'chunk_hist', 'part_hist') and k <= 12:
+            share[name] = 8.0 * bins
+        elif name in ('quad2_finalize', 'quad2_finalize_balanced'):
+            share[name] = 8.0 * bins
+        elif name in ('balance_tiled', 'balance_inplace'):
+            share[name] = 16.0 * bins
+        else:
+            share[name] = 0.0
+    dom = max(kern, key=lambda n: kern[n][0])
+    tot_ms, launches = kern[dom]
+    avg_ms = tot_ms / launches
+    launches_per_step = launches / steps
+    per_launch = share[dom] / max(launches_per_step, 1e-9)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9
+    alg_step = n_bytes_step + 8.0 * bins + (0.0 if fused_balance else 16.0 * bins)
+    r = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+         'avg_launch_ms': avg_ms, 'launches_per_step': launches_per_step, 'algorithmic_bytes_per_launch': per_launch,
+         'algorithmic_bytes_note': 'the dominant kernel is priced on the algorithmic bytes it alone moves (scatter: the input bytes; the kernel that '
+                                   'writes the finished table: 8*4^k; stand-alone balance: 16*4^k; intermediate kernels: none); the pipeline on all of them',
+         'pipeline': {'algorithmic_bytes_per_step': alg_step, 'achieved': alg_step / (ms_per_step * 1e-3) / 1e9,
+                      'frac': alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      'formula': 'B_in + 8*4^k' + ('' if fused_balance else ' + 16*4^k') + ' (count' + (' + balance fused into the finalisation' if fused_balance else ' + balance') + ')'},
+         'pipeline_frac': alg_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(kern.items())},
+         'kernel_frac_of_own_bytes': {n: (share[n] / max(v[1] / steps, 1e-9)) / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS for n, v in sorted(kern.items()) if share[n] > 0}}
+    per_step = {n: (v[0] / steps, v[1] / steps) for n, v in kern.items()}
+    r.update(pmc_traffic(per_step, dom, k, n_bytes_step))
+    if r.get('traffic_step'):
+        r['traffic_step_over_algorithmic'] = r['traffic_step'] / alg_step
+        r['traffic_step_rate_GBs'] = r['traffic_step'] / (ms_per_step * 1e-3) / 1e9
+    r['limiter'] = pmc_limiter(dom, k)
+    return r
+
+
+def count_measure(ctx, k, dev_buf, nbytes, n_reads, read_len, strategy, steps, warmup):
+    """One GPU, no communicator: `steps` timed steps of zero + count + balance over the resident buffer -> result dict."""
+    import numpy as np
+    ctx.count_begin(k, strategy)
+    table_ptr, bins = ctx.count_table()
+
+    def step():
+        ctx.count_begin(k, strategy)                   # zero the 4^k table
+        ctx.count_feed_device(dev_buf, nbytes)
+        ctx.count_balance()                            # Profile.balance on the table (k >= 13: fused into its finalisation)
+        ctx.sync()
+
+    for _ in range(warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    kern = {n: v for n, v in ctx.prof_get().items() if v[1] > 0}
+    ctx.prof_enable(False)
+    plan = ctx.count_last_plan()
+    out = np.empty(bins, dtype=np.int64)
+    ctx.d2h(out, table_ptr)
+    ok = int(out.sum()) == 2 * n_reads * (read_len - k + 1)
+    steps = max(steps, 1)
+    ms = elapsed / steps * 1e3
+    return {'ms_per_step': ms, 'value': n_reads * read_len / (elapsed / steps) / 1e9, 'checksum_ok': ok, 'plan': list(plan), 'bins': bins,
+            'roofline': count_roofline(kern, k, nbytes, bins, steps, ms, fused_balance='quad2_finalize_balanced' in kern), 'table': out}
+
+
+def end_to_end(ctx, k, dev_buf, nbytes, n_reads, read_len, kernel_s):
+    """SURVEY.md 8d protocol: end-to-end with HOST-resident input, reported separately and never the bench value.  The reads are
+    downloaded once (outside any timing), then: a plain H2D copy of them, the resident-input step (from the headline), the D2H
+    of the 4^k table -- and the library's own host feed (kpal_count_feed: 64 MiB pinned staging, copies overlapped with
+    counting) + balance + download, which is what a caller holding reads in host memory gets."""
+    import numpy as np
+    host = np.empty(nbytes, dtype=np.uint8)
+    ctx.d2h(host, dev_buf)
+    t0 = time.perf_counter()
+    ctx.h2d(dev_buf, host)
+    h2d_s = time.perf_counter() - t0
+    ctx.count_begin(k)
+    t0 = time.perf_counter()
+    ctx.count_feed(host)
+    ctx.count_balance()
+    ctx.sync()
+    feed_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    table = ctx.count_finish()
+    d2h_s = time.perf_counter() - t0
+    ok = int(table.sum()) == 2 * n_reads * (read_len - k + 1)
+    bases = n_reads * read_len
+    return {'h2d_s': h2d_s, 'kernel_s': kernel_s, 'd2h_s': d2h_s,
+            'serial_Gbases_per_s': bases / (h2d_s + kernel_s + d2h_s) / 1e9,
+            'overlapped_host_feed_s': feed_s, 'overlapped_Gbases_per_s': bases / (feed_s + d2h_s) / 1e9,
+            'h2d_GBs': nbytes / h2d_s / 1e9, 'checksum_ok': ok,
+            'note': 'input in pageable host memory (%d bytes); h2d_s = one plain copy; overlapped_host_feed_s = kpal_count_feed (pinned 64 MiB staging, '
+                    'copy/compute overlap) + balance; never the bench value' % nbytes}
+
+
+def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
+    """BASELINE configs 4 and 5 and the end-to-end figure, after the headline measurement (same process, same resident buffer)."""
+    extra = {}
+    L = args.read_len
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            extra[name] = fn()
+        except Exception as e:   # an extra never takes the headline line down
+            extra[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        extra[name]['wall_s'] = time.perf_counter() - t0
+
+    guarded('end_to_end', lambda: end_to_end(ctx, args.k, dev_buf, nbytes, args.reads, L, headline_ms * 1e-3))
+
+    def k15():
+        ctx.synth_reads_device(4, 0, args.reads, L, dev_buf)             # SURVEY.md 8d config 4: seed 4
+        r = count_measure(ctx, 15, dev_buf, nbytes, args.reads, L, 'auto', 3, 1)
+        r.pop('table')
+        r.update({'metric': 'Gbases/s k-mer counted (k=15, %dbp synthetic)' % L, 'unit': 'Gbases/s', 'steps': 3, 'warmup': 1, 'dtype': 'int64',
+                  'config': 'BASELINE config 4: k=15 (8 GiB table), %d reads resident in HBM, count+balance' % args.reads})
+        return r
+    guarded('k15', k15)
+
+    def matrices():
+        dprof, host = matrix_profiles(ctx, 12, args.profiles, args.profile_reads, keep_host=0 if args.no_cpu else 8)
+        try:
+            extra['matrix_prod'] = matrix_measure(ctx, 12, args.profiles, dprof, host, 'prod', False, 3, 1, check=not args.no_cpu)
+            extra['matrix_euclidean'] = matrix_measure(ctx, 12, args.profiles, dprof, host, 'euclidean', False, 3, 1, check=not args.no_cpu)
+        finally:
+            ctx.free(dprof)
+        return {'config': 'BASELINE config 5: %d profiles k=12 (%d reads each, seed 100+p) resident in HBM; see matrix_prod / matrix_euclidean' % (args.profiles, args.profile_reads)}
+    guarded('matrix', matrices)
+    return extra
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher + ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) as a plain command: start the N ranks as a fresh child process group BEFORE this
+    process touches the GPU (it never does), relay rank 0's JSON line, exit with the child's status."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL across processes)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    last = None
+    for raw in p.stdout:
+        text = raw.decode('utf-8', 'replace').rstrip('\n')
+        try:
+            obj = json.loads(text)
+            if isinstance(obj, dict) and 'metric' in obj:
+                last = text
+                continue
+        except ValueError:
+            pass
+        print(text, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if last is not None:
+        print(last, flush=True)
+    sys.exit(rc if rc else (0 if last is not None else 1))
+
+
+def stub_rank(args):
+    """--stub: the multi-process plumbing alone, on CPU (gloo) and WITHOUT any counting -- rendezvous, shard arithmetic, one
+    reduce(SUM) of int64 tables to rank 0, max-over-ranks timing, rank 0's JSON line.  Exists so that the launcher path of
+    `python bench.py --gpus N` can be tested where there is no GPU; `value` is null."""
+    import torch
+    import torch.distributed as td
+    from kpal_amd import dist as kdist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    total = 1000 * world + 7
+    first, n = kdist.shard_range(total, rank, world)
+    table = torch.zeros(4 ** 4, dtype=torch.int64)
+    idx = torch.arange(first, first + n) % table.numel()
+    table.index_add_(0, idx, torch.ones(n, dtype=torch.int64))          # "counts" of this rank's shard of unit ids
+    td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t = table.clone()
+        kdist.reduce_counts(t, dst=0)
+    td.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    td.all_reduce(el, op=td.ReduceOp.MAX)
+    if rank == 0:
+        want = torch.zeros_like(table)
+        want.index_add_(0, torch.arange(total) % table.numel(), torch.ones(total, dtype=torch.int64))
+        print(json.dumps({'metric': 'stub (plumbing only, no GPU work)', 'value': None, 'unit': 'Gbases/s', 'n_gpus': world, 'rccl_ranks': td.get_world_size(),
+                          'backend': 'gloo', 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(el.item()) / max(args.steps, 1) * 1e3,
+                          'checksum_ok': bool(torch.equal(t, want)), 'scaling': 'weak', 'data': 'synthetic'}), flush=True)
+    td.destroy_process_group()
 
 
 def main():
@@ -221,29 +522,37 @@ def main():
     ap.add_argument('--strategy', default='auto')
     ap.add_argument('--cpu-reads', type=int, default=4_000_000, help='reads in the CPU-baseline sample')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='N=1: skip BASELINE configs 4 / 5 and the end-to-end figure after the headline')
     ap.add_argument('--strong', action='store_true',
                     help='strong scaling: --reads is the TOTAL, split over the GPUs (default: weak, --reads per GPU)')
-    ap.add_argument('--reduce', default='int64', choices=['int64', 'u32'],
-                    help='N>1: dtype moved by the RCCL reduce (u32 halves the xGMI bytes; used only while every per-rank bin < 2^32)')
-    ap.add_argument('--overlap-reduce', action='store_true',
-                    help='N>1: reduce the table of step i on a second buffer while step i+1 counts')
+    ap.add_argument('--reduce-via', default='library', choices=['library', 'torch'],
+                    help='N>1: who issues the RCCL reduce -- libkpal_hip.so on its own streams (default), or torch.distributed (kpal_amd.dist.TableReducer)')
+    ap.add_argument('--serial-reduce', action='store_true',
+                    help='N>1, library: count -> reduce -> balance in ONE stream per step instead of the pipelined default (the reduce + balance of '
+                         'step i run on a copy of the table and a second stream while step i+1 counts)')
+    ap.add_argument('--reduce', default='int64', choices=['int64', 'u32'], help='N>1, --reduce-via torch only: dtype moved by the reduce')
+    ap.add_argument('--overlap-reduce', action='store_true', help='N>1, --reduce-via torch only: reduce on a second buffer while the next step counts')
+    ap.add_argument('--stub', action='store_true', help='plumbing self-test on CPU/gloo, no counting (tests of the launcher)')
     ap.add_argument('--profiles', type=int, default=64, help='matrix workload: number of profiles')
     ap.add_argument('--profile-reads', type=int, default=2_000_000, help='matrix workload: reads per profile')
     ap.add_argument('--metric', default='prod', choices=['prod', 'sum', 'euclidean'])
     ap.add_argument('--balance', action='store_true')
     args = ap.parse_args()
 
+    # ---- launcher: nothing above or in here imports torch.cuda, the native library or anything else that opens the GPU
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
+    if args.stub:
+        return stub_rank(args)
     if args.workload == 'matrix':
         return matrix_workload(args)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)' % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as td
     from kpal_amd import _native, dist as kdist
@@ -270,10 +579,46 @@ def main():
     ctx.synth_reads_device(seed, first_read, n_reads, L, dev_buf)
     ctx.sync()
 
+    if world == 1:
+        r = count_measure(ctx, k, dev_buf, nbytes, n_reads, L, args.strategy, args.steps, args.warmup)
+        line = {
+            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': r['value'], 'unit': 'Gbases/s',
+            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
+            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+balance' % (k, n_reads, L),
+                       'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy, 'pipeline': r['plan'],
+                       'parallelism': 'one GPU'},
+            'checksum_ok': r['checksum_ok'], 'rccl_ranks': 1, 'src_sha': source_sha(), 'roofline': r['roofline'],
+        }
+        ok = r['checksum_ok']
+        if not args.no_cpu:
+            line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
+        if not args.no_extra and k == 12 and args.strategy == 'auto':
+            line['extra'] = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
+        print(json.dumps(line), flush=True)
+        ctx.free(dev_buf)
+        ctx.close()
+        if not ok:
+            sys.exit('checksum mismatch')
+        return
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # N > 1: one rank per GPU
+    # ------------------------------------------------------------------------------------------------------------------
     ctx.count_begin(k, args.strategy)                   # allocates the table once
     table_ptr, bins = ctx.count_table()
     reducer = None
-    if world > 1:
+    library = args.reduce_via == 'library'
+    pipelined = library and not args.serial_reduce
+    if library:
+        # the communicator of the library: rank 0's id reaches the others through the process group torch.distributed.run set up
+        ident = torch.zeros(_native.COMM_ID_BYTES, dtype=torch.uint8, device='cuda')
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
+        td.broadcast(ident, src=0)
+        torch.cuda.synchronize()
+        ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+    else:
         reducer = kdist.TableReducer(kdist.table_as_tensor(ctx), sync=ctx.sync,
                                      balance=lambda t: ctx.balance_device(k, t.data_ptr()),
                                      mode=args.reduce, overlap=args.overlap_reduce)
@@ -281,18 +626,20 @@ def main():
     def step():
         ctx.count_begin(k, args.strategy)               # zero the 4^k table
         ctx.count_feed_device(dev_buf, nbytes)
-        if reducer is not None:
-            reducer.reduce_step()                       # RCCL reduce(SUM) to rank 0 (+ balance on rank 0)
-        elif rank == 0:
-            ctx.balance_device(k, table_ptr)            # Profile.balance on the table
-        ctx.sync()
+        if library:
+            # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step
+            ctx.comm_reduce_table(0, balance=True, pipelined=pipelined)
+            if not pipelined:
+                ctx.sync()
+        else:
+            reducer.reduce_step()                       # torch.distributed.reduce(SUM) to rank 0 (+ balance on rank 0)
+            ctx.sync()
 
     def fence():
-        ctx.sync()
+        ctx.sync()                                      # the context's streams (incl. a pipelined reduce)
         torch.cuda.synchronize()
-        if world > 1:
-            td.barrier()
-            torch.cuda.synchronize()
+        td.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -310,66 +657,37 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_get()
     ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    elapsed = float(t.item())
 
     # sanity: the last step's merged + balanced table has exactly 2 * (#k-mers) counts
     ok = True
     if rank == 0:
-        import numpy as np
         out = np.empty(bins, dtype=np.int64)
-        ctx.d2h(out, reducer.result_ptr() if reducer is not None else table_ptr)
+        ctx.d2h(out, ctx.comm_merged_table()[0] if library else reducer.result_ptr())
         ok = int(out.sum()) == 2 * total_reads * (L - k + 1)
-
-    if rank == 0:
         steps = max(args.steps, 1)
-        bases_per_step = total_reads * L
         ms_per_step = elapsed / steps * 1e3
-        value = bases_per_step / (elapsed / steps) / 1e9
-        # roofline of the dominant kernel (HIP events on the launch stream, this rank)
-        alg_bytes_step = n_reads * (L + 1) + 8 * bins    # B_in + 8*4^k, per GPU
         kern = {n: v for n, v in prof.items() if v[1] > 0}
-        dom = max(kern, key=lambda n: kern[n][0]) if kern else None
-        roofline = None
-        if dom:
-            tot_ms, launches = kern[dom]
-            per_launch_bytes = alg_bytes_step * steps / launches
-            avg_ms = tot_ms / launches
-            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': achieved / HBM_PEAK_GBS}
-            roofline.update(pmc_traffic(dom, k, n_reads * (L + 1) * steps / launches))
-            roofline.update({'avg_launch_ms': avg_ms,
-                             'launches_per_step': launches / steps,
-                             'algorithmic_bytes_per_launch': per_launch_bytes,
-                             'pipeline_frac': alg_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(kern.items())},
-                             # the contract prices the path against HBM; what actually limits the quad kernels since round 2
-                             # (counters: profiles/r2/pmc_lds_quad.json)
-                             'limiter': ('VALU + LDS issue (scatter), LDS atomics (histogram): the kernels move their bytes at 4-5 TB/s'
-                                         if dom.startswith('quad') else None)})
+        roofline = count_roofline(kern, k, nbytes, bins, steps, ms_per_step, fused_balance=False)
         line = {
-            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': value, 'unit': 'Gbases/s',
+            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': total_reads * L / (elapsed / steps) / 1e9, 'unit': 'Gbases/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
-            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count%s+balance'
-                                   % (k, n_reads, L, '+RCCL reduce' if world > 1 else ''),
+            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+RCCL reduce+balance' % (k, n_reads, L),
                        'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy,
-                       'parallelism': 'reads sharded x%d, 1 reduce(%s sum)%s' % (world, args.reduce, ', overlapped with the next count' if args.overlap_reduce else '')},
-            'checksum_ok': ok,
-            'src_sha': source_sha(),
-            'roofline': roofline,
+                       'parallelism': 'reads sharded x%d, 1 ncclReduce(int64 sum) of the 4^k table to rank 0 per step, issued by %s%s' % (
+                           world, 'libkpal_hip.so' if library else 'torch.distributed',
+                           ' on a second stream, overlapped with the next count' if pipelined else '')},
+            'checksum_ok': ok, 'rccl_ranks': td.get_world_size(), 'reduce_via': args.reduce_via, 'pipelined_reduce': pipelined,
+            'src_sha': source_sha(), 'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu:
-            line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
         print(json.dumps(line), flush=True)
 
     ctx.free(dev_buf)
     ctx.close()
-    if world > 1:
-        td.destroy_process_group()
+    td.destroy_process_group()
     if rank == 0 and not ok:
         sys.exit('checksum mismatch')
 

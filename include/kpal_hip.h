@@ -74,6 +74,7 @@ int kpal_dev_alloc(kpal_ctx *ctx, size_t nbytes, void **dev_out);
 int kpal_dev_free(kpal_ctx *ctx, void *dev);
 int kpal_memcpy_h2d(kpal_ctx *ctx, void *dev_dst, const void *host_src, size_t nbytes);
 int kpal_memcpy_d2h(kpal_ctx *ctx, void *host_dst, const void *dev_src, size_t nbytes);
+int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, size_t nbytes);   /* asynchronous, ordered on the context's stream */
 
 /* ---- counting: replaces Profile.from_sequences / from_fasta inner loops, klib.py:149-170 ----
  * Input is a flat byte stream; every byte outside AaCcGgTt separates sequences (klib.py:152,
@@ -97,6 +98,11 @@ int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, ui
 int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
                        size_t n_records, int64_t *host_out);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
+/* Profile.balance (klib.py:285-298) on the count table in place, on the device: count + balance is the unit the
+ * north-star metric is quoted on.  Call after the last feed, before kpal_count_finish (which then returns the balanced
+ * counts).  For k >= 13 on the two-level quad pipeline the balance is fused into the pass that finalises the table
+ * (one read and one write of the 4^k entries instead of two each); otherwise it is kpal_balance_device on the table. */
+int kpal_count_balance(kpal_ctx *ctx);
 /* Diagnostics (tests, A/B timing): the pipeline the last piece of the last feed actually took (a KPAL_STRATEGY_* value: AUTO
  * resolves per feed size and input composition) and the tile sizes of the quad scatters (wave-steps per wave and tile of level 1 /
  * level 2; 0 where not applicable).  The environment variables KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2, read when the context is
@@ -108,6 +114,27 @@ int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* devi
  * kpal_oracle_synth_reads): n_reads*(read_len+1) bytes, each read followed by '\n'. */
 int kpal_synth_reads_device(kpal_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
                             int read_len, int noisy, void *dev_out);
+
+/* ---- multi-GPU: one process per GPU, the per-rank count tables merged by ONE RCCL reduce over xGMI ----
+ * Replaces nothing the reference has (it is single-threaded); mirrors Profile.merge with the 'sum' merger, klib.py:269-283 /
+ * metrics.py:175: every rank counts its shard of the reads into its own table (begin / feed), the tables add -- int64 sums,
+ * bit-exact for any reduction order.  RCCL is bound at run time: rccl_library names the librccl.so to load (NULL: the
+ * KPAL_RCCL_LIBRARY environment variable, then the loader's search path); inside a PyTorch process pass PyTorch's copy.
+ *   rank 0:      kpal_comm_unique_id(lib, id)          -> hand the 128 bytes to the other ranks (MPI, a file, torch.distributed ...)
+ *   every rank:  kpal_comm_init(ctx, lib, rank, world, id)
+ *   per job:     kpal_count_begin / feed ...; kpal_comm_reduce_table(ctx, root, balance); kpal_count_finish(root's host buffer)
+ * kpal_comm_reduce_table: ncclReduce(int64, sum) of the count table onto `root` and, if balance != 0, Profile.balance there -- all
+ * queued on the context's stream, no host synchronisation.  kpal_comm_reduce_table_async: the same on a copy of the table and on a
+ * second stream, so that the next kpal_count_begin / feed overlaps it (throughput pipelines; two extra tables of HBM); the merged table
+ * is then read with kpal_comm_merged_table (valid until the reduce after next) after kpal_sync. */
+#define KPAL_COMM_ID_BYTES 128
+int kpal_comm_unique_id(const char *rccl_library, uint8_t *id_out /* KPAL_COMM_ID_BYTES */);
+int kpal_comm_init(kpal_ctx *ctx, const char *rccl_library, int rank, int world, const uint8_t *id);
+int kpal_comm_destroy(kpal_ctx *ctx);
+int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance);
+int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance);
+int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins);
+int kpal_comm_max_f64(kpal_ctx *ctx, double *inout);   /* max of a host scalar over the ranks (timing: the slowest rank) */
 
 /* ---- vector operations on 4^k int64 count vectors ---- */
 /* Profile.balance, klib.py:285-298: c[i] += c[rc(i)] (palindromes doubled), in place. */

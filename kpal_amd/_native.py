@@ -60,6 +60,7 @@ SIGNATURES = {
     'kpal_dev_free': (ctypes.c_int, [_vp, _vp]),
     'kpal_memcpy_h2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'kpal_memcpy_d2h': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    'kpal_memcpy_d2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'kpal_count_begin': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_count_set_strategy': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_count_feed': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
@@ -69,7 +70,15 @@ SIGNATURES = {
     'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_count_balance': (ctypes.c_int, [_vp]),
     'kpal_count_last_plan': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'kpal_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, _vp]),
+    'kpal_comm_init': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp]),
+    'kpal_comm_destroy': (ctypes.c_int, [_vp]),
+    'kpal_comm_reduce_table': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    'kpal_comm_reduce_table_async': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    'kpal_comm_merged_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_comm_max_f64': (ctypes.c_int, [_vp, _f64p]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_int, ctypes.c_int, _vp]),
     'kpal_balance': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
@@ -167,6 +176,35 @@ def _check(rc):
     raise RuntimeError('kpal_hip error %d: %s' % (rc, msg))
 
 
+COMM_ID_BYTES = 128
+
+
+def rccl_library():
+    """Path of the librccl.so the library should bind (bytes), or None for its own search: inside a process that has
+    PyTorch installed its bundled copy is taken -- the one that matches the HIP runtime ``_share_hip_runtime_with_torch``
+    loaded; KPAL_RCCL_LIBRARY overrides."""
+    env = os.environ.get('KPAL_RCCL_LIBRARY')
+    if env:
+        return env.encode()
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'librccl.so')
+        if os.path.exists(path):
+            return path.encode()
+    return None
+
+
+def comm_unique_id():
+    """128 opaque bytes (an ncclUniqueId) that rank 0 creates and every rank passes to ``Context.comm_init``."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(load().kpal_comm_unique_id(rccl_library(), buf))
+    return bytes(buf)
+
+
 def device_count():
     n = ctypes.c_int(0)
     rc = load().kpal_device_count(ctypes.byref(n))
@@ -234,6 +272,9 @@ class Context(object):
         assert host_array.flags['C_CONTIGUOUS']
         _check(self._L.kpal_memcpy_d2h(self._h, host_array.ctypes.data, _vp(dev_ptr), host_array.nbytes))
 
+    def d2d(self, dev_dst, dev_src, nbytes):
+        _check(self._L.kpal_memcpy_d2d(self._h, _vp(dev_dst), _vp(dev_src), int(nbytes)))
+
     def sync(self):
         _check(self._L.kpal_sync(self._h))
 
@@ -280,6 +321,10 @@ class Context(object):
         _check(self._L.kpal_count_table(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
+    def count_balance(self):
+        """Profile.balance on the device count table, in place (fused into the finalisation of the table for k >= 13)."""
+        _check(self._L.kpal_count_balance(self._h))
+
     def count_last_plan(self):
         """-> (strategy name, steps1, steps2): the pipeline and quad tile sizes the last piece of the last feed took."""
         st, s1, s2 = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
@@ -312,6 +357,32 @@ class Context(object):
         self.count_begin(k, strategy)
         self.count_feed(buf)
         return self.count_finish()
+
+    # -- multi-GPU (RCCL inside the library) -----------------------------------------------------------
+    def comm_init(self, rank, world, comm_id):
+        """Join the RCCL communicator identified by ``comm_id`` (``comm_unique_id()`` of rank 0)."""
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        _check(self._L.kpal_comm_init(self._h, rccl_library(), int(rank), int(world), buf))
+
+    def comm_destroy(self):
+        _check(self._L.kpal_comm_destroy(self._h))
+
+    def comm_reduce_table(self, root=0, balance=True, pipelined=False):
+        """ONE ncclReduce(int64, sum) of the count tables onto ``root`` (+ Profile.balance there), queued on the
+        context's streams.  ``pipelined``: on a copy of the table and a second stream -- the next count overlaps it."""
+        fn = self._L.kpal_comm_reduce_table_async if pipelined else self._L.kpal_comm_reduce_table
+        _check(fn(self._h, int(root), int(bool(balance))))
+
+    def comm_merged_table(self):
+        p = _vp()
+        n = ctypes.c_uint64(0)
+        _check(self._L.kpal_comm_merged_table(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def comm_max(self, value):
+        v = ctypes.c_double(float(value))
+        _check(self._L.kpal_comm_max_f64(self._h, ctypes.byref(v)))
+        return v.value
 
     # -- vector operations -----------------------------------------------------------------------
     def balance_inplace(self, counts, k):

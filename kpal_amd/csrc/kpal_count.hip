@@ -24,6 +24,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
     if (ctx->quad_error_word) HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
     ctx->chunk_error_armed = false;
+    ctx->finalize_pending = false;          // (staged forms of an abandoned count)
     ctx->cached_steps1 = ctx->cached_steps2 = 0;
     ctx->plan_strategy = ctx->plan_steps1 = ctx->plan_steps2 = 0;
     ctx->counting = true;
@@ -411,6 +412,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     piece &= ~(size_t)15;
     if (piece == 0) piece = 16;
     for (size_t off = 0; off < n; off += piece) {
+        CHK(quad2_finalize(ctx, false));   // the staged forms of the previous piece, before their buffer is reused
         const size_t len = std::min(piece, n - off);
         const size_t h = std::min(km1, halo + off);
         const Span s = make_span(addr + off, len, h);
@@ -687,6 +689,7 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
+    CHK(quad2_finalize(ctx, false));
     uint32_t pool_error = 0, quad_error = 0;
     if (ctx->chunk_error_armed)
         HIPCHK(hipMemcpyAsync(&pool_error, ctx->chunk_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -707,6 +710,15 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
     return KPAL_OK;
 }
 
+KPAL_API int kpal_count_balance(kpal_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_balance before kpal_count_begin");
+    // two-level quad pipeline: the pending finalisation of the table balances it in the same pass
+    if (ctx->finalize_pending) return quad2_finalize(ctx, true);
+    return launch_balance(ctx, ctx->k, (const int64_t *)ctx->table.p, (int64_t *)ctx->table.p);
+}
+
 KPAL_API int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int *steps2)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
@@ -720,6 +732,8 @@ KPAL_API int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
     if (!ctx->counting) return set_err(KPAL_E_STATE, "no count table (call kpal_count_begin)");
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(quad2_finalize(ctx, false));   // the caller is about to use the table
     if (dev_table) *dev_table = ctx->table.p;
     if (n_bins) *n_bins = ctx->bins;
     return KPAL_OK;

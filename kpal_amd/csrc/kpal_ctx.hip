@@ -63,6 +63,7 @@ int prof_collect(kpal_ctx *ctx)
 {
     if (ctx->prof_pending.empty()) return KPAL_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) HIPCHK(hipStreamSynchronize(ctx->comm_stream));
     for (auto &r : ctx->prof_pending) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
@@ -146,11 +147,14 @@ KPAL_API int kpal_ctx_create(int device, kpal_ctx **out)
     return KPAL_OK;
 }
 
+KPAL_API int kpal_comm_destroy(kpal_ctx *ctx);
+
 KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    (void)kpal_comm_destroy(ctx);
     DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
@@ -174,7 +178,9 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
 KPAL_API int kpal_sync(kpal_ctx *ctx)
 {
     CTX_ENTER(ctx);
+    CHK(quad2_finalize(ctx, false));   // (a pending finalisation of the count table belongs to "everything queued so far")
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) HIPCHK(hipStreamSynchronize(ctx->comm_stream));   // ... and so does a pipelined reduce
     return KPAL_OK;
 }
 
@@ -212,6 +218,15 @@ KPAL_API int kpal_memcpy_d2h(kpal_ctx *ctx, void *host_dst, const void *dev_src,
     if (nbytes == 0) return KPAL_OK;
     HIPCHK(hipMemcpyAsync(host_dst, dev_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (nbytes == 0) return KPAL_OK;
+    CHK(quad2_finalize(ctx, false));   // (the source may be the count table)
+    HIPCHK(hipMemcpyAsync(dev_dst, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));   // asynchronous, stream-ordered
     return KPAL_OK;
 }
 

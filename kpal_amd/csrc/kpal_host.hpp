@@ -89,6 +89,9 @@ struct kpal_ctx {
     int cached_steps1 = 0, cached_steps2 = 0;
     uint32_t cached_uses = 0;
     size_t cached_bytes = 0;
+    // two-level quad pipeline: the staged forms of the last piece have not been added to the table yet (quad2_finalize)
+    bool finalize_pending = false;
+    const void *finalize_stage = nullptr;
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     alignas(16) unsigned char chunk_pool_sent[96] = {};   // (ChunkPool) what the device copy of the pool descriptor holds
     void *chunk_pool_dev = nullptr;
@@ -108,6 +111,16 @@ struct kpal_ctx {
     DevBuf scratch[4];
     DevBuf partials, result;
     DevBuf opt_l, opt_r, opt_levels, opt_profiles;   // ProfileDistance option pipeline
+    // multi-GPU (kpal_multi.hip): RCCL communicator, the stream the pipelined reduce runs on, two side buffers for it
+    void *comm = nullptr;                    // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_table_copied = nullptr;
+    hipEvent_t ev_side_free[2] = {nullptr, nullptr};
+    bool side_used[2] = {false, false};
+    DevBuf side[2];
+    int side_turn = 0;
+    void *merged = nullptr;                  // where the last merged table lies (the count table or a side buffer)
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -230,4 +243,5 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
                       size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr);   // kpal_quads.hip
 double quad_expected_backlog(const std::vector<double> &mu, int slots);   // kpal_quads.hip
 constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
+int quad2_finalize(kpal_ctx *ctx, bool balance);                          // kpal_quads2.hip: no-op unless a finalisation is pending
 int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out);   // kpal_vec.hip

@@ -1,0 +1,211 @@
+// kpal_multi.hip -- multi-GPU entry points of the C-ABI: one process per GPU, the per-rank count tables merged by ONE
+// RCCL reduce (int64 sum: bit-exact for any reduction order) over xGMI, issued on the context's own HIP streams -- no host
+// synchronisation between count, reduce and balance.
+//
+// The reference has no parallelism of any kind; what is mirrored is Profile.merge with the 'sum' merger
+// (kpal/klib.py:269-283, kpal/metrics.py:175): "merging ... is equivalent to first concatenating both fasta files"
+// (doc/tutorial.rst:94-95) -- so every rank counts its shard of the reads into a private table and the tables add.
+//
+// RCCL is bound at run time (dlopen), not at link time: libkpal_hip.so stays loadable on a box without RCCL, and inside a
+// PyTorch process the SAME librccl.so PyTorch uses is taken (the Python side passes its path), next to the same HIP runtime.
+#include "kpal_host.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+int rccl_load(const char *path)
+{
+    if (g_rccl.handle) return KPAL_OK;
+    const char *candidates[] = {path, getenv("KPAL_RCCL_LIBRARY"), "librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    std::string tried;
+    for (const char *c : candidates) {
+        if (!c || !*c) continue;
+        h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        tried += std::string(tried.empty() ? "" : "; ") + c + ": " + (dlerror() ? "cannot be loaded" : "?");
+    }
+    if (!h) return set_err(KPAL_E_HIP, "RCCL not found (%s)", tried.c_str());
+    RcclApi a;
+    a.handle = h;
+#define KPAL_RCCL_SYM(field, name)                                                              \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                              \
+    if (!a.field) {                                                                             \
+        dlclose(h);                                                                             \
+        return set_err(KPAL_E_HIP, "RCCL library lacks %s", name);                              \
+    }
+    KPAL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    KPAL_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    KPAL_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    KPAL_RCCL_SYM(Reduce, "ncclReduce")
+    KPAL_RCCL_SYM(AllReduce, "ncclAllReduce")
+    KPAL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef KPAL_RCCL_SYM
+    g_rccl = a;
+    return KPAL_OK;
+}
+
+}  // namespace
+
+#define NCCLCHK(expr)                                                                                                    \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                                        \
+        if (r_ != ncclSuccess) return set_err(KPAL_E_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+static_assert(KPAL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "kpal_comm_unique_id hands out an ncclUniqueId");
+
+KPAL_API int kpal_comm_unique_id(const char *rccl_library, uint8_t *id_out)
+{
+    if (!id_out) return set_err(KPAL_E_INVALID, "id_out is NULL");
+    CHK(rccl_load(rccl_library));
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_destroy(kpal_ctx *ctx);
+
+KPAL_API int kpal_comm_init(kpal_ctx *ctx, const char *rccl_library, int rank, int world, const uint8_t *id)
+{
+    CTX_ENTER(ctx);
+    if (world < 1 || rank < 0 || rank >= world) return set_err(KPAL_E_INVALID, "bad rank / world size %d / %d", rank, world);
+    if (!id) return set_err(KPAL_E_INVALID, "id is NULL");
+    if (ctx->comm) return set_err(KPAL_E_STATE, "the context already has a communicator");
+    CHK(rccl_load(rccl_library));
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&comm, world, uid, rank));
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    // the pipelined reduce runs on its own stream, ahead of the counting kernels in the hardware queues
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    hipError_t e = hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_table_copied, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->ev_side_free[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        kpal_comm_destroy(ctx);
+        return set_err(KPAL_E_HIP, "communicator streams / events: %s", hipGetErrorString(e));
+    }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_destroy(kpal_ctx *ctx)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    ctx->comm_stream = nullptr;
+    if (ctx->ev_table_copied) (void)hipEventDestroy(ctx->ev_table_copied);
+    ctx->ev_table_copied = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_side_free[i]) (void)hipEventDestroy(ctx->ev_side_free[i]);
+        ctx->ev_side_free[i] = nullptr;
+        ctx->side_used[i] = false;
+        if (ctx->side[i].p) (void)hipFree(ctx->side[i].p);
+        ctx->side[i] = DevBuf();
+    }
+    ctx->merged = nullptr;
+    return KPAL_OK;
+}
+
+// count -> reduce -> [balance on root], all on the context's stream: the merged table replaces the count table on root.
+KPAL_API int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_comm_reduce_table before kpal_count_begin");
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (root < 0 || root >= ctx->comm_world) return set_err(KPAL_E_INVALID, "root %d not in 0..%d", root, ctx->comm_world - 1);
+    CHK(quad2_finalize(ctx, false));   // the complete, unbalanced table goes on the wire
+    {
+        ProfScope ps_(ctx, "rccl_reduce");
+        NCCLCHK(g_rccl.Reduce(ctx->table.p, ctx->table.p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream));
+    }
+    ctx->merged = ctx->table.p;
+    if (balance && ctx->comm_rank == root) CHK(launch_balance(ctx, ctx->k, (const int64_t *)ctx->table.p, (int64_t *)ctx->table.p));
+    return KPAL_OK;
+}
+
+// Pipelined: the table is copied to one of two side buffers (0.05 ms at k = 12) and reduced + balanced THERE, on the
+// communicator's stream, while the context's stream goes on with the next count.  The side buffers alternate: the merged
+// table of step i stays valid until the reduce of step i+2 is issued.
+KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_comm_reduce_table_async before kpal_count_begin");
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (root < 0 || root >= ctx->comm_world) return set_err(KPAL_E_INVALID, "root %d not in 0..%d", root, ctx->comm_world - 1);
+    CHK(quad2_finalize(ctx, false));
+    ctx->side_turn ^= 1;
+    const int t = ctx->side_turn;
+    const size_t bytes = (size_t)ctx->bins * sizeof(int64_t);
+    if (ctx->side[t].cap < bytes && ctx->side_used[t]) HIPCHK(hipEventSynchronize(ctx->ev_side_free[t]));   // (re-allocation: its last reader is done)
+    CHK(ensure(ctx, ctx->side[t], bytes));
+    // the buffer's previous content (the merged table of two steps ago) may go once its reduce + balance are done
+    if (ctx->side_used[t]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side_free[t], 0));
+    HIPCHK(hipMemcpyAsync(ctx->side[t].p, ctx->table.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_table_copied, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_table_copied, 0));
+    std::swap(ctx->stream, ctx->comm_stream);   // (LAUNCH / ProfScope work on ctx->stream)
+    int rc = KPAL_OK;
+    {
+        ProfScope ps_(ctx, "rccl_reduce");
+        const ncclResult_t r = g_rccl.Reduce(ctx->side[t].p, ctx->side[t].p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream);
+        if (r != ncclSuccess) rc = set_err(KPAL_E_HIP, "ncclReduce failed: %s", g_rccl.GetErrorString(r));
+    }
+    if (rc == KPAL_OK && balance && ctx->comm_rank == root)
+        rc = launch_balance(ctx, ctx->k, (const int64_t *)ctx->side[t].p, (int64_t *)ctx->side[t].p);
+    std::swap(ctx->stream, ctx->comm_stream);
+    if (rc != KPAL_OK) return rc;
+    HIPCHK(hipEventRecord(ctx->ev_side_free[t], ctx->comm_stream));
+    ctx->side_used[t] = true;
+    ctx->merged = ctx->side[t].p;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (!ctx->merged) return set_err(KPAL_E_STATE, "no merged table (kpal_comm_reduce_table[_async])");
+    if (dev_table) *dev_table = ctx->merged;
+    if (n_bins) *n_bins = ctx->bins;
+    return KPAL_OK;
+}
+
+// A scalar agreed on by all ranks (bench: the slowest rank's time; tests): max over the ranks, through the device.
+KPAL_API int kpal_comm_max_f64(kpal_ctx *ctx, double *inout)
+{
+    CTX_ENTER(ctx);
+    if (!inout) return set_err(KPAL_E_INVALID, "inout is NULL");
+    if (!ctx->comm) return KPAL_OK;
+    CHK(ensure(ctx, ctx->result, 64));
+    HIPCHK(hipMemcpyAsync(ctx->result.p, inout, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(g_rccl.AllReduce(ctx->result.p, ctx->result.p, 1, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
+    HIPCHK(hipMemcpyAsync(inout, ctx->result.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}

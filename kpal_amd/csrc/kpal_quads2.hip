@@ -124,8 +124,28 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
 
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
                G2, (uint32_t)tiles2, table, stage);
-        LAUNCH(ctx, "quad2_combine", (quad2_combine_kernel<K>), dim3((unsigned)(ctx->bins / 2048)), dim3(256), (const uint16_t *)stage, table);
     });
 #undef KPAL_QUAD2_LAUNCH
+    // The staged forms are added to the table by quad2_finalize_kernel -- LATER: kpal_count_balance fuses Profile.balance into
+    // that pass; anything else that needs the table (the next piece or feed, kpal_count_finish / _table, kpal_sync) flushes it
+    // first (quad2_finalize(ctx, false)).
+    ctx->finalize_pending = true;
+    ctx->finalize_stage = stage;
+    return KPAL_OK;
+}
+
+// Adds the staged forms of the last two-level quad piece to the count table (and balances the table in the same pass).
+int quad2_finalize(kpal_ctx *ctx, bool balance)
+{
+    if (!ctx->finalize_pending) return KPAL_OK;
+    ctx->finalize_pending = false;
+    const uint16_t *stage = (const uint16_t *)ctx->finalize_stage;
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    DISPATCH_K_13_16(ctx->k, {
+        if (balance)
+            LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<K, true>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+        else
+            LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+    });
     return KPAL_OK;
 }

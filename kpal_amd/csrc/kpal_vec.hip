@@ -34,6 +34,7 @@ KPAL_API int kpal_balance_device(kpal_ctx *ctx, int k, int64_t *dev_inout)
     CTX_ENTER(ctx);
     if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range", k);
     if (!dev_inout) return set_err(KPAL_E_INVALID, "dev_inout is NULL");
+    if (ctx->counting && dev_inout == (int64_t *)ctx->table.p && k == ctx->k) return kpal_count_balance(ctx);   // (fuses with a pending finalisation)
     return launch_balance(ctx, k, dev_inout, dev_inout);
 }
 

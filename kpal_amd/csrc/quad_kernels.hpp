@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "kpal_device.hpp"
+#include "quad2_index.hpp"
 
 namespace kpal {
 
@@ -91,6 +92,12 @@ struct QuadCfg {
     // (XOR, not OR: at k = 14 the two copies of t overlap, and quad2_combine_kernel relies on smask1(a) ^ smask1(b) = smask1(a ^ b))
     __host__ __device__ static constexpr uint32_t smask1(uint32_t t) { return (kCoarseBits > 4 ? ((t << (kCoarseBits - 4)) ^ t) : t) & (uint32_t)(kCoarse - 1); }
 };
+
+static_assert(Quad2Index<13>::smask(11) == QuadCfg<13>::smask(11) && Quad2Index<16>::smask(5) == QuadCfg<16>::smask(5) &&
+                  Quad2Index<13>::smask1(9) == QuadCfg<13>::smask1(9) && Quad2Index<14>::smask1(13) == QuadCfg<14>::smask1(13) &&
+                  Quad2Index<15>::smask1(7) == QuadCfg<15>::smask1(7) && Quad2Index<16>::smask1(15) == QuadCfg<16>::smask1(15) &&
+                  Quad2Index<15>::CB == QuadCfg<15>::kCoarseBits,
+              "quad2_index.hpp restates the scramble masks of QuadCfg");
 
 // item = hi6 << (L+4) | low << 4 | mask4 (mask bit 3 = oldest k-mer).  0 = null item.
 template <int K>
@@ -881,25 +888,32 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     __syncthreads();
     if (stage) {
         // two-level path: every table entry would receive four atomic adds (one per form, from four different
-        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are stored as they are instead, as 16-bit counts --
-        // one coalesced 64 KiB write per workgroup -- and quad2_combine_kernel gathers the four of every entry.  A
-        // count that does not fit 16 bits (a k-mer seen 65536 times in one batch within ONE of its four positions)
-        // goes to the table directly and is staged as zero.
-        uint16_t *dst = reinterpret_cast<uint16_t *>(stage) + (size_t)row_linear * (4 * BINS);
-        for (int i = threadIdx.x; i < 4 * BINS / 8; i += blockDim.x) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(&hist[8 * i]);
-            const uint4 b = *reinterpret_cast<const uint4 *>(&hist[8 * i + 4]);
-            uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
+        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are staged instead, as 16-bit counts, and
+        // quad2_finalize_kernel gathers the four of every entry.  Layout (quad2_index.hpp): plane i of the TRUE bucket,
+        // t-major -- the bins of one t (the top four bits of the low part, which select the scramble mask) belong to one
+        // true bucket and leave as one piece of 1 KiB; 16 pieces per form.  A count that does not fit 16 bits (a k-mer
+        // seen 65536 times in one batch within ONE of its four positions) goes to the table directly and is staged as zero.
+        if constexpr (C::kTwoLevel) {
+            using Q = Quad2Index<K>;
+            uint16_t *dst = reinterpret_cast<uint16_t *>(stage);
+            for (int j = threadIdx.x; j < 4 * BINS / 8; j += blockDim.x) {
+                const int i = j >> 10;                                     // plane (form)
+                const uint32_t o = ((uint32_t)j & 1023u) * 8u;           // first of eight words of the plane
+                const uint32_t local = Q::bin_of_word(i, o);              // ... which are eight consecutive bins
+                const uint4 a = *reinterpret_cast<const uint4 *>(&hist[i * BINS + local]);
+                const uint4 b = *reinterpret_cast<const uint4 *>(&hist[i * BINS + local + 4]);
+                uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c[e] >> 16) {
-                        const uint32_t bin = 8u * (uint32_t)i + (uint32_t)e;
-                        atomicAdd(&table[quad_bin_index<K>(row, coarse, (int)(bin / BINS), bin % BINS)], (unsigned long long)c[e]);
-                        c[e] = 0;
-                    }
+                    for (int e = 0; e < 8; ++e)
+                        if (c[e] >> 16) {
+                            atomicAdd(&table[quad_bin_index<K>(row, coarse, i, local + (uint32_t)e)], (unsigned long long)c[e]);
+                            c[e] = 0;
+                        }
+                }
+                *reinterpret_cast<uint4 *>(dst + Q::word_pos(i, coarse, row, o)) =
+                    make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
             }
-            *reinterpret_cast<uint4 *>(dst + 8 * i) = make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
         }
         return;
     }
@@ -912,49 +926,116 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     }
 }
 
-// Q4 (k = 13..16): table[idx] += the four staged form counts of entry idx.  Form i of entry idx lives in the staged
-// histogram of (scrambled) bucket (coarse ^ smask1(t), fine ^ smask(t)) at local = hi << s | lo, s = 7 + 2i, where
-// lo = idx's low s bits, t = lo's top four bits, fine / coarse / hi the fields above.  Exclusive per entry: plain adds.
-//   Read as they lie, the form-0 counts of consecutive entries come in pieces of 8 (16 bytes: t changes every eight
-// entries and sends the next piece to another bucket's histogram, megabytes away) -- 1.7 x the bytes at k = 15 (PMC), 4 x
-// the time at k = 16.  So a workgroup takes a set of entries that is CLOSED under the scrambling: for one hi field of
-// form 0 and one orbit {(c0 ^ smask1(m), f0 ^ smask(m)), m = 0..15} of (coarse, fine) pairs, the 16 runs of 128
-// entries.  Their form-0 counts are the 16 complete 128-bin runs of the orbit's histograms (run j, entry l sits in
-// member j ^ (l >> 3)): read coalesced into LDS, picked from there.  Forms 1..3 come in pieces of 64 bytes or more and
-// are read directly; the table is updated in runs of 1 KiB.
-template <int K>
-__global__ __launch_bounds__(256) void quad2_combine_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
+// Q4 (k = 13..16): the finalisation.  table[idx] += the four staged form counts of entry idx -- and, BALANCE, Profile.balance
+// (klib.py:285-298) in the same pass: table[idx] = v[idx] + v[rc(idx)], v = table + forms.  Balancing afterwards costs a
+// second read and write of the whole table (k = 15: 8 GiB each way, 5.8 of 31 ms); here the table is read once and written
+// once either way.
+//   Workgroup R owns set R of quad2_index.hpp: 2^14 entries = every value of the low 7 bits x every value of their
+// reverse-complement image (the top 6 bits and bit 2K-8).  rc maps set R onto set R' = rc(R), so the pair is closed:
+// the workgroup of the smaller base takes both, the other returns at once (a set that is its own partner -- even k
+// only -- is handled alone).  The ten sources (table + four forms, of R and of R') are read as THEY lie -- 16 bytes per
+// lane, consecutive lanes consecutive addresses, pieces of 256 B .. 16 KiB (stream_entry) -- and every value is added
+// into ONE LDS array indexed by the position in set R: a value of R' goes to the position of its reverse complement.
+// The array then holds out[p] = v[p] + v'[rc(p)] for every p of R, and out is symmetric: row-wise it is written to R's
+// table entries, column-wise to those of R' (rows padded to 129: both directions free of bank conflicts).  64-bit
+// LDS adds: exact for any counts.
+template <int K, bool BALANCE>
+__global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
 {
-    using C = QuadCfg<K>;
-    constexpr int CB = C::kCoarseBits;
-    __shared__ __attribute__((aligned(16))) uint16_t form0[16][128];
-    const uint32_t g = blockIdx.x;
-    const uint32_t hi0 = g >> (CB + 5), c0 = (g >> 5) & (uint32_t)(C::kCoarse - 1), f0 = (g & 31u) << 4;   // the orbit's member with fine & 15 == 0
-    {
-        const uint32_t m = threadIdx.x >> 4, part = threadIdx.x & 15u;
-        const uint32_t row_linear = (c0 ^ C::smask1(m)) * 512u + (f0 ^ C::smask(m));
-        *reinterpret_cast<uint4 *>(&form0[m][8 * part]) =
-            *reinterpret_cast<const uint4 *>(stage + ((size_t)row_linear * 4 + 0) * 8192 + ((size_t)hi0 << 7) + 8 * part);
+    using Q = Quad2Index<K>;
+    constexpr int RS = Q::kRowStride;
+    __shared__ unsigned long long acc[128 * RS];
+    const uint64_t base = Q::set_base(blockIdx.x);
+    const uint64_t pbase = BALANCE ? Q::partner_base(base) : base;
+    if (BALANCE && base > pbase) return;                        // block-uniform
+    const bool self = BALANCE && base == pbase;
+    const bool pair = BALANCE && base != pbase;
+    for (int i = threadIdx.x; i < 128 * RS; i += 1024) acc[i] = 0ull;
+    __syncthreads();
+    // a value of set R at (lo7, hi7) -> acc[hi7][lo7]; of the partner set (or, self-paired, once more) -> the transposed place
+    auto add_own = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
+        if (v) atomicAdd(&acc[hi7 * RS + lo7], v);
+    };
+    auto add_partner = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
+        if (v) atomicAdd(&acc[Q::partner_hi7(lo7) * RS + Q::partner_lo7(hi7)], v);
+    };
+    // ---- the table itself: 8192 vectors of two entries per set
+#pragma unroll 1
+    for (int half = 0; half < (pair ? 2 : 1); ++half) {
+        const uint64_t b = half ? pbase : base;
+        ulonglong2 t[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)it);
+            uint32_t lo7, hi7;
+            Q::stream_entry(4, q, lo7, hi7);
+            t[it] = *reinterpret_cast<const ulonglong2 *>(table + Q::entry(b, lo7, hi7));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)it);
+            uint32_t lo7, hi7;
+            Q::stream_entry(4, q, lo7, hi7);
+            if (half == 0) {
+                add_own(lo7, hi7, t[it].x);
+                add_own(lo7 + 1u, hi7, t[it].y);
+            }
+            if (half == 1 || self) {
+                add_partner(lo7, hi7, t[it].x);
+                add_partner(lo7 + 1u, hi7, t[it].y);
+            }
+        }
+    }
+    // ---- the four forms: 2048 vectors of eight 16-bit counts per form and set
+#pragma unroll 1
+    for (int half = 0; half < (pair ? 2 : 1); ++half) {
+        const uint64_t b = half ? pbase : base;
+        uint4 f[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int form = it >> 1;
+            const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(it & 1));
+            uint32_t lo7, hi7;
+            Q::stream_entry(form, q, lo7, hi7);
+            f[it] = *reinterpret_cast<const uint4 *>(stage + Q::stage_pos(form, Q::entry(b, lo7, hi7)));
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int form = it >> 1;
+            const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(it & 1));
+            uint32_t lo7, hi7;
+            Q::stream_entry(form, q, lo7, hi7);
+            if ((f[it].x | f[it].y | f[it].z | f[it].w) == 0u) continue;
+            const uint32_t w[4] = {f[it].x, f[it].y, f[it].z, f[it].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned long long v = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                if (half == 0) add_own(lo7 + (uint32_t)e, hi7, v);
+                if (half == 1 || self) add_partner(lo7 + (uint32_t)e, hi7, v);
+            }
+        }
     }
     __syncthreads();
-    const uint32_t l = threadIdx.x & 127u;
+    // ---- out: rows of R as they lie, rows of R' transposed
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t j = (threadIdx.x >> 7) + 2u * (uint32_t)r;
-        const uint64_t idx = ((uint64_t)hi0 << (16 + CB)) | ((uint64_t)(c0 ^ C::smask1(j)) << 16) | ((uint64_t)(f0 ^ C::smask(j)) << 7) | l;
-        uint32_t sum = form0[j ^ (l >> 3)][l];
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t v = threadIdx.x + 1024u * (uint32_t)it;
+        const uint32_t hi7 = v >> 6, lo7 = (v & 63u) * 2u;
+        ulonglong2 o;
+        o.x = acc[hi7 * RS + lo7];
+        o.y = acc[hi7 * RS + lo7 + 1u];
+        *reinterpret_cast<ulonglong2 *>(table + Q::entry(base, lo7, hi7)) = o;
+    }
+    if (pair) {
 #pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            const int sh = 7 + 2 * i;
-            const uint32_t lopart = (uint32_t)idx & ((1u << sh) - 1u);
-            const uint32_t fine = (uint32_t)(idx >> sh) & 511u;
-            const uint32_t coarse = (uint32_t)(idx >> (sh + 9)) & (uint32_t)(C::kCoarse - 1);
-            const uint32_t hipart = (uint32_t)(idx >> (sh + 9 + CB));
-            const uint32_t t = lopart >> (sh - 4);
-            const uint32_t row_linear = (coarse ^ C::smask1(t)) * 512u + (fine ^ C::smask(t));
-            sum += (uint32_t)stage[((size_t)row_linear * 4 + i) * 8192 + ((hipart << sh) | lopart)];
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t v = threadIdx.x + 1024u * (uint32_t)it;
+            const uint32_t hi7 = v >> 6, lo7 = (v & 63u) * 2u;            // an entry pair of R'
+            ulonglong2 o;
+            o.x = acc[Q::partner_hi7(lo7) * RS + Q::partner_lo7(hi7)];
+            o.y = acc[Q::partner_hi7(lo7 + 1u) * RS + Q::partner_lo7(hi7)];
+            *reinterpret_cast<ulonglong2 *>(table + Q::entry(pbase, lo7, hi7)) = o;
         }
-        if (sum) table[idx] += (unsigned long long)sum;
     }
 }
 

@@ -417,6 +417,85 @@ ORACLE_API void kpal_oracle_distance_matrix(const int64_t *profiles, int P, int 
                                             do_balance, metric);
 }
 
+/* The same matrix on T threads (test infrastructure for BASELINE config 5 at its stated size: 2016 pairs of 4^12 bins are
+ * ~200 s on one core).  Every profile is balanced ONCE when do_balance is set -- identical to the balanced copies
+ * kdistlib.py:136-141 makes inside every pair -- and the pairs are dealt to the threads; each pair's value is computed by
+ * the single-threaded functions above (same summation order). */
+typedef struct {
+    const int64_t *profiles;
+    int P, k, metric, T, t;
+    double *out;
+} matrix_job;
+
+static void *matrix_worker(void *arg)
+{
+    matrix_job *m = (matrix_job *)arg;
+    const size_t n = (size_t)1 << (2 * m->k);
+    size_t o = 0;
+    for (int i = 1; i < m->P; i++)
+        for (int j = 0; j < i; j++, o++)
+            if ((int)(o % (size_t)m->T) == m->t)
+                m->out[o] = kpal_oracle_distance(m->profiles + (size_t)i * n, m->profiles + (size_t)j * n, m->k, 0, m->metric);
+    return NULL;
+}
+
+typedef struct {
+    int64_t *profiles;
+    int P, k, T, t;
+} balance_job;
+
+static void *balance_worker(void *arg)
+{
+    balance_job *b = (balance_job *)arg;
+    const size_t n = (size_t)1 << (2 * b->k);
+    for (int p = b->t; p < b->P; p += b->T) kpal_oracle_balance(b->profiles + (size_t)p * n, b->k);
+    return NULL;
+}
+
+ORACLE_API int kpal_oracle_distance_matrix_mt(const int64_t *profiles, int P, int k, int do_balance, int metric, int threads,
+                                              double *out)
+{
+    if (P < 2) return 0;
+    const size_t n = (size_t)1 << (2 * k);
+    int T = threads < 1 ? 1 : (threads > 256 ? 256 : threads);
+    int64_t *work = NULL;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    char *joinable = (char *)calloc(T, 1);
+    matrix_job *jobs = (matrix_job *)malloc(sizeof(matrix_job) * T);
+    balance_job *bjobs = (balance_job *)malloc(sizeof(balance_job) * T);
+    int rc = (!th || !joinable || !jobs || !bjobs) ? -2 : 0;
+    if (rc == 0 && do_balance) {
+        work = (int64_t *)malloc((size_t)P * n * sizeof(int64_t));
+        if (!work) rc = -2;
+        else {
+            memcpy(work, profiles, (size_t)P * n * sizeof(int64_t));
+            for (int t = 0; t < T; t++) {
+                bjobs[t].profiles = work; bjobs[t].P = P; bjobs[t].k = k; bjobs[t].T = T; bjobs[t].t = t;
+                joinable[t] = pthread_create(&th[t], NULL, balance_worker, &bjobs[t]) == 0;
+                if (!joinable[t]) balance_worker(&bjobs[t]);
+            }
+            for (int t = 0; t < T; t++)
+                if (joinable[t]) pthread_join(th[t], NULL);
+        }
+    }
+    if (rc == 0) {
+        for (int t = 0; t < T; t++) {
+            jobs[t].profiles = work ? work : profiles; jobs[t].P = P; jobs[t].k = k; jobs[t].metric = metric;
+            jobs[t].T = T; jobs[t].t = t; jobs[t].out = out;
+            joinable[t] = pthread_create(&th[t], NULL, matrix_worker, &jobs[t]) == 0;
+            if (!joinable[t]) matrix_worker(&jobs[t]);
+        }
+        for (int t = 0; t < T; t++)
+            if (joinable[t]) pthread_join(th[t], NULL);
+    }
+    free(work);
+    free(bjobs);
+    free(jobs);
+    free(joinable);
+    free(th);
+    return rc;
+}
+
 /* a13: strand-balance score of `kpal showbalance`.  kpal/kmer.py:243-245:
  *   forward, reverse = profile.split(); metrics.multiset(forward, reverse, pairwise['prod']) */
 ORACLE_API double kpal_oracle_strand_balance(const int64_t *counts, int k, int pairwise)

@@ -200,11 +200,22 @@ def profile_distance(left, right, length, do_balance=False, do_positive=False, d
                                               METRIC[metric])
 
 
-def distance_matrix_values(profiles, length, do_balance=False, metric='prod'):
-    """Lower-triangle values in kdistlib.distance_matrix order (kdistlib.py:179-186)."""
-    p = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.int64) for x in profiles]))
+def distance_matrix_values(profiles, length, do_balance=False, metric='prod', threads=1):
+    """Lower-triangle values in kdistlib.distance_matrix order (kdistlib.py:179-186).  ``threads`` > 1: the pairs are dealt
+    to that many threads (every value still comes from the single-threaded pair function)."""
+    p = profiles if isinstance(profiles, np.ndarray) and profiles.ndim == 2 else np.stack([np.asarray(x, dtype=np.int64) for x in profiles])
+    p = np.ascontiguousarray(p, dtype=np.int64)
     P = p.shape[0]
     out = np.empty(P * (P - 1) // 2, dtype=np.float64)
+    if threads > 1:
+        L = lib()
+        L.kpal_oracle_distance_matrix_mt.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_f64p]
+        L.kpal_oracle_distance_matrix_mt.restype = ctypes.c_int
+        rc = L.kpal_oracle_distance_matrix_mt(p.ctypes.data_as(_c_i64p), P, length, int(do_balance), METRIC[metric], int(threads),
+                                              out.ctypes.data_as(_c_f64p))
+        if rc:
+            raise MemoryError('kpal_oracle_distance_matrix_mt failed (%d)' % rc)
+        return out
     lib().kpal_oracle_distance_matrix(p.ctypes.data_as(_c_i64p), P, length, int(do_balance),
                                       METRIC[metric], out.ctypes.data_as(_c_f64p))
     return out

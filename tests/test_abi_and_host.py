@@ -181,6 +181,25 @@ def test_world_size_2_gloo_reduce(tmp_path):
     assert 'REDUCER_OK' in outs[0], outs[0]
 
 
+def test_bench_launcher_spawns_the_ranks():
+    """`python bench.py --gpus 2` as a PLAIN command (how the driver starts the scaling runs): the launcher must start the
+    two ranks itself through torch.distributed.run, before anything touches a GPU, relay rank 0's JSON line and exit with
+    the ranks' status.  --stub replaces the GPU work by CPU tensors over gloo (plumbing only, value null)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['checksum_ok'] is True and line['steps'] == 3
+    # a failing rank fails the launcher
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=dict(env, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES=''), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+
+
 def test_kmer_caller_host_logic():
     """kpal_amd.kmer (kpal/kmer.py:41-48,112-146,541-700): handle names, custom functions, and the argument
     errors that are raised before any profile is touched."""

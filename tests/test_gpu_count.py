@@ -21,12 +21,21 @@ def sha(v):
     return hashlib.sha256(np.ascontiguousarray(v, dtype='<i8').tobytes()).hexdigest()
 
 
+# The pipelines AUTO no longer takes for any input -- the exact-offset 'partition' (round 1) and the level-2 variants
+# KPAL_LEVEL2=0/1 of the two-level path -- keep ONE cross-check each in the default run (test_small_partition_batches,
+# test_partition_pipelines_on_skewed_inputs, test_two_level_variants_of_level2); KPAL_TEST_RETIRED=1 puts them back into
+# every strategy loop.
+RETIRED = os.environ.get('KPAL_TEST_RETIRED', '0') not in ('', '0')
+retired = pytest.mark.skipif(not RETIRED, reason='retired pipeline: KPAL_TEST_RETIRED=1 runs its full matrix')
+
+
 def strategies(k):
     s = ['auto', 'global_atomic']
     if k <= 7:
         s.append('lds_direct')
     if 8 <= k <= 12:
-        s.append('partition')
+        if RETIRED:
+            s.append('partition')
         s.append('partition_chunked')
         s.append('partition_quads')
     if 13 <= k <= 16:
@@ -447,6 +456,24 @@ def test_full_size_k15(ctx):
         other.sync()
         assert torch.equal(dist.table_as_tensor(other), full)
         torch.cuda.synchronize()
+        # count + balance as bench.py --k 15 times it: Profile.balance fused into the finalisation of the quad pipeline
+        # (kpal_count_balance) against the round-1 pipeline's table balanced by the stand-alone kernel -- all 4^15 bins
+        other.balance_device(k, other.count_table()[0])
+        other.sync()
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, nbytes)
+        ctx.count_balance()
+        ctx.count_finish(to_host=False)
+        ctx.sync()
+        bal = dist.table_as_tensor(ctx)
+        assert int(bal.sum()) == 2 * n_reads * (150 - k + 1)
+        assert torch.equal(bal, dist.table_as_tensor(other))
+        torch.cuda.synchronize()
+        ctx.count_begin(k)                       # the unbalanced table again, for the checks below
+        ctx.count_feed_device(d, nbytes)
+        ctx.count_finish(to_host=False)
+        ctx.sync()
+        full = dist.table_as_tensor(ctx)
         # linearity: the two half-shards counted by the second context (quad pipeline) add up to the same table
         half = n_reads // 2
         other.count_begin(k)
@@ -491,7 +518,7 @@ def test_full_size_k15(ctx):
         ctx.free(d)
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '2'])
+@pytest.mark.parametrize('mode', [pytest.param('0', marks=retired), pytest.param('1', marks=retired), '2'])
 def test_two_level_k15_against_oracle(mode):
     """k = 15 (64 coarse buckets) through every level-2 pipeline, on inputs large enough for AUTO to take
     the two-level path (feeds above 256 KiB), bin for bin against the oracle: noisy reads, one unbroken
@@ -520,6 +547,94 @@ def test_two_level_k15_against_oracle(mode):
                 del got
     finally:
         c2.close()
+
+
+def test_count_balance_fused_with_the_finalisation():
+    """kpal_count_balance (count + balance, the unit of the north-star metric).  On the two-level quad pipeline the balance
+    is fused into the pass that adds the staged forms to the table (quad2_finalize_kernel<K, true>): against
+    oracle.balance(oracle.count) for k = 13, 14, 15 on noisy reads, one unbroken sequence and skewed composition; with two
+    feeds (the first one's forms are flushed unbalanced, the second's finalisation balances the sum); with entries beyond
+    32 bits already in the table; through kpal_balance_device on the table pointer; and on the pipelines without a staged
+    finalisation (k = 5, 12: the stand-alone balance kernel)."""
+    from kpal_amd import _native
+    c2 = _native.Context(_native.default_device())
+    rs = np.random.RandomState(23)
+    buf = oracle.synth_reads(71, 0, 30000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    skew = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=4 << 20, p=[.4, .1, .1, .4])].copy()
+    skew[1 << 20:(1 << 20) + 500000] = ord('A')
+    try:
+        for k in (13, 14, 15):
+            for data in (buf, seq, skew):
+                want = oracle.balance(oracle.count_flat(data, k, threads=8), k)
+                c2.count_begin(k, 'partition2_quads')
+                c2.count_feed(data)
+                assert c2.count_last_plan()[0] == 'partition2_quads'
+                c2.count_balance()
+                assert np.array_equal(c2.count_finish(), want), k
+                del want
+            # two feeds + entries beyond 32 bits that are already in the table when the last finalisation runs
+            a, b = buf[:buf.size // 3], buf[buf.size // 3:]
+            c2.count_begin(k, 'partition2_quads')
+            c2.count_feed(a)
+            ptr, bins = c2.count_table()
+            big_at = np.array([0, 4 ** k - 1, 12345, 4 ** k // 2 + 77], dtype=np.int64)     # AAA.., TTT.. (partners), two others
+            unb = oracle.count_flat(a, k) + oracle.count_flat(b, k)
+            for j, at in enumerate(big_at):
+                v = np.empty(1, dtype=np.int64)
+                c2.d2h(v, ptr + int(at) * 8)
+                v[0] += (1 << 40) + j
+                c2.h2d(ptr + int(at) * 8, v)
+                unb[at] += (1 << 40) + j
+            c2.count_feed(b)
+            c2.balance_device(k, ptr)            # == kpal_count_balance: the table pointer of a running count
+            assert np.array_equal(c2.count_finish(), oracle.balance(unb, k)), k
+            del unb
+        for k in (5, 12):
+            c2.count_begin(k)
+            c2.count_feed(buf)
+            c2.count_balance()
+            assert np.array_equal(c2.count_finish(), oracle.balance(oracle.count_flat(buf, k), k))
+    finally:
+        c2.close()
+
+
+def test_count_balance_fused_k16_on_device():
+    """k = 16 (32 GiB table, self-paired finalisation sets exist for even k): the fused finalisation + balance against the
+    plain finalisation followed by the stand-alone balance kernel, compared on the device; and the plain finalisation
+    against the global-atomic kernel."""
+    torch = pytest.importorskip('torch')
+    from kpal_amd import _native, dist
+    k = 16
+    buf = oracle.synth_reads(72, 0, 60000, 150, noisy=True)
+    a = _native.Context(_native.default_device())
+    b = _native.Context(_native.default_device())
+    try:
+        a.count_begin(k, 'partition2_quads')
+        a.count_feed(buf)
+        assert a.count_last_plan()[0] == 'partition2_quads'
+        a.count_finish(to_host=False)            # plain finalisation
+        b.count_begin(k, 'global_atomic')
+        b.count_feed(buf)
+        b.count_finish(to_host=False)
+        a.sync()
+        b.sync()
+        ta, tb = dist.table_as_tensor(a), dist.table_as_tensor(b)
+        assert int(ta.sum()) == int(tb.sum()) > 0
+        assert torch.equal(ta, tb)
+        torch.cuda.synchronize()
+        b.balance_device(k, b.count_table()[0])  # stand-alone balance of the atomic kernel's table
+        a.count_begin(k, 'partition2_quads')
+        a.count_feed(buf)
+        a.count_balance()                        # fused
+        a.count_finish(to_host=False)
+        a.sync()
+        b.sync()
+        assert torch.equal(dist.table_as_tensor(a), dist.table_as_tensor(b))
+        torch.cuda.synchronize()
+    finally:
+        a.close()
+        b.close()
 
 
 def test_partition_pipelines_on_skewed_inputs(ctx):

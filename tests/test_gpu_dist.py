@@ -24,7 +24,7 @@ def test_bench_single_gpu_small():
     """bench.py contract on a small workload: one JSON line with roofline and a true checksum."""
     import json
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
-                        '--reads', '2000000', '--cpu-reads', '200000'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        '--reads', '2000000', '--cpu-reads', '200000', '--profile-reads', '100000'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -33,3 +33,25 @@ def test_bench_single_gpu_small():
     assert line['checksum_ok'] and line['n_gpus'] == 1 and line['unit'] == 'Gbases/s'
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
     assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] == 1
+    assert line['rccl_ranks'] == 1 and line['roofline']['pipeline']['frac'] > 0
+    # the extras of the default run: BASELINE configs 4 and 5 and the end-to-end figure, each with its own parity flag
+    ex = line['extra']
+    for name in ('end_to_end', 'k15', 'matrix_prod', 'matrix_euclidean'):
+        assert 'error' not in ex[name], (name, ex[name])
+        assert ex[name]['checksum_ok'] is True, (name, ex[name])
+    assert ex['k15']['ms_per_step'] > 0 and ex['k15']['roofline']['pipeline']['frac'] > 0
+    assert ex['matrix_prod']['parity_pairs'] == 28 and ex['matrix_euclidean']['roofline']['bound'] == 'mfma'
+    assert ex['end_to_end']['h2d_s'] > 0 and ex['end_to_end']['d2h_s'] > 0
+
+
+def test_library_rccl_world_1():
+    """The in-library multi-GPU entry points on one GPU (world size 1; the 8-GPU run is the driver's): communicator from a
+    unique id, kpal_comm_reduce_table in its serial and its pipelined form (second stream, side buffers alternating over
+    three steps) + balance, against oracle.balance(oracle.count).  In a child process: a communicator that cannot be
+    built must not take the test session down."""
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_library_check.py')], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    assert 'RCCL_LIBRARY_OK' in out

@@ -154,11 +154,14 @@ def test_from_fasta_by_record_batched(ctx, monkeypatch):
     from kpal_amd import klib
     rnd = random.Random(21)
     text = '>r1 first\nACGTNACGT\n>\nAC\n>r3\n\n>r4\nA\n>r5\nC\n>r6\nGGGTTTAAACCC\n' + random_fasta(rnd, 300, 700)
-    recs = seqio_records(text)
+    head = '>r1 first\nACGTNACGT\n>\nAC\n>r3\n\n>r4\nA\n>r5\nC\n>r6\nGGGTTTAAACCC\n'
+    short = head + random_fasta(rnd, 24, 700)            # k = 12: one 128 MiB table per record comes back over PCIe
     for k in (1, 3, 8, 12):
+        text_k = short if k == 12 else text
+        recs = seqio_records(text_k)
         for batch in (1 << 30, 3 * 8 * 4 ** k):          # everything in a few batches / three records per batch
             monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', batch)
-            profiles = list(klib.Profile.from_fasta_by_record(io.StringIO(text), k, prefix='p'))
+            profiles = list(klib.Profile.from_fasta_by_record(io.StringIO(text_k), k, prefix='p'))
             assert len(profiles) == len(recs)
             for i, (p, (name, seq)) in enumerate(zip(profiles, recs)):
                 assert p.name == 'p_' + (name or str(i + 1))

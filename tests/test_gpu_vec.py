@@ -288,9 +288,11 @@ def test_config5_matrix_k12_64_profiles(ctx, n_reads):
     """BASELINE config 5 at its stated size: 64 profiles at k = 12, profile p = the
     count of n_reads synthetic reads with seed 100 + p (dense: 2 M reads, mean 16.6 per bin; sparse: 100 k
     reads, ~43 % zero bins), kdistlib.distance_matrix values through kpal_distance_matrix_device (the
-    super-tile kernel) for prod / sum / euclidean with and without balancing (kdistlib.py:164-186):
-      * all 2016 entries against the pair kernel (IEEE divisions, another summation order),
-      * 64 random entries against the oracle (<= 1e-9 relative; euclidean bit-identical),
+    super-tile kernels; euclidean on the matrix cores) for prod / sum / euclidean with and without balancing
+    (kdistlib.py:164-186):
+      * ALL 2016 entries of all six matrices against the oracle (its pair function on every pair, dealt to the host's
+        cores): <= 1e-9 relative, euclidean bit-identical,
+      * 150 entries against the pair kernel (IEEE divisions, another summation order),
       * the text of a 12-profile sub-matrix through kdistlib.distance_matrix against the oracle's text."""
     from kpal_amd import klib, kdistlib
     k, P = 12, 64
@@ -298,37 +300,35 @@ def test_config5_matrix_k12_64_profiles(ctx, n_reads):
     rs = np.random.RandomState(n_reads % 1000 + 5)
     d = ctx.alloc(n_reads * 151)
     dprof = ctx.alloc(P * n * 8)
-    host = []
+    host = np.empty((P, n), dtype=np.int64)
+    threads = min(64, os.cpu_count() or 1)
     try:
         for p in range(P):
             ctx.synth_reads_device(100 + p, 0, n_reads, 150, d)
             ctx.count_begin(k)
             ctx.count_feed_device(d, n_reads * 151)
-            c = ctx.count_finish()
-            assert c.sum() == n_reads * (150 - k + 1)
-            host.append(c)
-            ctx.h2d(dprof + p * n * 8, c)
+            host[p] = ctx.count_finish()
+            assert host[p].sum() == n_reads * (150 - k + 1)
+        ctx.h2d(dprof, host)
         if n_reads == 100_000:
             assert 0.40 < np.mean(host[0] == 0) < 0.46          # the sparse variant really is sparse
         pairs = [(i, j) for i in range(1, P) for j in range(i)]
-        pick = [pairs[t] for t in rs.choice(len(pairs), 64, replace=False)]
+        pick = [pairs[t] for t in rs.choice(len(pairs), 150, replace=False)]
         for metric in ('prod', 'sum', 'euclidean'):
             code = ('prod', 'sum', 'euclidean').index(metric)
             for bal in (False, True):
                 got = ctx.distance_matrix_device(P, k, dprof, code, bal)
                 assert got.shape == (2016,)
-                byp = np.array([ctx.pair_distance_device(n, dprof + i * n * 8, dprof + j * n * 8, code, bal, k) for i, j in pairs])
+                want = oracle.distance_matrix_values(host, k, bal, metric, threads=threads)
                 if metric == 'euclidean':
-                    np.testing.assert_array_equal(got, byp)
+                    np.testing.assert_array_equal(got, want)
                 else:
-                    np.testing.assert_allclose(got, byp, rtol=RTOL, atol=0)
-                for i, j in pick[:64 if not bal else 16]:
-                    want = oracle.distance(host[i], host[j], k, bal, metric)
+                    rel = np.abs(got - want) / np.abs(want)
+                    assert rel.max() <= RTOL, (metric, bal, float(rel.max()), int(rel.argmax()))
+                for i, j in pick:
+                    byp = ctx.pair_distance_device(n, dprof + i * n * 8, dprof + j * n * 8, code, bal, k)
                     g = got[i * (i - 1) // 2 + j]
-                    if metric == 'euclidean':
-                        assert g == want, (metric, bal, i, j)
-                    else:
-                        assert close(g, want), (metric, bal, i, j, g, want)
+                    assert (g == byp) if metric == 'euclidean' else close(g, byp), (metric, bal, i, j, g, byp)
         # text (precision <= 8) of a sub-matrix through the drop-in API
         sub = [klib.Profile(host[p], 'p%d' % p) for p in range(0, 60, 5)]
         for prec in (3, 8):
