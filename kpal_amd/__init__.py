@@ -8,7 +8,7 @@
 The hot path lives in ``libkpal_hip.so`` (hand-written HIP for gfx950, C-ABI in
 ``include/kpal_hip.h``); build it with ``__graft_entry__.build()``.
 """
-__version__ = '0.2.0'
+__version__ = '0.3.0'
 
 from . import _native, metrics, klib, kdistlib, files, kmer, dist  # noqa: E402,F401
 from .files import FileType, ProfileFileType  # noqa: F401

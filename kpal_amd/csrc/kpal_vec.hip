@@ -328,12 +328,27 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
             for (int sj = 0; sj <= si; ++sj) supers.push_back(make_int2(si, sj));
         const uint32_t nsuper = (uint32_t)supers.size();
         gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / kSuperBins, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 8 / nsuper)));
-        CHK(ensure(ctx, ctx->scratch[3], (size_t)nsuper * sizeof(int2)));
+        CHK(ensure(ctx, ctx->scratch[3], (size_t)nsuper * sizeof(int2) + 16));
         HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, supers.data(), (size_t)nsuper * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
         CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
         Partial *pp = (Partial *)ctx->partials.p;
         const int2 *dt = (const int2 *)ctx->scratch[3].p;
-        if (metric == 0) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<0>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
+        // multiset 'prod' as a difference of reciprocals (matrix_rdiff_kernel; KPAL_MATRIX_RDIFF=0 forces the pair-of-counts
+        // kernel): valid while every count is below 2^20 -- the kernel says whether it saw a larger one
+        static const bool allow_rdiff = [] { const char *e = getenv("KPAL_MATRIX_RDIFF"); return !e || atoi(e) != 0; }();
+        bool rdiff_done = false;
+        if (metric == 0 && allow_rdiff) {
+            uint32_t *big = (uint32_t *)((int2 *)ctx->scratch[3].p + nsuper);
+            HIPCHK(hipMemsetAsync(big, 0, sizeof(uint32_t), ctx->stream));
+            HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));   // (.s / .m of a slot come from different threads)
+            LAUNCH(ctx, "matrix_rdiff", matrix_rdiff_kernel, dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp, big);
+            uint32_t saw_big = 0;
+            HIPCHK(hipMemcpyAsync(&saw_big, big, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));   // (also: `supers` was read by the asynchronous copy above)
+            rdiff_done = saw_big == 0;
+        }
+        if (rdiff_done) {
+        } else if (metric == 0) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<0>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
         else if (metric == 1) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<1>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
         else LAUNCH(ctx, "matrix_super", (matrix_super_kernel<2>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
         HIPCHK(hipStreamSynchronize(ctx->stream));   // `supers` is read by the asynchronous copy above

@@ -9,16 +9,17 @@
 // and the k-mer was histogrammed by the workgroup of the SCRAMBLED bucket (coarse ^ smask1(t), fine ^ smask(t)) in bin
 // local = hipart << s | lopart (quad_bin_index).
 //
-// STAGING LAYOUT (16-bit counts).  Plane i of TRUE bucket (coarse, fine) holds that bucket's 8192 form-i bins ordered
-// t-major:   pos = ((coarse * 512 + fine) * 4 + i) * 8192 + t * 512 + hipart * 2^(s-4) + (lopart mod 2^(s-4)).
-// A histogram workgroup writes 16 pieces of 1 KiB per form (one per t: the bins of one t belong to one true bucket); a
-// reader that lets the low bits of idx and its top bits run finds every form in pieces of >= 256 bytes -- the
-// scrambling (which exists to spread compositional skew over the scatter rows) no longer shows in the layout.
+// STAGING LAYOUT (16-bit counts).  A histogram workgroup stores its four planes of 8192 bins as ONE contiguous 64 KiB block
+// (scattered 1 KiB pieces cost the histogram kernel 20 % at k = 15), each plane ordered t-major:
+//        pos = ((scrambled coarse * 512 + scrambled fine) * 4 + i) * 8192 + t * 512 + hipart * 2^(s-4) + (lopart mod 2^(s-4)).
+// The bins of one t are the bins of ONE true bucket, so a reader that lets the low bits of idx and its top bits run finds
+// every form in pieces of 256 bytes (form 3) to 1 KiB: the scrambling (which exists to spread compositional skew over the
+// scatter rows) only decides which block a piece lies in.
 //
 // SETS.  Finalisation workgroup R owns the 2^14 entries whose bits outside FREE equal R's, FREE = the low 7 bits
 // (digits 0..2 and the low bit of digit 3) and their reverse-complement image (the top 6 bits and bit 2K-8).  The
 // reverse complement maps set R onto set R' = rc(R): balancing (out[i] = v[i] + v[rc(i)]) needs the pair (R, R') and
-// nothing else, the table is read and written in runs of 1 KiB, the forms in pieces of 256 B .. 16 KiB.
+// nothing else, the table is read and written in runs of 1 KiB, the forms in pieces of 256 B .. 1 KiB.
 #pragma once
 #include <stdint.h>
 
@@ -52,7 +53,8 @@ struct Quad2Index {
         const uint32_t coarse = (uint32_t)(idx >> (s + 9)) & kCoarseMask;
         const uint32_t hipart = (uint32_t)(idx >> (s + 9 + CB));
         const uint32_t t = lopart >> (s - 4), rest = lopart & ((1u << (s - 4)) - 1u);
-        return ((uint64_t)((coarse * 512u + fine) * 4u + (uint32_t)i) << 13) + (t << 9) + (hipart << (s - 4)) + rest;
+        const uint32_t sc = coarse ^ smask1(t), sf = fine ^ smask(t);   // the block of the workgroup that histogrammed it
+        return ((uint64_t)((sc * 512u + sf) * 4u + (uint32_t)i) << 13) + (t << 9) + (hipart << (s - 4)) + rest;
     }
     // the histogram side: word o (0 .. 8191, t-major) of plane i as written by the workgroup of scrambled bucket
     // (sc, sf): which of its LDS bins it is, and where it goes
@@ -64,9 +66,7 @@ struct Quad2Index {
     }
     static KPAL_HD uint64_t word_pos(int i, uint32_t sc, uint32_t sf, uint32_t o)
     {
-        const uint32_t t = o >> 9;
-        const uint32_t coarse = sc ^ smask1(t), fine = sf ^ smask(t);
-        return ((uint64_t)((coarse * 512u + fine) * 4u + (uint32_t)i) << 13) + o;
+        return ((uint64_t)((sc * 512u + sf) * 4u + (uint32_t)i) << 13) + o;
     }
 
     // ---- sets
@@ -102,7 +102,7 @@ struct Quad2Index {
     static KPAL_HD uint32_t partner_hi7(uint32_t lo7) { return (rc3(lo7 & 63u) << 1) | ((lo7 >> 6) ^ 1u); }
     // Stream order of the entries of a set as source `src` (0..3: the forms, 4: the table itself) sees them: position
     // q (0 .. 16383) -> (lo7, hi7), such that consecutive q are consecutive addresses of that source as far as they go
-    // (form 0: 8192 words, form 1: 2048, form 2: 512, form 3 / table: 128 entries).  q and lo7 agree in their low 3 bits.
+    // (forms 0..2: 512 words -- one t of one true bucket --, form 3 / table: 128 entries).  q and lo7 agree in their low 3 bits.
     static KPAL_HD void stream_entry(int src, uint32_t q, uint32_t &lo7, uint32_t &hi7)
     {
         uint32_t top6;

@@ -253,6 +253,12 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
             over |= (counted && !fits) ? (1u << q) : 0u;
         }
     }
+#if defined(KPAL_AB_SCATTER_NO_RIDER)   // A/B timing builds (wrong counts): what the rider path costs
+    riders = 0;
+#endif
+#if defined(KPAL_AB_SCATTER_NO_SPILL)   // A/B timing builds (wrong counts): what the overflow path costs
+    over = 0;
+#endif
     if constexpr (ITEM3) {
         // Item 16 + r of a row rides in the top bytes of dwords 4r, 4r+1, 4r+2 (one byte each; a 23-bit item leaves the
         // top byte of its own dword free).  Everything is OR-ed into rows that the flush left zeroed, so the order in which
@@ -274,6 +280,31 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
         constexpr bool direct = true;
 #else
         constexpr bool direct = DIRECT;
+#endif
+#if defined(KPAL_AB_SPILL_LANE)   // A/B: every overflowing lane reserves its own list entries (a returning LDS atomic per item, few lanes)
+        if constexpr (!direct) {
+            uint32_t at[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q) at[q] = cap;
+            if (over) {
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    if ((over >> q) & 1u) at[q] = atomicAdd(spill_n, 1u);
+            }
+            uint32_t unlisted = 0;
+#pragma unroll
+            for (int q = 0; q < N; ++q) {
+                const bool ov = (over >> q) & 1u;
+                if (ov && at[q] < cap) spill[at[q]] = QuadSpill{row[q], item[q]};
+                unlisted |= (ov && at[q] >= cap) ? (1u << q) : 0u;
+            }
+            if (__builtin_expect(__any(unlisted != 0u), 0)) {
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+                    if (__any((unlisted >> q) & 1u)) quad_items_direct<K, LEVEL>((unlisted >> q) & 1u, row[q], item[q], table, hot, coarse);
+            }
+            return over;
+        }
 #endif
         // one LDS atomic per call reserves the list entries of all the wave's overflowed items (a lane finds its own
         // with ballots and lane counts)
@@ -478,6 +509,8 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         __builtin_nontemporal_store(rec[i].y, q + 1);
         __builtin_nontemporal_store(rec[i].z, q + 2);
         __builtin_nontemporal_store(rec[i].w, q + 3);
+#elif defined(KPAL_AB_SCATTER_NO_STORE)   // A/B timing builds (wrong counts): no record stores
+        asm volatile("" ::"v"(rec[i].x ^ rec[i].y ^ rec[i].z ^ rec[i].w), "v"(o), "s"((uint32_t)sc));
 #else
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool) + sc + o) = rec[i];
 #endif
@@ -517,7 +550,11 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                 const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, (uint32_t)lane, row[q], item[q]);
             }
+#if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
+            asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
+#else
             quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
+#endif
         }
         have_rec = false;
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
@@ -786,8 +823,18 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // kPairRows: rows 2j and 2j+1 share every 128-byte line of their records.  Workgroups b and b + 8 are dispatched to
     // the same XCD (round-robin over eight) at nearly the same time: they take such a pair, so the second reader of a
     // line finds it in that XCD's L2 (or, drifting apart, in the memory-side cache).
+#if defined(KPAL_AB_HIST_ORBIT)   // A/B: the 16 workgroups of a scramble orbit dispatched next to each other (their staged pieces complete whole planes)
+    uint32_t row = C::kPairRows ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
+    uint32_t coarse = blockIdx.y;
+    if constexpr (C::kTwoLevel) {
+        const uint32_t lin = blockIdx.y * 512u + blockIdx.x, m = lin & 15u, rest = lin >> 4;
+        row = ((rest & 31u) << 4) ^ C::smask(m);
+        coarse = (rest >> 5) ^ C::smask1(m);
+    }
+#else
     const uint32_t row = C::kPairRows ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
     const uint32_t coarse = blockIdx.y;
+#endif
     const uint32_t row_linear = coarse * (C::kTwoLevel ? 512u : 0u) + row;
     nrounds += (size_t)coarse * G;
     for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
@@ -834,7 +881,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                 if (i1 & 15u) add_item(i1, std::false_type{});
                 if (i2 & 15u) add_item(i2, std::false_type{});
                 if (i3 & 15u) add_item(i3, std::false_type{});
+#if !defined(KPAL_AB_HIST_NO_RIDER)   // A/B timing builds (wrong counts): what the fifth item group costs
                 if (i4 & 15u) add_item(i4, std::false_type{});
+#endif
             }
             return;
         }
@@ -875,10 +924,14 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         while (v < nvec) {
             v += parts * 256u;
             const uint4 n0 = fetch(v), n1 = fetch(v + 64u), n2 = fetch(v + 128u), n3 = fetch(v + 192u);
+#if defined(KPAL_AB_HIST_NO_ADD)     // A/B timing builds (wrong counts): the record stream alone
+            asm volatile("" ::"v"(q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w ^ q2.x ^ q2.y ^ q2.z ^ q2.w ^ q3.x ^ q3.y ^ q3.z ^ q3.w));
+#else
             add4(q0);
             add4(q1);
             add4(q2);
             add4(q3);
+#endif
             q0 = n0;
             q1 = n1;
             q2 = n2;
@@ -889,10 +942,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     if (stage) {
         // two-level path: every table entry would receive four atomic adds (one per form, from four different
         // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are staged instead, as 16-bit counts, and
-        // quad2_finalize_kernel gathers the four of every entry.  Layout (quad2_index.hpp): plane i of the TRUE bucket,
-        // t-major -- the bins of one t (the top four bits of the low part, which select the scramble mask) belong to one
-        // true bucket and leave as one piece of 1 KiB; 16 pieces per form.  A count that does not fit 16 bits (a k-mer
-        // seen 65536 times in one batch within ONE of its four positions) goes to the table directly and is staged as zero.
+        // quad2_finalize_kernel gathers the four of every entry.  Layout (quad2_index.hpp): the workgroup's four planes as one
+        // contiguous 64 KiB block, each plane t-major -- the bins of one t (the top four bits of the low part, which select
+        // the scramble mask) are the bins of one true bucket, so the finalisation reads them as one piece of 1 KiB.  A count
+        // that does not fit 16 bits (a k-mer seen 65536 times in one batch within ONE of its four positions) goes to the
+        // table directly and is staged as zero.
         if constexpr (C::kTwoLevel) {
             using Q = Quad2Index<K>;
             uint16_t *dst = reinterpret_cast<uint16_t *>(stage);
@@ -917,6 +971,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         }
         return;
     }
+#if defined(KPAL_AB_HIST_NO_MERGE)   // A/B timing builds (wrong counts): what the merge into the table costs
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
@@ -945,19 +1002,39 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
     using Q = Quad2Index<K>;
     constexpr int RS = Q::kRowStride;
     __shared__ unsigned long long acc[128 * RS];
+#if defined(KPAL_AB_FIN_INTERLEAVE)   // A/B: consecutive workgroups alternate between neighbours in R's low bits and in its high bits (= the partner's low bits)
+    uint32_t rr = 0;
+    {
+        constexpr int SB = Q::kSetBits;
+        uint32_t b = blockIdx.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rr |= ((b >> (2 * j)) & 1u) << j;
+            rr |= ((b >> (2 * j + 1)) & 1u) << (SB - 1 - j);
+        }
+        rr |= ((b >> 8) & ((1u << (SB - 8)) - 1u)) << 4;
+    }
+    const uint64_t base = Q::set_base(rr);
+#else
     const uint64_t base = Q::set_base(blockIdx.x);
+#endif
     const uint64_t pbase = BALANCE ? Q::partner_base(base) : base;
     if (BALANCE && base > pbase) return;                        // block-uniform
     const bool self = BALANCE && base == pbase;
     const bool pair = BALANCE && base != pbase;
     for (int i = threadIdx.x; i < 128 * RS; i += 1024) acc[i] = 0ull;
     __syncthreads();
+    // Entry (lo7, hi7) of set R lives at acc[hi7][lo7 ^ swizzle]: a lane that unpacks eight consecutive 16-bit counts adds to
+    // eight consecutive entries while its neighbours add 8 entries further on -- unswizzled, the lanes of a 32-lane group
+    // would share four 8-byte banks (8-way conflicts: measured 55-70 % of the LDS cycles at LDS 55 % busy); XOR-ing the low three
+    // bits with the next three spreads them over all banks, and keeps even / odd neighbours adjacent.
+    auto at = [&](uint32_t hi7, uint32_t lo7) -> uint32_t { return hi7 * RS + (lo7 ^ ((lo7 >> 3) & 7u)); };
     // a value of set R at (lo7, hi7) -> acc[hi7][lo7]; of the partner set (or, self-paired, once more) -> the transposed place
     auto add_own = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
-        if (v) atomicAdd(&acc[hi7 * RS + lo7], v);
+        if (v) atomicAdd(&acc[at(hi7, lo7)], v);
     };
     auto add_partner = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
-        if (v) atomicAdd(&acc[Q::partner_hi7(lo7) * RS + Q::partner_lo7(hi7)], v);
+        if (v) atomicAdd(&acc[at(Q::partner_hi7(lo7), Q::partner_lo7(hi7))], v);
     };
     // ---- the table itself: 8192 vectors of two entries per set
 #pragma unroll 1
@@ -1022,8 +1099,8 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
         const uint32_t v = threadIdx.x + 1024u * (uint32_t)it;
         const uint32_t hi7 = v >> 6, lo7 = (v & 63u) * 2u;
         ulonglong2 o;
-        o.x = acc[hi7 * RS + lo7];
-        o.y = acc[hi7 * RS + lo7 + 1u];
+        o.x = acc[at(hi7, lo7)];
+        o.y = acc[at(hi7, lo7 + 1u)];
         *reinterpret_cast<ulonglong2 *>(table + Q::entry(base, lo7, hi7)) = o;
     }
     if (pair) {
@@ -1032,8 +1109,8 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
             const uint32_t v = threadIdx.x + 1024u * (uint32_t)it;
             const uint32_t hi7 = v >> 6, lo7 = (v & 63u) * 2u;            // an entry pair of R'
             ulonglong2 o;
-            o.x = acc[Q::partner_hi7(lo7) * RS + Q::partner_lo7(hi7)];
-            o.y = acc[Q::partner_hi7(lo7 + 1u) * RS + Q::partner_lo7(hi7)];
+            o.x = acc[at(Q::partner_hi7(lo7), Q::partner_lo7(hi7))];
+            o.y = acc[at(Q::partner_hi7(lo7 + 1u), Q::partner_lo7(hi7))];
             *reinterpret_cast<ulonglong2 *>(table + Q::entry(pbase, lo7, hi7)) = o;
         }
     }

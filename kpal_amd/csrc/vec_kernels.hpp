@@ -752,4 +752,128 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
         }
 }
 
+// Multiset with the 'prod' pairwise function (the default of kpal distance / matrix; metrics.py:101-123, 159-162) as a
+// difference of reciprocals:
+//        |x - y| / ((x + 1)(y + 1))  =  |(x + 1) - (y + 1)| / ((x + 1)(y + 1))  =  | 1/(y + 1) - 1/(x + 1) |.
+// With r = 1 / (count + 1) staged instead of the counts a term is ONE subtraction and ONE add of an absolute value -- two
+// fp64 instructions (matrix_super_kernel<0>: three, plus the conversions; the plain division: ~12) -- and the number of
+// terms (bins where x != 0 or y != 0) leaves the fp64 loop entirely: the loader's waves read 64 bins of one profile at a
+// time, so ONE ballot gives that row's zero mask, and the bins where BOTH profiles are zero are popcount(mask_i & mask_j),
+// two v_bcnt per pair and stage, accumulated by thread (i, j) of the 16 x 16 super-tile.
+//   Accuracy: r is within 1 ulp of 1 / (x + 1) (rcp_counts), so a term's error is at most 2^-52 (r_x + r_y) against a term
+// of at least r_x r_y (x != y: |x - y| >= 1): relative 2^-52 (x + y + 2) -- below 4.7e-10 while both counts are below 2^20,
+// and every term being non-negative that bounds the relative error of the sum as well; the contract for fp64 results is
+// 1e-9 (typical: 1e-15).  A count >= 2^20 (or negative) anywhere raises *big and the caller reruns the pair-of-counts kernel.
+//   Reciprocals of counts below 2048 come from a table in LDS (one ds_read_b64 instead of v_rcp_f64 + four fused
+// multiply-adds per staged value -- the loader would cost 60 % of the arithmetic otherwise); larger counts are computed.
+constexpr int kRdiffTable = 2048;
+__global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                           const int2 *__restrict__ supers, Partial *__restrict__ partials,
+                                                           uint32_t *__restrict__ big)
+{
+    constexpr int TILE = 4;
+    __shared__ double rstage[2][32][kSuperRow];
+    __shared__ unsigned long long zmask[2][32];
+    __shared__ double rtable[kRdiffTable];
+    for (int i = threadIdx.x; i < kRdiffTable; i += 256) rtable[i] = rcp_counts((double)i + 1.0);
+    const int si = supers[blockIdx.y].x, sj = supers[blockIdx.y].y;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int ti = si * 4 + (g >> 2), tj = sj * 4 + (g & 3);
+    const int side = (P + TILE - 1) / TILE;
+    const bool mine = ti < side && tj <= ti;           // this group's 4 x 4 tile is part of the lower triangle
+    double s[TILE][TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) s[a][b] = 0.0;
+    uint32_t both_zero = 0;                            // pair (row threadIdx.x >> 4, column threadIdx.x & 15) of the super-tile
+    bool saw_big = false;
+    // loader: value q of thread t is bin (t & 63) of staged row 4 q + (t >> 6): a wave reads one 512-byte run
+    const int lrow = threadIdx.x >> 6, lcol = threadIdx.x & 63;
+    const int64_t *src[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 4 * q + lrow;                    // 0..15 rows of the super-tile, 16..31 its columns
+        const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
+        src[q] = prof + (uint64_t)min(profile, P - 1) * n + lcol;
+    }
+    __syncthreads();                                   // the table
+    auto put = [&](int buf, int q, int64_t v) {
+        const int row = 4 * q + lrow;
+        double r;
+        if (__all((unsigned long long)v < (unsigned long long)kRdiffTable)) {   // wave-uniform
+            r = rtable[(uint32_t)v];
+        } else {
+            saw_big |= (unsigned long long)v >= (1ull << 20);
+            r = (unsigned long long)v < (unsigned long long)kRdiffTable ? rtable[(uint32_t)v & (kRdiffTable - 1)]
+                                                                         : rcp_counts((double)(uint32_t)v + 1.0);
+        }
+        rstage[buf][row][lcol] = r;
+        const unsigned long long z = __builtin_amdgcn_ballot_w64(v == 0);
+        if (lcol == 0) zmask[buf][row] = z;
+    };
+    const uint64_t chunks = n / kSuperBins;
+    int64_t next[8];
+    uint64_t c = blockIdx.x;
+    uint64_t stages = 0;
+    if (c < chunks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) put(0, q, src[q][c * kSuperBins]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; c < chunks; c += gridDim.x, ++stages) {
+        const bool more = c + gridDim.x < chunks;      // block-uniform
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) next[q] = src[q][(c + gridDim.x) * kSuperBins];
+        }
+        both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < kSuperBins / 16; ++u) {
+                double rx[TILE], ry[TILE];
+#pragma unroll
+                for (int a = 0; a < TILE; ++a) {
+                    rx[a] = rstage[cur][4 * (g >> 2) + a][16 * u + l];
+                    ry[a] = rstage[cur][16 + 4 * (g & 3) + a][16 * u + l];
+                }
+#pragma unroll
+                for (int a = 0; a < TILE; ++a)
+#pragma unroll
+                    for (int b = 0; b < TILE; ++b) s[a][b] += fabs(rx[a] - ry[b]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) put(cur ^ 1, q, next[q]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (saw_big) atomicOr(big, 1u);
+    // sums: per-group reduction over its 16 lanes (fixed order), lane 0 of the group writes .s
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            double ps = s[a][b];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 16);
+            if (mine && l == 0) {
+                const uint64_t t = (uint64_t)ti * (ti + 1) / 2 + tj;
+                partials[(t * TILE * TILE + a * TILE + b) * gridDim.x + blockIdx.x].s = ps;
+            }
+        }
+    // term counts: thread (i, j) of the super-tile writes .m = bins seen - bins where both are zero
+    {
+        const int i = si * 16 + (int)(threadIdx.x >> 4), j = sj * 16 + (int)(threadIdx.x & 15);
+        const int pti = i / TILE, ptj = j / TILE;
+        if (pti < side && ptj <= pti) {
+            const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
+            partials[(t * TILE * TILE + (i % TILE) * TILE + (j % TILE)) * gridDim.x + blockIdx.x].m = stages * kSuperBins - both_zero;
+        }
+    }
+}
+
 }  // namespace kpal

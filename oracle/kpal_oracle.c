@@ -189,10 +189,8 @@ static double np_pairwise_sum(const double *a, size_t n)
  *   return distances.sum() / (len(distances) + 1)           (123)
  * pairwise: 0 = prod, 1 = sum.  *m_out (optional) receives len(distances).
  * ------------------------------------------------------------------------------------ */
-ORACLE_API double kpal_oracle_multiset_i64(const int64_t *left, const int64_t *right, size_t n,
-                                           int pairwise, int64_t *m_out)
+static double multiset_i64_scratch(const int64_t *left, const int64_t *right, size_t n, int pairwise, int64_t *m_out, double *distances)
 {
-    double *distances = (double *)malloc((n ? n : 1) * sizeof(double));
     size_t m = 0;
     for (size_t i = 0; i < n; i++) {
         if (left[i] != 0 || right[i] != 0)
@@ -200,9 +198,17 @@ ORACLE_API double kpal_oracle_multiset_i64(const int64_t *left, const int64_t *r
                                            : pairwise_sum_i64(left[i], right[i]);
     }
     double s = np_pairwise_sum(distances, m);
-    free(distances);
     if (m_out) *m_out = (int64_t)m;
     return s / (double)(m + 1);
+}
+
+ORACLE_API double kpal_oracle_multiset_i64(const int64_t *left, const int64_t *right, size_t n,
+                                           int pairwise, int64_t *m_out)
+{
+    double *distances = (double *)malloc((n ? n : 1) * sizeof(double));
+    const double d = multiset_i64_scratch(left, right, n, pairwise, m_out, distances);
+    free(distances);
+    return d;
 }
 
 /* float64 inputs (profiles after do_scale, kdistlib.py:149-157) */
@@ -431,11 +437,19 @@ static void *matrix_worker(void *arg)
 {
     matrix_job *m = (matrix_job *)arg;
     const size_t n = (size_t)1 << (2 * m->k);
+    /* kpal_oracle_distance without its copies (nothing is balanced here, the inputs are not modified) and with ONE scratch
+     * array per thread: 64 threads allocating and freeing 128 MiB blocks per pair spend their time in the kernel's mmap lock */
+    double *scratch = m->metric == 2 ? NULL : (double *)malloc((n ? n : 1) * sizeof(double));
     size_t o = 0;
     for (int i = 1; i < m->P; i++)
         for (int j = 0; j < i; j++, o++)
-            if ((int)(o % (size_t)m->T) == m->t)
-                m->out[o] = kpal_oracle_distance(m->profiles + (size_t)i * n, m->profiles + (size_t)j * n, m->k, 0, m->metric);
+            if ((int)(o % (size_t)m->T) == m->t) {
+                const int64_t *l = m->profiles + (size_t)i * n, *r = m->profiles + (size_t)j * n;
+                if (m->metric == 2) m->out[o] = kpal_oracle_euclidean_i64(l, r, n, NULL);
+                else if (scratch) m->out[o] = multiset_i64_scratch(l, r, n, m->metric, NULL, scratch);
+                else m->out[o] = kpal_oracle_multiset_i64(l, r, n, m->metric, NULL);
+            }
+    free(scratch);
     return NULL;
 }
 

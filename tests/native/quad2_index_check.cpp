@@ -108,8 +108,8 @@ static int check_properties(int sample_sets)
                 if (q && addr != prev + 1) ++breaks;
                 prev = addr;
             }
-            // pieces: form 0 two of 8192 words, form 1 eight of 2048, form 2 32 of 512, form 3 and the table 128 of 128
-            static const int max_pieces[5] = {2, 8, 32, 128, 128};
+            // pieces: forms 0..2 32 of 512 words (one t of one true bucket each), form 3 and the table 128 of 128
+            static const int max_pieces[5] = {32, 32, 32, 128, 128};
             CHECK(breaks + 1 <= max_pieces[src], "source %d comes in %d pieces", src, breaks + 1);
         }
     }

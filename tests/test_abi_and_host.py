@@ -52,11 +52,28 @@ def test_fails_loudly_without_gpu(built):
 
 
 def test_no_oracle_import_in_product():
-    for dirpath, _, files in os.walk(os.path.join(ROOT, 'kpal_amd')):
-        for f in files:
-            if f.endswith(('.py', '.hip', '.hpp', '.h')):
-                text = open(os.path.join(dirpath, f)).read()
-                assert 'import oracle' not in text and 'from oracle' not in text and 'kpal_oracle' not in text, f
+    for top in ('kpal_amd', 'kpal', 'include'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert 'import oracle' not in text and 'from oracle' not in text and 'kpal_oracle' not in text, f
+
+
+def test_import_kpal_is_the_drop_in():
+    """`import kpal` (the reference's package name) resolves to kpal_amd's modules: stock callers run unmodified with this
+    repository first on sys.path -- `from kpal import klib`, `from kpal.kdistlib import ProfileDistance`, `kpal.kmer.main`."""
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'import kpal, kpal.klib, kpal.kmer, kpal_amd\n'
+            'from kpal.kdistlib import ProfileDistance, distance_matrix\n'
+            'from kpal import metrics, ProfileFileType\n'
+            'assert kpal.klib is kpal_amd.klib and kpal.kmer.main is kpal_amd.kmer.main\n'
+            'assert ProfileDistance is kpal_amd.kdistlib.ProfileDistance and metrics.multiset is kpal_amd.metrics.multiset\n'
+            'print("SHIM_OK")\n') % ROOT
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and b'SHIM_OK' in p.stdout, p.stdout.decode()[-2000:]
+    p = subprocess.run([sys.executable, '-m', 'kpal', '--help'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and b'count' in p.stdout and b'matrix' in p.stdout
 
 
 def test_fasta_tokeniser_and_profile_surface():
@@ -179,6 +196,23 @@ def test_world_size_2_gloo_reduce(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GLOO_OK %d' % (1001 * 145) in outs[0]
     assert 'REDUCER_OK' in outs[0], outs[0]
+
+
+def test_quad2_index_arithmetic(tmp_path):
+    """The index arithmetic of the two-level quad pipeline's finalisation (kpal_amd/csrc/quad2_index.hpp: staging layout,
+    reverse-complement-closed sets, stream orders, partner positions) on the host: the functions the device kernels use
+    drive a CPU emulation of staging + finalisation (plain and balancing) at k = 13 over random forms and tables, compared
+    with v = T + forms and out[i] = v[i] + v[rc(i)]; single sets incl. self-paired ones for k = 13..16
+    (tests/native/quad2_index_check.cpp)."""
+    import shutil
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'quad2_index_check')
+    b = subprocess.run(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'native', 'quad2_index_check.cpp')],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert b.returncode == 0, b.stdout.decode()[-3000:]
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and 'QUAD2_INDEX_OK' in r.stdout.decode(), r.stdout.decode()[-3000:]
 
 
 def test_bench_launcher_spawns_the_ranks():
