@@ -843,6 +843,17 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // Fast path: one ds_add per k-mer.  GUARD = true (skewed input only, chosen per 16-byte load when the wave's
     // first items repeat): per form the occurrences of the first active lane's bin are counted with a ballot and
     // those lanes add to private dummy words -- 64 adds to one LDS address serialise.
+    // Two-level path: the planes are staged t-major (below), i.e. read from LDS with the hipart running fastest -- rows of 128
+    // (form 0) or 512 (form 1) words apart, all in the same banks.  So the bins of those two forms are kept swizzled in LDS:
+    // low bits of the hipart XOR-ed into bank bits that the staging read holds fixed (8 consecutive bins stay 8 consecutive,
+    // aligned words).  The adds hit random bins either way.
+    auto stage_swizzle = [](int i, uint32_t local) -> uint32_t {
+        if constexpr (C::kTwoLevel) {
+            if (i == 0) return local ^ (((local >> 7) & 7u) << 3);                                   // hipart[2:0] -> bits 5:3 (t's low bits)
+            if (i == 1) return local ^ (((local >> 9) & 1u) << 5) ^ (((local >> 10) & 3u) << 3);   // hipart[0] -> bit 5, hipart[2:1] -> bits 4:3
+        }
+        return local;
+    };
     auto add_item = [&](uint32_t it, auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
         // bin of k-mer i in its form: the low 6-2i bits of hi6 above the top L-6+2i bits of low -- with the item laid out
@@ -850,7 +861,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t counted = __builtin_amdgcn_ubfe(it, 3 - i, 1);
-            const uint32_t local = __builtin_amdgcn_ubfe(it, 10 - 2 * i, L);
+            const uint32_t local = stage_swizzle(i, __builtin_amdgcn_ubfe(it, 10 - 2 * i, L));
             if constexpr (GUARD) {
                 const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
                 const bool eq = counted && local == hot;
@@ -954,8 +965,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                 const int i = j >> 10;                                     // plane (form)
                 const uint32_t o = ((uint32_t)j & 1023u) * 8u;           // first of eight words of the plane
                 const uint32_t local = Q::bin_of_word(i, o);              // ... which are eight consecutive bins
-                const uint4 a = *reinterpret_cast<const uint4 *>(&hist[i * BINS + local]);
-                const uint4 b = *reinterpret_cast<const uint4 *>(&hist[i * BINS + local + 4]);
+                const uint32_t phys = stage_swizzle(i, local);            // (aligned blocks of eight stay together)
+                const uint4 a = *reinterpret_cast<const uint4 *>(&hist[i * BINS + phys]);
+                const uint4 b = *reinterpret_cast<const uint4 *>(&hist[i * BINS + phys + 4]);
                 uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
 #pragma unroll
@@ -1002,22 +1014,24 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
     using Q = Quad2Index<K>;
     constexpr int RS = Q::kRowStride;
     __shared__ unsigned long long acc[128 * RS];
-#if defined(KPAL_AB_FIN_INTERLEAVE)   // A/B: consecutive workgroups alternate between neighbours in R's low bits and in its high bits (= the partner's low bits)
-    uint32_t rr = 0;
-    {
+    // Which set a workgroup takes.  Plain: blockIdx (neighbours in the dispatch order touch adjacent 1 KiB runs).  Balancing: a set's
+    // 128 table runs lie 128 MiB apart and its partner's runs somewhere else entirely -- with R's low bits running fastest every
+    // workgroup in flight has partner runs in pages of its own (the partner's page number is the reverse complement of R's LOW
+    // bits), and the kernel ran at 2.9 TB/s against 4.9 TB/s for the plain form: address translation, not DRAM.  So the
+    // bits of R that are neither page bits of its own runs (index bits >= 18: 2 MiB pages of 8-byte entries) nor of the
+    // partner's (index bits <= 2K-19) run fastest: workgroups dispatched together share the pages on both sides.
+    uint32_t set_id = blockIdx.x;
+    if constexpr (BALANCE) {
         constexpr int SB = Q::kSetBits;
-        uint32_t b = blockIdx.x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            rr |= ((b >> (2 * j)) & 1u) << j;
-            rr |= ((b >> (2 * j + 1)) & 1u) << (SB - 1 - j);
+        constexpr int LO = 2 * K - 25 > 0 ? 2 * K - 25 : 0;          // R bit j is index bit 7 + j (j <= 2K-16)
+        constexpr int HI = 10 < SB - 2 ? 10 : SB - 2;
+        constexpr int NN = HI - LO + 1;
+        if constexpr (NN > 0 && LO > 0) {
+            const uint32_t b = blockIdx.x;
+            set_id = ((b & ((1u << NN) - 1u)) << LO) | ((b >> NN) & ((1u << LO) - 1u)) | ((b >> (NN + LO)) << (NN + LO));
         }
-        rr |= ((b >> 8) & ((1u << (SB - 8)) - 1u)) << 4;
     }
-    const uint64_t base = Q::set_base(rr);
-#else
-    const uint64_t base = Q::set_base(blockIdx.x);
-#endif
+    const uint64_t base = Q::set_base(set_id);
     const uint64_t pbase = BALANCE ? Q::partner_base(base) : base;
     if (BALANCE && base > pbase) return;                        // block-uniform
     const bool self = BALANCE && base == pbase;

@@ -1,48 +1,67 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash tools/profile_round.sh r2'): the round's measurement artefacts into
+# Run on the GPU box (gpurun -- 'bash tools/profile_round.sh r3'): the round's measurement artefacts into
 # gpurun_out/<round>/ -- copy what should be judged into profiles/<round>/.
-#   bench_k12_n1.json                  default bench command (cpu_baseline included)
-#   bench_k12_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the same command
-#   pmc_hbm_traffic.json               FETCH_SIZE / WRITE_SIZE passes (separate), per kernel
-#   pmc_lds_quad.json                  SQ LDS / VALU / VMEM counters of the dominant kernels
-#   bench_k15_* / pmc_hbm_traffic_k15  BASELINE config 4
-#   matrix_k12_P64_*                   BASELINE config 5 (multiset prod, euclidean on the matrix cores)
+#   pmc_hbm_traffic.json / _k15        FETCH_SIZE / WRITE_SIZE passes (separate), per kernel; taken FIRST and copied to
+#                                      profiles/<round>/ so that the bench lines of the same call report roofline.traffic
+#   pmc_lds_quad.json / _k15           SQ LDS / VALU / VMEM counters of the counting kernels
+#   bench_k12_n1.json                  the default bench command: headline + extra (config 4, config 5, end to end) + cpu_baseline
+#   bench_k12_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the headline alone (--no-extra: the extras launch
+#                                      kernels of the same names on other sizes and would blur the averages)
+#   bench_k15_*                        BASELINE config 4 as its own command, + kernel stats
+#   matrix_k12_P64_*                   BASELINE config 5 (multiset prod, euclidean) as its own command, + kernel stats
 set -u
-ROUND=${1:-r2}
+ROUND=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$ROUND
-mkdir -p "$OUT"
+mkdir -p "$OUT" "$ROOT/profiles/$ROUND"
 export KPAL_HEAD=$(cat "$ROOT/.head" 2>/dev/null || echo unknown)
 cd /tmp && export TMPDIR=/tmp
-# counter passes first: the bench lines below then report roofline.traffic from THIS build's profile
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_k12" -o f -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_fetch_k12.err"
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_k12" -o w -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_write_k12.err"
-# 3 steps (1 warm-up + 2) of 20 M reads x 151 bytes, one launch of quad_scatter per step
+B="$ROOT/bench.py"
+pmc() {   # name, counters..., then -- bench args
+  local name=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  rocprofv3 --output-format csv --pmc "${ctrs[@]}" -d "$OUT/$name" -o p -- python3 "$B" --no-cpu --no-extra "$@" > /dev/null 2> "$OUT/$name.err"
+}
+# ---- k = 12 counters: 3 steps (1 warm-up + 2) of 20 M reads x 151 bytes, one quad_scatter + one quad_hist launch per step
+K12="--reads 20000000 --steps 2 --warmup 1"
+pmc pmc_fetch_k12 FETCH_SIZE -- $K12
+pmc pmc_write_k12 WRITE_SIZE -- $K12
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_k12" "$OUT/pmc_write_k12" 9060000000 \
-  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --reads 20000000 --k 12 --steps 2 --warmup 1; KB per dispatch averaged over dispatches; gfx950 correction: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)" quad_scatter > "$OUT/pmc_hbm_traffic.json"
-rocprofv3 --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_INSTS_VALU -d "$OUT/pmc_lds" -o l -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_lds.err"
-rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -d "$OUT/pmc_wave" -o v -- python3 "$ROOT/bench.py" --no-cpu --reads 20000000 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_wave.err"
-python3 "$ROOT/tools/pmc_counters.py" "rocprofv3 --pmc (two passes: LDS/VALU/VMEM instruction counters; wave-cycle breakdown) -- python3 bench.py --no-cpu --reads 20000000 --steps 2 --warmup 1 (k=12; 3.02 GB and one quad_scatter + one quad_hist launch per step)" "$OUT/pmc_lds" "$OUT/pmc_wave" > "$OUT/pmc_lds_quad.json"
-mkdir -p "$ROOT/profiles/$ROUND" && cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/$ROUND/pmc_hbm_traffic.json"
-python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_k12_n1.json" 2> "$OUT/bench_k12_n1.err"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_k12" -o k12 -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu > "$OUT/bench_k12_n1_under_rocprof.json" 2> "$OUT/stats_k12.err"
-find "$OUT/stats_k12" -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_k12_kernel_stats.csv" \;
-# BASELINE config 4 (k = 15)
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_k15" -o f -- python3 "$ROOT/bench.py" --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_fetch_k15.err"
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_k15" -o w -- python3 "$ROOT/bench.py" --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_write_k15.err"
-# (40 M reads = 6.04 GB per step: AUTO takes the two-level quad pipeline once the feed is larger than half the 8 GiB table)
+  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --no-extra $K12 (k=12); KB per dispatch averaged over dispatches; gfx950 correction: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM)" quad_scatter > "$OUT/pmc_hbm_traffic.json"
+cp "$OUT/pmc_hbm_traffic.json" "$ROOT/profiles/$ROUND/pmc_hbm_traffic.json"
+pmc pmc_lds_k12 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_INSTS_VALU -- $K12
+pmc pmc_wave_k12 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -- $K12
+python3 "$ROOT/tools/pmc_counters.py" "rocprofv3 --pmc (two passes: LDS/VALU/VMEM instruction counters; wave-cycle breakdown) -- python3 bench.py --no-cpu --no-extra $K12 (k=12; 3.02 GB and one quad_scatter + one quad_hist launch per step)" "$OUT/pmc_lds_k12" "$OUT/pmc_wave_k12" > "$OUT/pmc_lds_quad.json"
+cp "$OUT/pmc_lds_quad.json" "$ROOT/profiles/$ROUND/pmc_lds_quad.json"
+# ---- k = 15 counters (40 M reads = 6.04 GB per step: AUTO takes the two-level quad pipeline once the feed is larger than half the 8 GiB table)
+K15="--reads 40000000 --k 15 --steps 2 --warmup 1"
+pmc pmc_fetch_k15 FETCH_SIZE -- $K15
+pmc pmc_write_k15 WRITE_SIZE -- $K15
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_k15" "$OUT/pmc_write_k15" 18120000000 \
-  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --reads 40000000 --k 15 --steps 2 --warmup 1 (one batch of 6.04 GB per step); gfx950 correction: FETCH_SIZE x2" quad_scatter > "$OUT/pmc_hbm_traffic_k15.json"
+  "rocprofv3 --output-format csv --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around python3 bench.py --no-cpu --no-extra $K15 (one batch of 6.04 GB per step); gfx950 correction: FETCH_SIZE x2" quad_scatter > "$OUT/pmc_hbm_traffic_k15.json"
 cp "$OUT/pmc_hbm_traffic_k15.json" "$ROOT/profiles/$ROUND/pmc_hbm_traffic_k15.json"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_k15" -o k15 -- python3 "$ROOT/bench.py" --k 15 --steps 3 --warmup 1 --no-cpu > "$OUT/bench_k15_n1_under_rocprof.json" 2> "$OUT/stats_k15.err"
+pmc pmc_lds_k15 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_INSTS_VALU -- $K15
+pmc pmc_wave_k15 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM -- $K15
+python3 "$ROOT/tools/pmc_counters.py" "rocprofv3 --pmc (two passes) -- python3 bench.py --no-cpu --no-extra $K15 (k=15, 6.04 GB per step)" "$OUT/pmc_lds_k15" "$OUT/pmc_wave_k15" > "$OUT/pmc_lds_quad_k15.json"
+cp "$OUT/pmc_lds_quad_k15.json" "$ROOT/profiles/$ROUND/pmc_lds_quad_k15.json"
+# ---- the bench lines (they read the counter profiles copied above)
+python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_k12_n1.json" 2> "$OUT/bench_k12_n1.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_k12" -o k12 -- python3 "$B" --steps 10 --warmup 2 --no-cpu --no-extra > "$OUT/bench_k12_n1_under_rocprof.json" 2> "$OUT/stats_k12.err"
+find "$OUT/stats_k12" -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_k12_kernel_stats.csv" \;
+python3 "$B" --k 15 --steps 5 --warmup 1 --no-cpu --no-extra > "$OUT/bench_k15_n1.json" 2> "$OUT/bench_k15_n1.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_k15" -o k15 -- python3 "$B" --k 15 --steps 3 --warmup 1 --no-cpu --no-extra > "$OUT/bench_k15_n1_under_rocprof.json" 2> "$OUT/stats_k15.err"
 find "$OUT/stats_k15" -name '*kernel_stats.csv' -exec cp {} "$OUT/bench_k15_kernel_stats.csv" \;
-# BASELINE config 5 (64 profiles, k = 12)
-python3 "$ROOT/bench.py" --workload matrix --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_prod_bench.json" 2> "$OUT/matrix_prod.err"
-python3 "$ROOT/bench.py" --workload matrix --metric euclidean --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_euclidean_bench.json" 2> "$OUT/matrix_eucl.err"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix" -o m -- python3 "$ROOT/bench.py" --workload matrix --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_prod_under_rocprof.json" 2> "$OUT/stats_matrix.err"
+for k in 9 11 13 14; do python3 "$B" --k $k --steps 5 --warmup 1 --no-cpu --no-extra > "$OUT/bench_k${k}_n1.json" 2> "$OUT/bench_k${k}_n1.err"; done
+# ---- BASELINE config 5 (64 profiles, k = 12)
+python3 "$B" --workload matrix --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_prod_bench.json" 2> "$OUT/matrix_prod.err"
+python3 "$B" --workload matrix --metric euclidean --steps 5 --warmup 1 > "$OUT/matrix_k12_P64_euclidean_bench.json" 2> "$OUT/matrix_eucl.err"
+python3 "$B" --workload matrix --metric sum --steps 3 --warmup 1 > "$OUT/matrix_k12_P64_sum_bench.json" 2> "$OUT/matrix_sum.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix" -o m -- python3 "$B" --workload matrix --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_prod_under_rocprof.json" 2> "$OUT/stats_matrix.err"
 find "$OUT/stats_matrix" -name '*kernel_stats.csv' -exec cp {} "$OUT/matrix_k12_P64_prod_kernel_stats.csv" \;
-rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix_e" -o m -- python3 "$ROOT/bench.py" --workload matrix --metric euclidean --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_euclidean_under_rocprof.json" 2> "$OUT/stats_matrix_e.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix_e" -o m -- python3 "$B" --workload matrix --metric euclidean --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_euclidean_under_rocprof.json" 2> "$OUT/stats_matrix_e.err"
 find "$OUT/stats_matrix_e" -name '*kernel_stats.csv' -exec cp {} "$OUT/matrix_k12_P64_euclidean_kernel_stats.csv" \;
+# ---- skewed inputs
+cd "$ROOT"
+python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
 # keep only the small summaries (the merge back is capped at 64 MiB)
-find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -size +20M -delete
-ls -la "$OUT"; for f in "$OUT"/*.json; do echo "== $f"; head -c 1500 "$f"; echo; done
+find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -delete
+ls -la "$OUT"; for f in "$OUT"/bench_k1[25]_n1.json "$OUT"/matrix*_bench.json; do echo "== $f"; head -c 1200 "$f"; echo; done
