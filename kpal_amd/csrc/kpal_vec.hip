@@ -328,6 +328,7 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
             for (int sj = 0; sj <= si; ++sj) supers.push_back(make_int2(si, sj));
         const uint32_t nsuper = (uint32_t)supers.size();
         gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / kSuperBins, std::max<uint64_t>(1, (uint64_t)ctx->num_cu * 8 / nsuper)));
+        gx = std::max(8u, gx / 8u * 8u);   // (matrix_rdiff_kernel deals bin-groups to the 8 XCDs; n / 64 >= 64 for k >= 6)
         CHK(ensure(ctx, ctx->scratch[3], (size_t)nsuper * sizeof(int2) + 16));
         HIPCHK(hipMemcpyAsync(ctx->scratch[3].p, supers.data(), (size_t)nsuper * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
         CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
@@ -341,7 +342,7 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
             uint32_t *big = (uint32_t *)((int2 *)ctx->scratch[3].p + nsuper);
             HIPCHK(hipMemsetAsync(big, 0, sizeof(uint32_t), ctx->stream));
             HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));   // (.s / .m of a slot come from different threads)
-            LAUNCH(ctx, "matrix_rdiff", matrix_rdiff_kernel, dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp, big);
+            LAUNCH(ctx, "matrix_rdiff", matrix_rdiff_kernel, dim3(gx * nsuper), dim3(256), prof, P, n, dt, nsuper, pp, big);   // (gx: a multiple of 8)
             uint32_t saw_big = 0;
             HIPCHK(hipMemcpyAsync(&saw_big, big, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));   // (also: `supers` was read by the asynchronous copy above)

@@ -848,6 +848,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // low bits of the hipart XOR-ed into bank bits that the staging read holds fixed (8 consecutive bins stay 8 consecutive,
     // aligned words).  The adds hit random bins either way.
     auto stage_swizzle = [](int i, uint32_t local) -> uint32_t {
+#if defined(KPAL_AB_NO_STAGE_SWIZZLE)   // A/B timing
+        return local;
+#endif
         if constexpr (C::kTwoLevel) {
             if (i == 0) return local ^ (((local >> 7) & 7u) << 3);                                   // hipart[2:0] -> bits 5:3 (t's low bits)
             if (i == 1) return local ^ (((local >> 9) & 1u) << 5) ^ (((local >> 10) & 3u) << 3);   // hipart[0] -> bit 5, hipart[2:1] -> bits 4:3
@@ -964,10 +967,16 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             for (int j = threadIdx.x; j < 4 * BINS / 8; j += blockDim.x) {
                 const int i = j >> 10;                                     // plane (form)
                 const uint32_t o = ((uint32_t)j & 1023u) * 8u;           // first of eight words of the plane
+#if defined(KPAL_AB_STAGE_LINEAR)   // A/B timing (wrong counts): the planes stored in bin order, as round 2 did
+                const uint32_t local = o;
+#else
                 const uint32_t local = Q::bin_of_word(i, o);              // ... which are eight consecutive bins
-                const uint32_t phys = stage_swizzle(i, local);            // (aligned blocks of eight stay together)
-                const uint4 a = *reinterpret_cast<const uint4 *>(&hist[i * BINS + phys]);
-                const uint4 b = *reinterpret_cast<const uint4 *>(&hist[i * BINS + phys + 4]);
+#endif
+                const uint32_t phys = stage_swizzle(i, local) & ~7u;     // (aligned blocks of eight stay together; the mask only tells the
+                                                                          // compiler so: without it the two reads become four ds_read2_b32)
+                const uint4 *src = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(&hist[i * BINS + phys], 16));
+                const uint4 a = src[0];
+                const uint4 b = src[1];
                 uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
 #pragma unroll

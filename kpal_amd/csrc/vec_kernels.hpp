@@ -768,15 +768,21 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
 // multiply-adds per staged value -- the loader would cost 60 % of the arithmetic otherwise); larger counts are computed.
 constexpr int kRdiffTable = 2048;
 __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
-                                                           const int2 *__restrict__ supers, Partial *__restrict__ partials,
-                                                           uint32_t *__restrict__ big)
+                                                           const int2 *__restrict__ supers, uint32_t nsuper,
+                                                           Partial *__restrict__ partials, uint32_t *__restrict__ big)
 {
     constexpr int TILE = 4;
     __shared__ double rstage[2][32][kSuperRow];
     __shared__ unsigned long long zmask[2][32];
     __shared__ double rtable[kRdiffTable];
     for (int i = threadIdx.x; i < kRdiffTable; i += 256) rtable[i] = rcp_counts((double)i + 1.0);
-    const int si = supers[blockIdx.y].x, sj = supers[blockIdx.y].y;
+    // Every profile is staged by several super-tiles (64 profiles: 10 super-tiles x 32 rows = 5 x the profiles' bytes, 43 GB at
+    // k = 12 -- more than the arithmetic takes).  Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2:
+    // the 1-D grid is cut so that the `nsuper` workgroups that stage the SAME bins are neighbours on ONE XCD -- linear id
+    // L = (c * nsuper + s) * 8 + x  ->  super-tile s, bin-group c * 8 + x -- and the second to tenth reader of a line hits that L2.
+    const uint32_t lin = blockIdx.x, xcd = lin & 7u, sidx = (lin >> 3) % nsuper, cgrp = (lin >> 3) / nsuper;
+    const uint32_t group = cgrp * 8u + xcd, ngroups = gridDim.x / nsuper;   // (the host launches nsuper * a multiple of 8 workgroups)
+    const int si = supers[sidx].x, sj = supers[sidx].y;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int ti = si * 4 + (g >> 2), tj = sj * 4 + (g & 3);
     const int side = (P + TILE - 1) / TILE;
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     };
     const uint64_t chunks = n / kSuperBins;
     int64_t next[8];
-    uint64_t c = blockIdx.x;
+    uint64_t c = group;
     uint64_t stages = 0;
     if (c < chunks) {
 #pragma unroll
@@ -822,11 +828,11 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     }
     __syncthreads();
     int cur = 0;
-    for (; c < chunks; c += gridDim.x, ++stages) {
-        const bool more = c + gridDim.x < chunks;      // block-uniform
+    for (; c < chunks; c += ngroups, ++stages) {
+        const bool more = c + ngroups < chunks;        // block-uniform
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) next[q] = src[q][(c + gridDim.x) * kSuperBins];
+            for (int q = 0; q < 8; ++q) next[q] = src[q][(c + ngroups) * kSuperBins];
         }
         both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
         if (mine) {
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
             for (int d = 8; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 16);
             if (mine && l == 0) {
                 const uint64_t t = (uint64_t)ti * (ti + 1) / 2 + tj;
-                partials[(t * TILE * TILE + a * TILE + b) * gridDim.x + blockIdx.x].s = ps;
+                partials[(t * TILE * TILE + a * TILE + b) * ngroups + group].s = ps;
             }
         }
     // term counts: thread (i, j) of the super-tile writes .m = bins seen - bins where both are zero
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         const int pti = i / TILE, ptj = j / TILE;
         if (pti < side && ptj <= pti) {
             const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
-            partials[(t * TILE * TILE + (i % TILE) * TILE + (j % TILE)) * gridDim.x + blockIdx.x].m = stages * kSuperBins - both_zero;
+            partials[(t * TILE * TILE + (i % TILE) * TILE + (j % TILE)) * ngroups + group].m = stages * kSuperBins - both_zero;
         }
     }
 }
