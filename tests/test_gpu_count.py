@@ -574,6 +574,8 @@ def test_count_balance_fused_with_the_finalisation():
                 c2.count_balance()
                 assert np.array_equal(c2.count_finish(), want), k
                 del want
+            if k != 13:
+                continue
             # two feeds + entries beyond 32 bits that are already in the table when the last finalisation runs
             a, b = buf[:buf.size // 3], buf[buf.size // 3:]
             c2.count_begin(k, 'partition2_quads')

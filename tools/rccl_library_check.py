@@ -15,7 +15,7 @@ from kpal_amd import _native
 
 ctx = _native.Context(_native.default_device())
 ctx.comm_init(0, 1, _native.comm_unique_id())
-for k in (9, 12, 13):
+for k in (12, 13):
     for pipelined in (False, True):
         wants, gots = [], []
         for step in range(3):
