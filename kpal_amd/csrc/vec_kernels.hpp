@@ -764,15 +764,17 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
 // of at least r_x r_y (x != y: |x - y| >= 1): relative 2^-52 (x + y + 2) -- below 4.7e-10 while both counts are below 2^20,
 // and every term being non-negative that bounds the relative error of the sum as well; the contract for fp64 results is
 // 1e-9 (typical: 1e-15).  A count >= 2^20 (or negative) anywhere raises *big and the caller reruns the pair-of-counts kernel.
-//   Reciprocals of counts below 2048 come from a table in LDS (one ds_read_b64 instead of v_rcp_f64 + four fused
+//   Reciprocals of counts below 512 come from a table in LDS (one ds_read_b64 instead of v_rcp_f64 + four fused
 // multiply-adds per staged value -- the loader would cost 60 % of the arithmetic otherwise); larger counts are computed.
-constexpr int kRdiffTable = 2048;
+constexpr int kRdiffTable = 512;    // reciprocals 1 / (c + 1) of counts c < 512 (4 KiB: four workgroups per CU)
+constexpr int kRdiffRow = 64;       // staged row: 64 bins, unpadded -- with 16-byte reads a 16-lane group covers all 64 banks, and
+                                    // rows a multiple of 8 doubles apart keep the lanes of two groups that share a read pass apart
 __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
                                                            const int2 *__restrict__ supers, uint32_t nsuper,
                                                            Partial *__restrict__ partials, uint32_t *__restrict__ big)
 {
     constexpr int TILE = 4;
-    __shared__ double rstage[2][32][kSuperRow];
+    __shared__ __attribute__((aligned(16))) double rstage[2][32][kRdiffRow];
     __shared__ unsigned long long zmask[2][32];
     __shared__ double rtable[kRdiffTable];
     for (int i = threadIdx.x; i < kRdiffTable; i += 256) rtable[i] = rcp_counts((double)i + 1.0);
@@ -836,18 +838,23 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         }
         both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
         if (mine) {
+            // lane l takes the bin pairs (2l, 2l+1) and (32 + 2l, 32 + 2l + 1): 16-byte LDS reads (ds_read_b128 moves 256 B/clk per
+            // CU; the ds_read2_b64 the 8-byte form compiled to, half of that -- and the LDS, not the fp64 pipe, set the pace)
 #pragma unroll
-            for (int u = 0; u < kSuperBins / 16; ++u) {
-                double rx[TILE], ry[TILE];
+            for (int u = 0; u < kSuperBins / 32; ++u) {
+                double2 rx[TILE], ry[TILE];
 #pragma unroll
                 for (int a = 0; a < TILE; ++a) {
-                    rx[a] = rstage[cur][4 * (g >> 2) + a][16 * u + l];
-                    ry[a] = rstage[cur][16 + 4 * (g & 3) + a][16 * u + l];
+                    rx[a] = *reinterpret_cast<const double2 *>(&rstage[cur][4 * (g >> 2) + a][32 * u + 2 * l]);
+                    ry[a] = *reinterpret_cast<const double2 *>(&rstage[cur][16 + 4 * (g & 3) + a][32 * u + 2 * l]);
                 }
 #pragma unroll
                 for (int a = 0; a < TILE; ++a)
 #pragma unroll
-                    for (int b = 0; b < TILE; ++b) s[a][b] += fabs(rx[a] - ry[b]);
+                    for (int b = 0; b < TILE; ++b) {
+                        s[a][b] += fabs(rx[a].x - ry[b].x);
+                        s[a][b] += fabs(rx[a].y - ry[b].y);
+                    }
             }
         }
         if (more) {
