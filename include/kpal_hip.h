@@ -134,6 +134,13 @@ int kpal_comm_destroy(kpal_ctx *ctx);
 int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance);
 int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance);
 int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins);
+/* kdistlib.distance_matrix (kdistlib.py:164-186) over several GPUs, sharded by BIN RANGE: every rank holds the same bins
+ * [first, first + bin_count) of all P profiles (dev_slices: int64[P][bin_count] on the device, profile-major; ranges of different
+ * ranks tile 0 .. 4^k; a multiple of 64 bins lets the LDS-staged kernels run), computes every pair's partial sum / term count / dot
+ * product over its bins, and ONE all-reduce (two calls: fp64 sums, 64-bit counts -- 32 KB at P = 64) gives every rank the finished lower
+ * triangle.  metric: prod / sum / euclidean; balancing needs whole profiles (kpal_balance_device before slicing). */
+int kpal_comm_distance_matrix_device(kpal_ctx *ctx, int P, uint64_t bin_count, const int64_t *dev_slices, int metric,
+                                     double *out_lower /* P(P-1)/2, kdistlib.py:179-186 order */);
 int kpal_comm_max_f64(kpal_ctx *ctx, double *inout);   /* max of a host scalar over the ranks (timing: the slowest rank) */
 
 /* ---- vector operations on 4^k int64 count vectors ---- */

@@ -79,6 +79,7 @@ SIGNATURES = {
     'kpal_comm_reduce_table_async': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     'kpal_comm_merged_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_comm_max_f64': (ctypes.c_int, [_vp, _f64p]),
+    'kpal_comm_distance_matrix_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64, _vp, ctypes.c_int, _f64p]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_int, ctypes.c_int, _vp]),
     'kpal_balance': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
@@ -378,6 +379,14 @@ class Context(object):
         n = ctypes.c_uint64(0)
         _check(self._L.kpal_comm_merged_table(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def comm_distance_matrix_device(self, P, bin_count, dev_slices, metric):
+        """distance_matrix values from bin-range shards: this rank's int64[P][bin_count] slices on the device -> the full lower
+        triangle on every rank (one all-reduce of the per-pair partial sums and counts)."""
+        out = np.zeros(P * (P - 1) // 2, dtype=np.float64)
+        _check(self._L.kpal_comm_distance_matrix_device(self._h, int(P), int(bin_count), _vp(dev_slices), int(metric),
+                                                        out.ctypes.data_as(_f64p)))
+        return out
 
     def comm_max(self, value):
         v = ctypes.c_double(float(value))

@@ -245,3 +245,5 @@ double quad_expected_backlog(const std::vector<double> &mu, int slots);   // kpa
 constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
 int quad2_finalize(kpal_ctx *ctx, bool balance);                          // kpal_quads2.hip: no-op unless a finalisation is pending
 int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out);   // kpal_vec.hip
+int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce);   // kpal_vec.hip
+int comm_allreduce_partials(kpal_ctx *ctx, void *dev_partials, size_t count);   // kpal_multi.hip: {double sum, uint64 count} pairs added over the ranks, in place

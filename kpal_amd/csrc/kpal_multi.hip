@@ -196,6 +196,57 @@ KPAL_API int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n
     return KPAL_OK;
 }
 
+// ---- distance matrix over bin-range shards --------------------------------------------------------------------
+// Partial of vec_kernels.hpp restated (that header's kernels belong to kpal_vec.hip): a double sum and a 64-bit count / wrapping dot
+struct PartialPod {
+    double s;
+    unsigned long long m;
+};
+
+__global__ void partials_split_kernel(const PartialPod *__restrict__ p, size_t n, double *__restrict__ s, unsigned long long *__restrict__ m)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        s[i] = p[i].s;
+        m[i] = p[i].m;
+    }
+}
+
+__global__ void partials_join_kernel(PartialPod *__restrict__ p, size_t n, const double *__restrict__ s, const unsigned long long *__restrict__ m)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = PartialPod{s[i], m[i]};
+}
+
+int comm_allreduce_partials(kpal_ctx *ctx, void *dev_partials, size_t count)
+{
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (count == 0) return KPAL_OK;
+    CHK(ensure(ctx, ctx->scratch[1], count * 16));
+    double *s = (double *)ctx->scratch[1].p;
+    unsigned long long *m = (unsigned long long *)(s + count);
+    const unsigned grid = (unsigned)std::min<size_t>((count + 255) / 256, 1024);
+    LAUNCH(ctx, "partials_split", partials_split_kernel, dim3(grid), dim3(256), (const PartialPod *)dev_partials, count, s, m);
+    {
+        ProfScope ps_(ctx, "rccl_allreduce");
+        NCCLCHK(g_rccl.AllReduce(s, s, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+        NCCLCHK(g_rccl.AllReduce(m, m, count, ncclUint64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+    }
+    LAUNCH(ctx, "partials_join", partials_join_kernel, dim3(grid), dim3(256), (PartialPod *)dev_partials, count, (const double *)s,
+           (const unsigned long long *)m);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_distance_matrix_device(kpal_ctx *ctx, int P, uint64_t bin_count, const int64_t *dev_slices, int metric, double *out_lower)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (P < 1) return set_err(KPAL_E_INVALID, "P must be >= 1");
+    if (metric < 0 || metric > 2) return set_err(KPAL_E_INVALID, "unknown metric %d", metric);
+    if (P == 1) return KPAL_OK;
+    if (!dev_slices || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (bin_count == 0 || ((uintptr_t)dev_slices & 15)) return set_err(KPAL_E_INVALID, "every rank needs a non-empty, 16-byte aligned slice");
+    return distance_matrix_core(ctx, P, bin_count, dev_slices, metric, out_lower, true);
+}
+
 // A scalar agreed on by all ranks (bench: the slowest rank's time; tests): max over the ranks, through the device.
 KPAL_API int kpal_comm_max_f64(kpal_ctx *ctx, double *inout)
 {

@@ -92,11 +92,12 @@ KPAL_API int kpal_split(kpal_ctx *ctx, int k, const int64_t *host_counts, int64_
 }
 
 // Reduce `nq` groups of `nblocks` partials and fetch them.
-static int finish_partials(kpal_ctx *ctx, uint32_t nq, uint32_t nblocks, std::vector<Partial> &out)
+static int finish_partials(kpal_ctx *ctx, uint32_t nq, uint32_t nblocks, std::vector<Partial> &out, bool allreduce = false)
 {
     CHK(ensure(ctx, ctx->result, (size_t)nq * sizeof(Partial)));
     LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(nq), dim3(256), (const Partial *)ctx->partials.p,
            nblocks, (Partial *)ctx->result.p);
+    if (allreduce) CHK(comm_allreduce_partials(ctx, ctx->result.p, nq));   // bin-range shards: the sums and counts of all ranks
     out.resize(nq);
     HIPCHK(hipMemcpyAsync(out.data(), ctx->result.p, (size_t)nq * sizeof(Partial), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -220,7 +221,7 @@ KPAL_API int kpal_pair_distance_f64(kpal_ctx *ctx, size_t n, const double *host_
 
 // Euclidean distances of all pairs from the fp64 Gram matrix (gram_kernels.hpp).  *exact = false (and
 // out_lower untouched) when some |x|^2 >= 2^53: the caller then takes the wrapping-int64 path.
-static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, double *out_lower, bool *exact)
+static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, double *out_lower, bool *exact, bool allreduce)
 {
     const int nb = (P + 63) / 64;
     std::vector<int2> diag, off;
@@ -250,6 +251,7 @@ static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof,
         LAUNCH(ctx, "reduce_partials", reduce_partials_kernel, dim3(no * 4096), dim3(256), (const Partial *)(pp + part_d), gx_o,
                res_d + (size_t)nd * 4096);
     }
+    if (allreduce) CHK(comm_allreduce_partials(ctx, res_d, (size_t)(nd + no) * 4096));   // (sums of exact integers: exact in any order below 2^53)
     std::vector<Partial> res((size_t)(nd + no) * 4096);
     HIPCHK(hipMemcpyAsync(res.data(), res_d, res.size() * sizeof(Partial), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // also: `all` was read by the asynchronous copy above
@@ -284,6 +286,8 @@ static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof,
     return KPAL_OK;
 }
 
+int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce);
+
 KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles, int metric,
                                          int do_balance, double *out_lower)
 {
@@ -302,12 +306,20 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
             CHK(launch_balance(ctx, k, dev_profiles + (uint64_t)p * n, (int64_t *)ctx->scratch[2].p + (uint64_t)p * n));
         prof = (const int64_t *)ctx->scratch[2].p;
     }
+    return distance_matrix_core(ctx, P, n, prof, metric, out_lower, false);
+}
+
+// The lower triangle over n bins per profile (profile p at prof + p * n).  allreduce: this rank holds a bin RANGE of every
+// profile -- the per-pair sums / term counts / dot products of all ranks are added (one all-reduce) before they are finished.
+int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce)
+{
+    const bool tiled = n >= 4096 && n % 64 == 0;   // (whole profiles: k >= 6) the LDS-staged kernels take 64 bins at a time
     // euclidean with enough profiles and bins: fp64 Gram matrix on the matrix cores (gram_kernels.hpp), exact
     // while every |x|^2 < 2^53 (checked on the result); KPAL_MATRIX_MFMA=0 forces the int64 kernels
     static const bool allow_mfma = [] { const char *e = getenv("KPAL_MATRIX_MFMA"); return !e || atoi(e) != 0; }();
-    if (metric == KPAL_EUCLIDEAN && allow_mfma && P > 8 && k >= 6) {
+    if (metric == KPAL_EUCLIDEAN && allow_mfma && P > 8 && tiled) {
         bool exact = false;
-        CHK(gram_euclidean(ctx, P, n, prof, out_lower, &exact));
+        CHK(gram_euclidean(ctx, P, n, prof, out_lower, &exact, allreduce));
         if (exact) return KPAL_OK;
     }
     constexpr int TILE = 4;
@@ -319,7 +331,7 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
     // LDS-staged 16 x 16 super-tiles when there are enough profiles and bins to share; KPAL_MATRIX_SUPER=0 forces
     // the register-tile kernel (A/B timing, cross-check)
     static const bool allow_super = [] { const char *e = getenv("KPAL_MATRIX_SUPER"); return !e || atoi(e) != 0; }();
-    const bool super = allow_super && P > 8 && k >= 6;
+    const bool super = allow_super && P > 8 && tiled;
     unsigned gx;
     if (super) {
         const int sside = (P + 15) / 16;
@@ -365,7 +377,7 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
         else LAUNCH(ctx, "matrix_tile", (matrix_tile_kernel<2, TILE>), dim3(gx, ntiles), dim3(256), prof, P, n, dt, pp);
     }
     std::vector<Partial> res;
-    CHK(finish_partials(ctx, ntiles * TILE * TILE, gx, res));
+    CHK(finish_partials(ctx, ntiles * TILE * TILE, gx, res, allreduce));
     for (int i = 1; i < P; ++i)
         for (int j = 0; j < i; ++j) {
             const int ti = i / TILE, tj = j / TILE;

@@ -35,6 +35,27 @@ for k in (12, 13):
             gots.append(got)
         for g, w in zip(gots, wants):
             assert np.array_equal(g, w), (k, pipelined)
+# distance matrix from bin-range shards (world size 1: the one shard is the whole range; the split / all-reduce / join of the
+# per-pair partials runs all the same): LDS-staged kernels (64-bin multiples) and the register-tile kernel (a ragged range)
+rs = np.random.RandomState(3)
+for k, P, bins in ((8, 12, 4 ** 8), (7, 9, 4 ** 7 - 100)):
+    prof = rs.poisson(3.0, (P, 4 ** k)).astype(np.int64)
+    prof[1, ::5] = 0
+    sl = np.ascontiguousarray(prof[:, :bins])
+    d = ctx.alloc(sl.nbytes)
+    ctx.h2d(d, sl)
+    for metric, name in ((0, 'prod'), (1, 'sum'), (2, 'euclidean')):
+        got = ctx.comm_distance_matrix_device(P, bins, d, metric)
+        if bins == 4 ** k:
+            want = oracle.distance_matrix_values(prof, k, False, name)
+        else:       # a ragged range is not a profile: pair by pair through the oracle's metric functions
+            want = np.array([oracle.euclidean(sl[i], sl[j]) if metric == 2 else oracle.multiset(sl[i], sl[j], name)
+                             for i in range(1, P) for j in range(i)])
+        if metric == 2:
+            assert np.array_equal(got, want), (k, name)
+        else:
+            assert np.max(np.abs(got - want) / np.abs(want)) <= 1e-9, (k, name)
+    ctx.free(d)
 assert ctx.comm_max(3.5) == 3.5
 ctx.comm_destroy()
 try:
