@@ -530,13 +530,17 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
+            uint64_t window;
+            uint32_t mask;
+            encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask, edge);
+            // the previous round's records leave AFTER this step's chunk has been consumed: the compiler guards the first use of
+            // raw[] in a tile with s_waitcnt vmcnt(0) (the loads were issued a tile ago, under conditions it cannot count) --
+            // with a record store issued just before, every wave of the workgroup waited out that store's round trip at the
+            // top of every tile, right after the barrier, all at the same time
             if (have_rec) {
 #pragma unroll
                 for (int i = st; i < FI; i += STEPS) store_rec(i);
             }
-            uint64_t window;
-            uint32_t mask;
-            encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask, edge);
             {
                 uint32_t l16 = lane16;
                 asm volatile("" : "+v"(l16));
@@ -728,12 +732,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         if (more) seek(j + 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
-            if (have_rec) {
-#pragma unroll
-                for (int i = st; i < FI; i += STEPS) store_rec(i);
-            }
             const uint4 v = raw[st];
-            if (more) raw[st] = fetch_next();
             const uint32_t it[4] = {v.x, v.y, v.z, v.w};
             uint32_t row[4], item[4];
 #pragma unroll
@@ -742,6 +741,12 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
                 row[q] = ((it[q] >> 17) & 511u) ^ C::smask(t);
                 item[q] = ((it[q] >> 26) << 17) | (it[q] & 0x1FFFFu);   // the fine bucket leaves the item
             }
+            asm volatile("" ::"v"(row[0]), "v"(item[0]));   // (the step's records are in use before the stores below are issued: see quad_scatter_kernel)
+            if (have_rec) {
+#pragma unroll
+                for (int i = st; i < FI; i += STEPS) store_rec(i);
+            }
+            if (more) raw[st] = fetch_next();
             quad_place<K, false, 2>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
         }
         have_rec = false;
@@ -927,10 +932,19 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                                ? reinterpret_cast<const uint4 *>(pool + ((uint64_t)((row_linear >> 1) * G + g) * rounds_cap) * (2 * S) + (row_linear & 1u) * S)
                                : reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
-        // four 16-byte loads per lane in flight; the next four are requested before these are counted
-        auto fetch = [&](uint32_t at) -> uint4 {   // (a select between src[at] and a zero constant becomes a flat load of a selected address)
-            uint4 r = make_uint4(0u, 0u, 0u, 0u);
-            if (at < nvec) r = src[C::kPairRows ? ((at >> 2) * 8u + (at & 3u)) : at];   // (pairs: the row's half of every 128-byte line)
+        if (nvec == 0u) continue;                  // wave-uniform: this scatter workgroup wrote nothing
+        // four 16-byte loads per lane in flight; the next four are requested before these are counted.  The loads are
+        // UNCONDITIONAL (index clamped, value zeroed afterwards): predicated ones sit in basic blocks of their own, the
+        // compiler then waits with vmcnt(0) before the first use -- for the four just requested as well, so every
+        // iteration paid a full memory latency and the LDS idled 43 % of the time.
+        auto fetch = [&](uint32_t at) -> uint4 {
+            const uint32_t a = min(at, nvec - 1u);
+            uint4 r = src[C::kPairRows ? ((a >> 2) * 8u + (a & 3u)) : a];   // (pairs: the row's half of every 128-byte line)
+            const uint32_t keep = at < nvec ? 0xFFFFFFFFu : 0u;
+            r.x &= keep;
+            r.y &= keep;
+            r.z &= keep;
+            r.w &= keep;
             return r;
         };
         uint32_t v = part * 256u + lane;
