@@ -20,7 +20,12 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     ctx->k = k;
     ctx->bins = 1ULL << (2 * k);
     CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
-    HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+    // k >= 13: the zeroing of the table (8.6 GB at k = 15) is deferred -- a first piece on the two-level quad pipeline writes the whole
+    // table in its finalisation and never needs it (kpal_quads2.hip, FRESH); whatever else touches the table first zeroes it (table_ready)
+    static const bool allow_fresh = [] { const char *e = getenv("KPAL_FRESH"); return !e || atoi(e) != 0; }();
+    ctx->table_zero_pending = allow_fresh && k >= 13 && (ctx->strategy == KPAL_STRATEGY_AUTO || ctx->strategy == KPAL_STRATEGY_PARTITION2_QUADS);
+    ctx->finalize_fresh = false;
+    if (!ctx->table_zero_pending) HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
     if (ctx->chunk_error_word) HIPCHK(hipMemsetAsync(ctx->chunk_error_word, 0, sizeof(uint32_t), ctx->stream));
     if (ctx->quad_error_word) HIPCHK(hipMemsetAsync(ctx->quad_error_word, 0, sizeof(uint32_t), ctx->stream));
     ctx->chunk_error_armed = false;
@@ -412,8 +417,10 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     piece &= ~(size_t)15;
     if (piece == 0) piece = 16;
     for (size_t off = 0; off < n; off += piece) {
-        CHK(quad2_finalize(ctx, false));   // the staged forms of the previous piece, before their buffer is reused
         const size_t len = std::min(piece, n - off);
+        // FRESH: the first piece of a count, a whole device feed on the two-level quad pipeline, leaves the table unzeroed
+        const bool fresh = ctx->table_zero_pending && ctx->fresh_feed && strat == KPAL_STRATEGY_PARTITION2_QUADS && off == 0 && len == n && halo == 0;
+        if (!fresh) CHK(table_ready(ctx));   // zeros materialised; the staged forms of the previous piece added before their buffer is reused
         const size_t h = std::min(km1, halo + off);
         const Span s = make_span(addr + off, len, h);
         if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS) {
@@ -425,7 +432,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
-            const int rc = launch_partition2_quads(ctx, s);
+            const int rc = launch_partition2_quads(ctx, s, fresh);
+            if (rc == kQuadsUseChunked || rc == kSplitBatch) CHK(table_ready(ctx));   // (nothing was launched: the other paths need the zeros)
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the round-1 two-level pipeline
                 ctx->strategy = KPAL_STRATEGY_PARTITION2;
                 const int r2 = count_device_range(ctx, addr + off, len, halo + off);
@@ -474,7 +482,10 @@ KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t n
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_device before kpal_count_begin");
     if (nbytes == 0) return KPAL_OK;
     if (!dev_buf) return set_err(KPAL_E_INVALID, "dev_buf is NULL");
-    return count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
+    ctx->fresh_feed = true;   // (the caller keeps dev_buf alive until the stream has drained: a FRESH piece may be counted again)
+    const int rc = count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
+    ctx->fresh_feed = false;
+    return rc;
 }
 
 // Host copy into a pinned staging buffer on several cores: one core's memcpy (~10 GB/s) is what limits
@@ -689,7 +700,7 @@ KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_finish before kpal_count_begin");
-    CHK(quad2_finalize(ctx, false));
+    CHK(table_ready(ctx));
     uint32_t pool_error = 0, quad_error = 0;
     if (ctx->chunk_error_armed)
         HIPCHK(hipMemcpyAsync(&pool_error, ctx->chunk_error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -716,6 +727,7 @@ KPAL_API int kpal_count_balance(kpal_ctx *ctx)
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_balance before kpal_count_begin");
     // two-level quad pipeline: the pending finalisation of the table balances it in the same pass
     if (ctx->finalize_pending) return quad2_finalize(ctx, true);
+    CHK(table_ready(ctx));
     return launch_balance(ctx, ctx->k, (const int64_t *)ctx->table.p, (int64_t *)ctx->table.p);
 }
 
@@ -733,7 +745,7 @@ KPAL_API int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
     if (!ctx->counting) return set_err(KPAL_E_STATE, "no count table (call kpal_count_begin)");
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(quad2_finalize(ctx, false));   // the caller is about to use the table
+    CHK(table_ready(ctx));   // the caller is about to use the table
     if (dev_table) *dev_table = ctx->table.p;
     if (n_bins) *n_bins = ctx->bins;
     return KPAL_OK;

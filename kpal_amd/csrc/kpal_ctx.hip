@@ -114,6 +114,10 @@ static int ctx_init(kpal_ctx *ctx, int device)
     if (const char *e = getenv("KPAL_QUAD_STEPS")) ctx->quad_steps_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_STEPS2")) ctx->quad_steps2_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_VERBOSE")) ctx->quad_verbose = atoi(e) != 0;
+    if (const char *e = getenv("KPAL_DIRECT_SEG")) {   // tests: tiny TableSink segments force the overflow fallback of the FRESH mode
+        const long v = atol(e);
+        if (v >= 1 && v <= (1 << 20)) ctx->direct_seg = (uint32_t)v;
+    }
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1024) ctx->split_above = v;
@@ -155,7 +159,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)kpal_comm_destroy(ctx);
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->direct_list, &ctx->direct_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
@@ -178,7 +182,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
 KPAL_API int kpal_sync(kpal_ctx *ctx)
 {
     CTX_ENTER(ctx);
-    CHK(quad2_finalize(ctx, false));   // (a pending finalisation of the count table belongs to "everything queued so far")
+    if (ctx->counting) CHK(table_ready(ctx));   // (a pending finalisation of the count table belongs to "everything queued so far")
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->comm_stream) HIPCHK(hipStreamSynchronize(ctx->comm_stream));   // ... and so does a pipelined reduce
     return KPAL_OK;
@@ -225,7 +229,7 @@ KPAL_API int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, 
 {
     CTX_ENTER(ctx);
     if (nbytes == 0) return KPAL_OK;
-    CHK(quad2_finalize(ctx, false));   // (the source may be the count table)
+    if (ctx->counting) CHK(table_ready(ctx));   // (the source may be the count table)
     HIPCHK(hipMemcpyAsync(dev_dst, dev_src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));   // asynchronous, stream-ordered
     return KPAL_OK;
 }

@@ -92,6 +92,17 @@ struct kpal_ctx {
     // two-level quad pipeline: the staged forms of the last piece have not been added to the table yet (quad2_finalize)
     bool finalize_pending = false;
     const void *finalize_stage = nullptr;
+    // FRESH mode of that pipeline (kpal_quads2.hip): kpal_count_begin leaves the table of a k >= 13 count UNZEROED
+    // (table_zero_pending) -- the first piece, if it is a whole device feed on the two-level quad pipeline, lets its
+    // finalisation WRITE the table instead of adding to it, and keeps the few counts that bypass the records in lists until
+    // then (finalize_fresh).  Every other consumer of the table materialises the zeros first (table_ready).
+    bool table_zero_pending = false;
+    bool finalize_fresh = false;
+    bool fresh_feed = false;                 // set by kpal_count_feed_device around count_device_range: a whole device feed
+    Span fresh_span = {};                    // the piece of a FRESH finalisation (re-run classically if a list overflowed)
+    DevBuf direct_list, direct_meta;         // TableSink segments ((index << 32) | count entries); per-segment counts + overflow word
+    uint32_t direct_seg = 16384;             // entries per segment (KPAL_DIRECT_SEG: tests force the overflow path)
+    uint32_t direct_nseg = 0;                // segments in use by the pending finalisation
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     alignas(16) unsigned char chunk_pool_sent[96] = {};   // (ChunkPool) what the device copy of the pool descriptor holds
     void *chunk_pool_dev = nullptr;
@@ -238,12 +249,13 @@ inline unsigned stream_grid(kpal_ctx *ctx, uint64_t n_items, unsigned block = 25
 constexpr int kQuadsUseChunked = 2;   // launch_partition*_quads (AUTO): the sample shows a feed for the round-1 pipeline
 constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
 int launch_partition_quads(kpal_ctx *ctx, const Span &s);                 // kpal_quads.hip
-int launch_partition2_quads(kpal_ctx *ctx, const Span &s);                // kpal_quads2.hip
+int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh = false);   // kpal_quads2.hip
 int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
                       size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr);   // kpal_quads.hip
 double quad_expected_backlog(const std::vector<double> &mu, int slots);   // kpal_quads.hip
 constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
 int quad2_finalize(kpal_ctx *ctx, bool balance);                          // kpal_quads2.hip: no-op unless a finalisation is pending
+int table_ready(kpal_ctx *ctx);                                           // kpal_quads2.hip: zeros materialised, pending finalisation done: the table is the table
 int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out);   // kpal_vec.hip
 int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce);   // kpal_vec.hip
 int comm_allreduce_partials(kpal_ctx *ctx, void *dev_partials, size_t count);   // kpal_multi.hip: {double sum, uint64 count} pairs added over the ranks, in place

@@ -140,7 +140,7 @@ KPAL_API int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance)
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_comm_reduce_table before kpal_count_begin");
     if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
     if (root < 0 || root >= ctx->comm_world) return set_err(KPAL_E_INVALID, "root %d not in 0..%d", root, ctx->comm_world - 1);
-    CHK(quad2_finalize(ctx, false));   // the complete, unbalanced table goes on the wire
+    CHK(table_ready(ctx));   // the complete, unbalanced table goes on the wire
     {
         ProfScope ps_(ctx, "rccl_reduce");
         NCCLCHK(g_rccl.Reduce(ctx->table.p, ctx->table.p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream));
@@ -159,7 +159,7 @@ KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_comm_reduce_table_async before kpal_count_begin");
     if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
     if (root < 0 || root >= ctx->comm_world) return set_err(KPAL_E_INVALID, "root %d not in 0..%d", root, ctx->comm_world - 1);
-    CHK(quad2_finalize(ctx, false));
+    CHK(table_ready(ctx));
     ctx->side_turn ^= 1;
     const int t = ctx->side_turn;
     const size_t bytes = (size_t)ctx->bins * sizeof(int64_t);

@@ -178,7 +178,7 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     if (pool_bytes > ctx->quad_pool_max && s.nchunks > 64) return kSplitBatch;   // (heavily skewed 16 GiB piece: small tiles)
     CHK(ensure(ctx, ctx->keys, pool_bytes));
     uint32_t *pool = (uint32_t *)ctx->keys.p;
-    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    const TableOnly table = {(unsigned long long *)ctx->table.p};   // counts that bypass the records: atomics into the (zeroed) table
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
     LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, S>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
            error, table)

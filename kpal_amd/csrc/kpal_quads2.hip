@@ -5,7 +5,7 @@
 
 // Two-level partition of quads, k = 13..16 (quad_kernels.hpp, end): level-1 records by coarse bucket, level-2 records
 // by (coarse, fine) bucket, histogram per (coarse, fine) bucket.
-int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
+int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
 {
     const uint64_t total_steps = (s.nchunks + 63) / 64;
     if (total_steps == 0) return KPAL_OK;
@@ -100,19 +100,34 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     uint32_t *stage = pool1;
     uint32_t *pool2 = (uint32_t *)ctx->keys.p;
     uint32_t *nrounds2 = (uint32_t *)ctx->quad_meta2.p;
-    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    // Counts that bypass the records (TableSink, quad_kernels.hpp): classic -> atomic adds into the (zeroed) table; FRESH -> lists,
+    // one segment per scatter workgroup (level 1: G1, level 2: G2 x NB1) and one shared segment for the histogram stage
+    const uint32_t nseg = G1 + G2 * NB1 + 1;
+    TableSink table = {(unsigned long long *)ctx->table.p, nullptr, nullptr, 0u, nullptr};
+    TableSink table2 = table, table_h = table;
+    if (fresh) {
+        const uint32_t seg = ctx->direct_seg;
+        CHK(ensure(ctx, ctx->direct_list, (size_t)nseg * seg * sizeof(unsigned long long)));
+        CHK(ensure(ctx, ctx->direct_meta, ((size_t)nseg + 4) * sizeof(uint32_t)));
+        unsigned long long *list = (unsigned long long *)ctx->direct_list.p;
+        uint32_t *counts = (uint32_t *)ctx->direct_meta.p, *overflow = counts + nseg;
+        HIPCHK(hipMemsetAsync(counts, 0, ((size_t)nseg + 4) * sizeof(uint32_t), ctx->stream));
+        table = TableSink{nullptr, list, counts, seg, overflow};                                             // (the kernels add their workgroup's offset)
+        table2 = TableSink{nullptr, list + (size_t)G1 * seg, counts + G1, seg, overflow};
+        table_h = TableSink{nullptr, list + (size_t)(nseg - 1) * seg, counts + (nseg - 1), seg, overflow};   // global counter
+    }
 #define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
     LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
-           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table)
+           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table2)
     DISPATCH_K_13_16(ctx->k, {
         if (steps1 == 8)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else if (steps1 == 7)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else if (steps1 == 6)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         switch (steps2) {
         case 8: KPAL_QUAD2_LAUNCH(8); break;
         case 7: KPAL_QUAD2_LAUNCH(7); break;
@@ -122,8 +137,8 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
         default: KPAL_QUAD2_LAUNCH(2); break;
         }
 
-        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
-               G2, (uint32_t)tiles2, table, stage);
+        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K, TableSink>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
+               G2, (uint32_t)tiles2, table_h, stage);
     });
 #undef KPAL_QUAD2_LAUNCH
     // The staged forms are added to the table by quad2_finalize_kernel -- LATER: kpal_count_balance fuses Profile.balance into
@@ -131,7 +146,24 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s)
     // first (quad2_finalize(ctx, false)).
     ctx->finalize_pending = true;
     ctx->finalize_stage = stage;
+    ctx->finalize_fresh = fresh;
+    if (fresh) {
+        ctx->table_zero_pending = false;   // the finalisation writes every entry
+        ctx->fresh_span = s;
+        ctx->direct_nseg = nseg;
+    }
     return KPAL_OK;
+}
+
+// The table as every consumer other than a FRESH finalisation expects it: zeroed if nothing has been counted into it yet, the
+// staged forms of the last two-level quad piece added.
+int table_ready(kpal_ctx *ctx)
+{
+    if (ctx->table_zero_pending) {
+        HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+        ctx->table_zero_pending = false;
+    }
+    return quad2_finalize(ctx, false);
 }
 
 // Adds the staged forms of the last two-level quad piece to the count table (and balances the table in the same pass).
@@ -139,13 +171,38 @@ int quad2_finalize(kpal_ctx *ctx, bool balance)
 {
     if (!ctx->finalize_pending) return KPAL_OK;
     ctx->finalize_pending = false;
+    bool fresh = ctx->finalize_fresh;
+    ctx->finalize_fresh = false;
+    if (fresh) {
+        // did every bypassing count fit its list segment?  (one word; the host would wait for these kernels soon anyway)
+        uint32_t overflow = 0;
+        const uint32_t *word = (const uint32_t *)ctx->direct_meta.p + ctx->direct_nseg;
+        HIPCHK(hipMemcpyAsync(&overflow, word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (overflow) {
+            // heavily skewed piece (the lists are sized for the usual few hundred entries per workgroup): the classic way after
+            // all -- zero the table, count the piece again with atomic adds for what bypasses the records
+            HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+            const int rc = launch_partition2_quads(ctx, ctx->fresh_span, false);
+            if (rc != KPAL_OK) return rc == kQuadsUseChunked || rc == kSplitBatch ? set_err(KPAL_E_HIP, "two-level quad pipeline: cannot repeat a piece") : rc;
+            ctx->finalize_pending = false;
+            fresh = false;
+        }
+    }
     const uint16_t *stage = (const uint16_t *)ctx->finalize_stage;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {
-        if (balance)
-            LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<K, true>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+        if (balance && fresh)
+            LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<K, true, true>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+        else if (balance)
+            LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<K, true, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+        else if (fresh)
+            LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false, true>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
         else
-            LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+            LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
+        if (fresh)
+            LAUNCH(ctx, "quad2_apply_list", (quad2_apply_list_kernel<K>), dim3(ctx->direct_nseg), dim3(256), (const unsigned long long *)ctx->direct_list.p,
+                   (const uint32_t *)ctx->direct_meta.p, ctx->direct_seg, balance ? 1u : 0u, table);
     });
     return KPAL_OK;
 }

@@ -162,13 +162,55 @@ struct QuadHot {
 };
 constexpr int kQuadHotEntries = 256;
 
+// Where the counts that bypass the records go (hot items, items the spill list cannot hold, what is still carried when a
+// scatter kernel ends, staged counts beyond 16 bits).  Classic: atomic adds into the count table.  FRESH (two-level pipeline,
+// first piece of a count, kpal_quads2.hip): the table has NOT been zeroed and the finalisation will WRITE it without
+// reading it -- the bypassing counts are appended to a list instead ((index << 32) | count entries: per scatter workgroup a
+// segment with its counter in LDS, one shared segment with a global counter for the histogram stage) and added to the
+// finished table by quad2_apply_list_kernel.  A full segment raises *overflow: the host then zeroes the table and runs the
+// piece again the classic way.
+struct TableSink {
+    unsigned long long *table;      // classic target (nullptr in list mode)
+    unsigned long long *list;       // list mode: this workgroup's segment
+    uint32_t *count;                // entries appended so far (LDS or global)
+    uint32_t cap;                   // entries a segment holds
+    uint32_t *overflow;             // set when an append did not fit
+};
+
+// One-level pipeline (k <= 12): the table is always zeroed; nothing but its pointer travels through the kernels.
+struct TableOnly {
+    unsigned long long *table;
+};
+
+__device__ __forceinline__ void sink_add(const TableOnly &sink, uint64_t index, unsigned long long n) { atomicAdd(&sink.table[index], n); }
+
+// Inside the scatter kernels the TableSink lies in LDS and the helpers carry a pointer to it: eight dwords by value through the
+// placement code (and into the out-of-line quad_items_direct) cost the k >= 13 scatter 18 spilled registers.
+struct TableSinkRef {
+    const TableSink *p;
+};
+
+__device__ __forceinline__ void sink_add(const TableSink &sink, uint64_t index, unsigned long long n);
+__device__ __forceinline__ void sink_add(const TableSinkRef &ref, uint64_t index, unsigned long long n) { sink_add(*ref.p, index, n); }
+
+__device__ __forceinline__ void sink_add(const TableSink &sink, uint64_t index, unsigned long long n)
+{
+    if (sink.table) {               // (uniform)
+        atomicAdd(&sink.table[index], n);
+    } else {
+        const uint32_t at = atomicAdd(sink.count, 1u);
+        if (at < sink.cap) sink.list[at] = ((unsigned long long)index << 32) | (n & 0xFFFFFFFFull);
+        else *sink.overflow = 1u;
+    }
+}
+
 __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
 {
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
 }
 
-template <int K, int LEVEL = 1>
-__device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, unsigned long long *__restrict__ table,
+template <int K, int LEVEL = 1, typename SINK = TableOnly>
+__device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table,
                                                             QuadHot *hot, uint32_t coarse = 0)   // (rare path, called from the
                                                                             // unrolled placement loop: kept out of line)
 {
@@ -176,7 +218,7 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
     auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((it >> (3 - i)) & 1u) atomicAdd(&table[quad_kmer<K, LEVEL>(r, it, i, coarse)], n);
+            if ((it >> (3 - i)) & 1u) sink_add(table, quad_kmer<K, LEVEL>(r, it, i, coarse), n);
     };
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
     for (int round = 0; round < 8 && todo; ++round) {   // wave-uniform
@@ -223,9 +265,9 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
 // the row (the atomic returns the item's byte offset: one shift-add gives its LDS address).
-template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4>
+template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4, typename SINK = TableOnly>
 __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
-                                               const uint32_t (&row)[N], const uint32_t (&item)[N], unsigned long long *table,
+                                               const uint32_t (&row)[N], const uint32_t (&item)[N], const SINK &table,
                                                QuadHot *hot, uint32_t coarse = 0)
 {
     using C = typename std::conditional<LEVEL == 2, QuadCfg<11>, QuadCfg<K>>::type;   // level 2: 512 rows x 64 slots
@@ -301,7 +343,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
             if (__builtin_expect(__any(unlisted != 0u), 0)) {
 #pragma unroll
                 for (int q = 0; q < N; ++q)
-                    if (__any((unlisted >> q) & 1u)) quad_items_direct<K, LEVEL>((unlisted >> q) & 1u, row[q], item[q], table, hot, coarse);
+                    if (__any((unlisted >> q) & 1u)) quad_items_direct<K, LEVEL, SINK>((unlisted >> q) & 1u, row[q], item[q], table, hot, coarse);
             }
             return over;
         }
@@ -329,7 +371,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
                 base += (uint32_t)__popcll(b);
             }
             // carried items that still do not fit, and whatever the list cannot hold: counted now
-            if (__any(ov && !listed)) quad_items_direct<K, LEVEL>(ov && !listed, row[q], item[q], table, hot, coarse);
+            if (__any(ov && !listed)) quad_items_direct<K, LEVEL, SINK>(ov && !listed, row[q], item[q], table, hot, coarse);
         }
     }
     return over;
@@ -337,10 +379,10 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 
 // The items a thread carries from one round to the next (entries threadIdx.x + c * THREADS of the spill list).
 // Plain functions on array references: as [&] lambdas the arrays were kept in scratch memory.
-template <int K, int CARRY, int LEVEL = 1>
+template <int K, int CARRY, int LEVEL = 1, typename SINK = TableOnly>
 __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                    const uint32_t (&carry_row)[CARRY], uint32_t (&carry_item)[CARRY],
-                                                   unsigned long long *table, QuadHot *hot, uint32_t coarse = 0)
+                                                   const SINK &table, QuadHot *hot, uint32_t coarse = 0)
 {
 #pragma unroll
     for (int c = 0; c < CARRY; ++c) {
@@ -348,7 +390,7 @@ __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos
         const uint32_t i1[1] = {carry_item[c]};
         if (__any(carry_item[c] != 0u)) {
             // an item that does not fit even now has been counted: it is no longer carried
-            if (quad_place<K, true, LEVEL, 1>(rows, pos, spill, spill_n, cap, r1, i1, table, hot, coarse) & 1u) carry_item[c] = 0;
+            if (quad_place<K, true, LEVEL, 1, SINK>(rows, pos, spill, spill_n, cap, r1, i1, table, hot, coarse) & 1u) carry_item[c] = 0;
         }
     }
 }
@@ -438,13 +480,13 @@ __device__ __forceinline__ uint4 fetch_wave_step(const Span &s, uint64_t step, u
 // round) + one per-thread 32-bit offset fixed for the whole kernel.
 // pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots
 // (k = 12, kPairRows: (((row / 2) * G + g) * rounds_cap + round) * 32 + (row % 2) * 16).
-template <int K, int WAVES, int STEPS, int DEPTH>
+template <int K, int WAVES, int STEPS, int DEPTH, typename SINK = TableOnly>
 __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
                                                                   uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
-                                                                  uint32_t *__restrict__ error,
-                                                                  unsigned long long *__restrict__ table)
+                                                                  uint32_t *__restrict__ error, SINK sink_arg)
 {
     using C = QuadCfg<K>;
+    constexpr bool kLists = std::is_same<SINK, TableSink>::value;
     constexpr int S = C::kSlots, NB = C::kBuckets;
     constexpr int THREADS = WAVES * 64;
     constexpr int kQuadTileSteps = WAVES * STEPS;
@@ -458,6 +500,24 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                                                 // thread after the placement barrier, so it may only be reset a barrier later --
                                                 // thread 0 resets the OTHER one (for tile j+1) during the flush of tile j
     __shared__ QuadHot hot[kQuadHotEntries];    // items of persistently over-full rows, counted here instead of in the table
+    __shared__ uint32_t direct_n;               // list mode (TableSink): entries this workgroup appended to its segment
+    __shared__ TableSink sink_lds;              // (k >= 13) the sink as this workgroup uses it
+    using SINK2 = typename std::conditional<kLists, TableSinkRef, SINK>::type;
+    SINK2 table;
+    if constexpr (kLists) {
+        if (threadIdx.x == 0) {
+            TableSink t = sink_arg;
+            if (t.list) {                       // this workgroup's segment, counted in LDS
+                t.list += (size_t)blockIdx.x * t.cap;
+                t.count = &direct_n;
+            }
+            sink_lds = t;
+            direct_n = 0;
+        }
+        table = TableSinkRef{&sink_lds};
+    } else {
+        table = sink_arg;
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t lane16 = (uint32_t)lane * 16u;
     for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
@@ -524,7 +584,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const bool next_inside = more && (fnext + STEPS) * 64 <= s.nchunks;
         uint32_t *spill_n = &spill_cnt[j & 1];
         // ---- place: carried items, then this tile's
-        quad_place_carried<K, CARRY>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
+        quad_place_carried<K, CARRY, 1, SINK2>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
         Chunk carry = encode16(rawh);
         range_fix(s, (int64_t)(first * 64) - 1, carry);
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
@@ -557,7 +617,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 #if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
             asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
 #else
-            quad_place<K>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
+            quad_place<K, false, 1, 4, SINK2>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
 #endif
         }
         have_rec = false;
@@ -595,7 +655,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
     // what is still carried over, then the table of hot items: into the count table
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 1, SINK2>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot);
     __syncthreads();
     uint32_t used = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
@@ -605,10 +665,16 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             const uint32_t r = (uint32_t)(h.key >> 32), it = (uint32_t)h.key;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if ((it >> (3 - q)) & 1u) atomicAdd(&table[quad_kmer<K>(r, it, q)], (unsigned long long)h.count);
+                if ((it >> (3 - q)) & 1u) sink_add(table, quad_kmer<K>(r, it, q), (unsigned long long)h.count);
         }
     }
     if (used) atomicAdd(error + 1, used);   // statistics only (KPAL_QUAD_VERBOSE)
+    if constexpr (kLists) {
+        if (sink_arg.list) {                // list mode: how many entries of the segment are valid
+            __syncthreads();
+            if (threadIdx.x == 0) sink_arg.count[blockIdx.x] = min(direct_n, sink_arg.cap);
+        }
+    }
 }
 
 // ==========================================================================================
@@ -633,7 +699,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
                                                             uint32_t G1, uint32_t rounds_cap1, uint32_t upw, uint32_t tiles_per_block,
                                                             uint32_t *__restrict__ pool2, uint32_t rounds_cap2,
                                                             uint32_t *__restrict__ nrounds2, uint32_t *__restrict__ error,
-                                                            unsigned long long *__restrict__ table)
+                                                            TableSink sink_arg)
 {
     using C1 = QuadCfg<K>;
     using C = QuadCfg<11>;                      // rows of level 2: 512 x 64 slots, items of 23 bits
@@ -648,6 +714,19 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     __shared__ uint32_t spill_cnt[2];
     __shared__ QuadHot hot[kQuadHotEntries];
     __shared__ uint32_t nr1[256];               // rounds written by every level-1 workgroup
+    __shared__ uint32_t direct_n;               // list mode (TableSink): entries this workgroup appended to its segment
+    __shared__ TableSink sink_lds;
+    const uint32_t wg_linear = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+        TableSink t = sink_arg;
+        if (t.list) {
+            t.list += (size_t)wg_linear * t.cap;
+            t.count = &direct_n;
+        }
+        sink_lds = t;
+        direct_n = 0;
+    }
+    const TableSinkRef table = {&sink_lds};
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t coarse = blockIdx.y;
     for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
@@ -728,7 +807,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
         const bool more = j + 1 < tiles_per_block && (j + 1) * tile_bytes < (uint64_t)stream;
         uint32_t *spill_n = &spill_cnt[j & 1];
-        quad_place_carried<K, CARRY, 2>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
+        quad_place_carried<K, CARRY, 2, TableSinkRef>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
         if (more) seek(j + 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
@@ -747,7 +826,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
                 for (int i = st; i < FI; i += STEPS) store_rec(i);
             }
             if (more) raw[st] = fetch_next();
-            quad_place<K, false, 2>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
+            quad_place<K, false, 2, 4, TableSinkRef>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
         }
         have_rec = false;
         lds_barrier();
@@ -782,7 +861,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
     __syncthreads();
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
         const QuadHot h = hot[i];
@@ -790,8 +869,12 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
             const uint32_t r = (uint32_t)(h.key >> 32), itm = (uint32_t)h.key;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if ((itm >> (3 - q)) & 1u) atomicAdd(&table[quad_kmer<K, 2>(r, itm, q, coarse)], (unsigned long long)h.count);
+                if ((itm >> (3 - q)) & 1u) sink_add(table, quad_kmer<K, 2>(r, itm, q, coarse), (unsigned long long)h.count);
         }
+    }
+    if (sink_arg.list) {
+        __syncthreads();
+        if (threadIdx.x == 0) sink_arg.count[wg_linear] = min(direct_n, sink_arg.cap);
     }
 }
 
@@ -816,9 +899,9 @@ __device__ __forceinline__ uint64_t quad_bin_index(uint32_t row, uint32_t coarse
 // Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
 // Same hot-key guard as part_hist_kernel: per form the wave counts the occurrences of its first lane's bin
 // with a ballot, those lanes add to private dummy words instead (64 adds to one LDS address serialise).
-template <int K>
+template <int K, typename SINK = TableOnly>
 __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ nrounds,
-                                                         uint32_t G, uint32_t rounds_cap, unsigned long long *__restrict__ table,
+                                                         uint32_t G, uint32_t rounds_cap, SINK table,
                                                          uint32_t *__restrict__ stage)
 {
     using C = QuadCfg<K>;
@@ -996,7 +1079,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (c[e] >> 16) {
-                            atomicAdd(&table[quad_bin_index<K>(row, coarse, i, local + (uint32_t)e)], (unsigned long long)c[e]);
+                            sink_add(table, quad_bin_index<K>(row, coarse, i, local + (uint32_t)e), (unsigned long long)c[e]);
                             c[e] = 0;
                         }
                 }
@@ -1013,7 +1096,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     for (int i = 0; i < 4; ++i) {
         for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
             const uint32_t c = hist[i * BINS + local];
-            if (c) atomicAdd(&table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
+            if (c) atomicAdd(&table.table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
         }
     }
 }
@@ -1031,7 +1114,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 // The array then holds out[p] = v[p] + v'[rc(p)] for every p of R, and out is symmetric: row-wise it is written to R's
 // table entries, column-wise to those of R' (rows padded to 129: both directions free of bank conflicts).  64-bit
 // LDS adds: exact for any counts.
-template <int K, bool BALANCE>
+//   FRESH: the table holds nothing yet (first piece of a count; it was neither zeroed nor does it hold direct adds -- those wait in
+// the TableSink lists): it is not read, only written -- 8.6 GB less to move at k = 15, on top of the 8.6 GB the skipped memset saves.
+template <int K, bool BALANCE, bool FRESH>
 __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
 {
     using Q = Quad2Index<K>;
@@ -1073,59 +1158,66 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
     auto add_partner = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
         if (v) atomicAdd(&acc[at(Q::partner_hi7(lo7), Q::partner_lo7(hi7))], v);
     };
-    // ---- the table itself: 8192 vectors of two entries per set
+    // ---- the table itself: 8192 vectors of two entries per set (four loads in flight per thread at a time: with all eight
+    // live next to the partner arithmetic the balancing form needed more than the 128 registers a 1024-thread workgroup has)
 #pragma unroll 1
-    for (int half = 0; half < (pair ? 2 : 1); ++half) {
+    for (int half = 0; half < (FRESH ? 0 : (pair ? 2 : 1)); ++half) {
         const uint64_t b = half ? pbase : base;
-        ulonglong2 t[8];
+#pragma unroll 1
+        for (int batch = 0; batch < 2; ++batch) {
+            ulonglong2 t[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)it);
-            uint32_t lo7, hi7;
-            Q::stream_entry(4, q, lo7, hi7);
-            t[it] = *reinterpret_cast<const ulonglong2 *>(table + Q::entry(b, lo7, hi7));
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)it);
-            uint32_t lo7, hi7;
-            Q::stream_entry(4, q, lo7, hi7);
-            if (half == 0) {
-                add_own(lo7, hi7, t[it].x);
-                add_own(lo7 + 1u, hi7, t[it].y);
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)(4 * batch + j));
+                uint32_t lo7, hi7;
+                Q::stream_entry(4, q, lo7, hi7);
+                t[j] = *reinterpret_cast<const ulonglong2 *>(table + Q::entry(b, lo7, hi7));
             }
-            if (half == 1 || self) {
-                add_partner(lo7, hi7, t[it].x);
-                add_partner(lo7 + 1u, hi7, t[it].y);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = 2u * (threadIdx.x + 1024u * (uint32_t)(4 * batch + j));
+                uint32_t lo7, hi7;
+                Q::stream_entry(4, q, lo7, hi7);
+                if (half == 0) {
+                    add_own(lo7, hi7, t[j].x);
+                    add_own(lo7 + 1u, hi7, t[j].y);
+                }
+                if (half == 1 || self) {
+                    add_partner(lo7, hi7, t[j].x);
+                    add_partner(lo7 + 1u, hi7, t[j].y);
+                }
             }
         }
     }
-    // ---- the four forms: 2048 vectors of eight 16-bit counts per form and set
+    // ---- the four forms: 2048 vectors of eight 16-bit counts per form and set (two forms = four loads per batch)
 #pragma unroll 1
     for (int half = 0; half < (pair ? 2 : 1); ++half) {
         const uint64_t b = half ? pbase : base;
-        uint4 f[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int form = it >> 1;
-            const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(it & 1));
-            uint32_t lo7, hi7;
-            Q::stream_entry(form, q, lo7, hi7);
-            f[it] = *reinterpret_cast<const uint4 *>(stage + Q::stage_pos(form, Q::entry(b, lo7, hi7)));
-        }
+        for (int batch = 0; batch < 2; ++batch) {
+            uint4 f[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int form = it >> 1;
-            const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(it & 1));
-            uint32_t lo7, hi7;
-            Q::stream_entry(form, q, lo7, hi7);
-            if ((f[it].x | f[it].y | f[it].z | f[it].w) == 0u) continue;
-            const uint32_t w[4] = {f[it].x, f[it].y, f[it].z, f[it].w};
+            for (int j = 0; j < 4; ++j) {
+                const int form = 2 * batch + (j >> 1);
+                const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(j & 1));
+                uint32_t lo7, hi7;
+                Q::stream_entry(form, q, lo7, hi7);
+                f[j] = *reinterpret_cast<const uint4 *>(stage + Q::stage_pos(form, Q::entry(b, lo7, hi7)));
+            }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned long long v = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
-                if (half == 0) add_own(lo7 + (uint32_t)e, hi7, v);
-                if (half == 1 || self) add_partner(lo7 + (uint32_t)e, hi7, v);
+            for (int j = 0; j < 4; ++j) {
+                const int form = 2 * batch + (j >> 1);
+                const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(j & 1));
+                uint32_t lo7, hi7;
+                Q::stream_entry(form, q, lo7, hi7);
+                if ((f[j].x | f[j].y | f[j].z | f[j].w) == 0u) continue;
+                const uint32_t w[4] = {f[j].x, f[j].y, f[j].z, f[j].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned long long v = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                    if (half == 0) add_own(lo7 + (uint32_t)e, hi7, v);
+                    if (half == 1 || self) add_partner(lo7 + (uint32_t)e, hi7, v);
+                }
             }
         }
     }
@@ -1150,6 +1242,24 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
             o.y = acc[at(Q::partner_hi7(lo7 + 1u), Q::partner_lo7(hi7))];
             *reinterpret_cast<ulonglong2 *>(table + Q::entry(pbase, lo7, hi7)) = o;
         }
+    }
+}
+
+// FRESH finalisation, second step: the counts that bypassed the records (TableSink lists) are added to the finished table --
+// balanced: to the entry and to its reverse complement (a palindrome receives both adds: Profile.balance doubles it).
+// Segment g holds count[g] entries of (index << 32) | count.
+template <int K>
+__global__ __launch_bounds__(256) void quad2_apply_list_kernel(const unsigned long long *__restrict__ list, const uint32_t *__restrict__ count,
+                                                               uint32_t cap, uint32_t balance, unsigned long long *__restrict__ table)
+{
+    const uint32_t n = min(count[blockIdx.x], cap);
+    const unsigned long long *seg = list + (size_t)blockIdx.x * cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long e = seg[i];
+        const uint64_t idx = e >> 32;
+        const unsigned long long c = e & 0xFFFFFFFFull;
+        atomicAdd(&table[idx], c);
+        if (balance) atomicAdd(&table[Quad2Index<K>::revcomp(idx)], c);
     }
 }
 

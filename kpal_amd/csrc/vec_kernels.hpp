@@ -796,14 +796,15 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         for (int b = 0; b < TILE; ++b) s[a][b] = 0.0;
     uint32_t both_zero = 0;                            // pair (row threadIdx.x >> 4, column threadIdx.x & 15) of the super-tile
     bool saw_big = false;
-    // loader: value q of thread t is bin (t & 63) of staged row 4 q + (t >> 6): a wave reads one 512-byte run
-    const int lrow = threadIdx.x >> 6, lcol = threadIdx.x & 63;
+    // loader: value q of thread t is bin (t & 63) of staged row 4 q + (t >> 6): a wave reads one 512-byte run.  The row
+    // addresses are wave-uniform (scalar registers; a load is saddr + lane * 8).
+    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lcol = threadIdx.x & 63;
     const int64_t *src[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int r = 4 * q + lrow;                    // 0..15 rows of the super-tile, 16..31 its columns
         const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
-        src[q] = prof + (uint64_t)min(profile, P - 1) * n + lcol;
+        src[q] = prof + (uint64_t)min(profile, P - 1) * n;   // (uniform)
     }
     __syncthreads();                                   // the table
     auto put = [&](int buf, int q, int64_t v) {
@@ -821,21 +822,13 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         if (lcol == 0) zmask[buf][row] = z;
     };
     const uint64_t chunks = n / kSuperBins;
-    int64_t next[8];
-    uint64_t c = group;
-    uint64_t stages = 0;
-    if (c < chunks) {
+    auto request = [&](int64_t (&dst)[8], uint64_t chunk) {
+        if (chunk < chunks) {                          // block-uniform
 #pragma unroll
-        for (int q = 0; q < 8; ++q) put(0, q, src[q][c * kSuperBins]);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (; c < chunks; c += ngroups, ++stages) {
-        const bool more = c + ngroups < chunks;        // block-uniform
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) next[q] = src[q][(c + ngroups) * kSuperBins];
+            for (int q = 0; q < 8; ++q) dst[q] = src[q][chunk * kSuperBins + lcol];
         }
+    };
+    auto compute = [&](int cur) {
         both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
         if (mine) {
             // lane l takes the bin pairs (2l, 2l+1) and (32 + 2l, 32 + 2l + 1): 16-byte LDS reads (ds_read_b128 moves 256 B/clk per
@@ -857,6 +850,24 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
                     }
             }
         }
+    };
+    // the values of the next stage are requested before this stage's arithmetic and staged after it.  (Requesting TWO stages
+    // ahead -- a stage's arithmetic takes ~0.3 us, a load 1-2 us -- needs 16 more registers than four waves per SIMD leave:
+    // the compiler parked the prefetched values in scratch memory and the kernel was slower.)
+    int64_t next[8];
+    uint64_t c = group;
+    uint64_t stages = 0;
+    request(next, c);
+    if (c < chunks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) put(0, q, next[q]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; c < chunks; c += ngroups, ++stages) {
+        const bool more = c + ngroups < chunks;        // block-uniform
+        request(next, c + ngroups);
+        compute(cur);
         if (more) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) put(cur ^ 1, q, next[q]);

@@ -602,6 +602,65 @@ def test_count_balance_fused_with_the_finalisation():
         c2.close()
 
 
+@pytest.mark.parametrize('seg', [None, '8'])
+def test_fresh_table_of_the_two_level_quad_pipeline(seg):
+    """FRESH mode (k >= 13): kpal_count_begin leaves the table unzeroed, the first piece -- a whole DEVICE feed on the two-level
+    quad pipeline -- lets its finalisation write the table without reading it, and the counts that bypass the records (items the
+    spill list cannot hold, hot items, what is still carried when a scatter ends) wait in per-workgroup lists until then.
+    Against the oracle: plain and balancing finalisation, uniform and skewed input (homopolymer / two-letter stretches: the
+    hot-item path), a second feed after a fresh piece, an empty count, and -- seg = 8: list segments of eight entries -- the
+    overflow fallback (the table is zeroed after all and the piece counted again the classic way)."""
+    from kpal_amd import _native
+    if seg:
+        os.environ['KPAL_DIRECT_SEG'] = seg
+    try:
+        c2 = _native.Context(_native.default_device())
+    finally:
+        os.environ.pop('KPAL_DIRECT_SEG', None)
+    rs = np.random.RandomState(29)
+    buf = oracle.synth_reads(73, 0, 30000, 150, noisy=True)
+    skew = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=4 << 20, p=[.4, .1, .1, .4])].copy()
+    skew[1 << 20:(1 << 20) + 500000] = ord('A')
+    skew[3 << 20:(3 << 20) + 200000] = np.resize(np.frombuffer(b'AC', dtype=np.uint8), 200000)
+    d = c2.alloc(max(buf.size, skew.size) + 64)
+    try:
+        for k in (13, 14):
+            for data in (buf, skew):
+                want = oracle.count_flat(data, k, threads=8)
+                c2.h2d(d, data)
+                for balanced in (False, True):
+                    c2.count_begin(k, 'partition2_quads')
+                    c2.count_feed_device(d, data.size)
+                    assert c2.count_last_plan()[0] == 'partition2_quads'
+                    if balanced:
+                        c2.count_balance()
+                    got = c2.count_finish()
+                    assert np.array_equal(got, oracle.balance(want, k) if balanced else want), (k, balanced, seg)
+                if k == 13:
+                    # a second feed: the fresh piece is finalised (plain), the next one adds to a real table
+                    c2.count_begin(k, 'partition2_quads')
+                    c2.count_feed_device(d, data.size)
+                    c2.count_feed_device(d, data.size // 2)
+                    c2.count_balance()
+                    assert np.array_equal(c2.count_finish(), oracle.balance(want + oracle.count_flat(data[:data.size // 2], k), k)), (k, seg)
+                del want
+        # nothing fed: the zeros are materialised on demand
+        c2.count_begin(13, 'partition2_quads')
+        assert int(c2.count_finish().sum()) == 0
+        c2.count_begin(13)
+        c2.count_balance()
+        assert int(c2.count_finish().sum()) == 0
+        # a tiny feed (atomic kernel) and a host feed after kpal_count_begin left the table unzeroed
+        c2.count_begin(13)
+        c2.count_feed(buf[:5000])
+        c2.count_feed_device(d, 1000)
+        c2.h2d(d, buf)
+        assert np.array_equal(c2.count_finish(), oracle.count_flat(buf[:5000], 13) + oracle.count_flat(skew[:1000], 13))
+    finally:
+        c2.free(d)
+        c2.close()
+
+
 def test_count_balance_fused_k16_on_device():
     """k = 16 (32 GiB table, self-paired finalisation sets exist for even k): the fused finalisation + balance against the
     plain finalisation followed by the stand-alone balance kernel, compared on the device; and the plain finalisation
