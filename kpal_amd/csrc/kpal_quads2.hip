@@ -3,6 +3,12 @@
 
 #include "quad_kernels.hpp"
 
+// level 1, eight steps per tile: input chunks requested FOUR steps ahead (4 KiB per wave in flight) -- with a ring of eight the
+// kernel sits at 128 registers and the sink handling of its epilogue spills; kernels that use scratch at all ran 8 % slower
+#ifndef KPAL_L1_DEPTH8
+#define KPAL_L1_DEPTH8 4
+#endif
+
 // Two-level partition of quads, k = 13..16 (quad_kernels.hpp, end): level-1 records by coarse bucket, level-2 records
 // by (coarse, fine) bucket, histogram per (coarse, fine) bucket.
 int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
@@ -121,7 +127,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
            (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table2)
     DISPATCH_K_13_16(ctx->k, {
         if (steps1 == 8)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, 8, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, KPAL_L1_DEPTH8, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else if (steps1 == 7)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
         else if (steps1 == 6)

@@ -210,9 +210,7 @@ __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
 }
 
 template <int K, int LEVEL = 1, typename SINK = TableOnly>
-__device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table,
-                                                            QuadHot *hot, uint32_t coarse = 0)   // (rare path, called from the
-                                                                            // unrolled placement loop: kept out of line)
+__device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
 {
     const int lane = threadIdx.x & 63;
     auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
@@ -261,6 +259,15 @@ __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_
         }
         if (!done) to_table(row, item, 1ULL);
     }
+}
+
+// (rare path, called from the unrolled placement loop: kept out of line there; the scatter kernels' epilogues inline the body -- an
+// out-of-line call next to everything that is live there cost spilled registers, and kernels that use scratch memory at all ran
+// 8 % slower in same-box comparisons, wherever the spill sat)
+template <int K, int LEVEL = 1, typename SINK = TableOnly>
+__device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
+{
+    quad_items_direct_body<K, LEVEL, SINK>(active, row, item, table, hot, coarse);
 }
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
     // what is still carried over, then the table of hot items: into the count table
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 1, SINK2>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct_body<K, 1, SINK2>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot);
     __syncthreads();
     uint32_t used = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
@@ -822,8 +829,12 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
             }
             asm volatile("" ::"v"(row[0]), "v"(item[0]));   // (the step's records are in use before the stores below are issued: see quad_scatter_kernel)
             if (have_rec) {
+                // step st stores the records [lo, hi): FI / STEPS each, the first FI % STEPS steps one more (consecutive records: one
+                // address stride; dealt st, st + STEPS, ... the 7- and 6-step variants needed 20 more registers than there are)
+                const int lo = st * (FI / STEPS) + (st < FI % STEPS ? st : FI % STEPS);   // (compile-time after unrolling)
+                const int hi = lo + FI / STEPS + (st < FI % STEPS ? 1 : 0);
 #pragma unroll
-                for (int i = st; i < FI; i += STEPS) store_rec(i);
+                for (int i = lo; i < hi; ++i) store_rec(i);
             }
             if (more) raw[st] = fetch_next();
             quad_place<K, false, 2, 4, TableSinkRef>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
@@ -861,7 +872,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct_body<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
     __syncthreads();
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
         const QuadHot h = hot[i];
@@ -1193,7 +1204,7 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
 #pragma unroll 1
     for (int half = 0; half < (pair ? 2 : 1); ++half) {
         const uint64_t b = half ? pbase : base;
-#pragma unroll
+#pragma unroll 1
         for (int batch = 0; batch < 2; ++batch) {
             uint4 f[4];
 #pragma unroll
