@@ -83,7 +83,8 @@ int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, size_t nb
 int kpal_count_begin(kpal_ctx *ctx, int k);            /* klib.py:149-151: zeroed 4^k table */
 int kpal_count_set_strategy(kpal_ctx *ctx, int strategy);
 int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);        /* klib.py:154-168 */
-int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous */
+int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous: dev_buf must stay valid
+                                                                                     * and unchanged until kpal_sync / kpal_count_finish / kpal_count_table returns */
 /* FASTA text of whole records (Profile.from_fasta, klib.py:97-112; tokenising the reference
  * delegates to Bio.SeqIO.parse, klib.py:111): header lines dropped, the lines of a record joined
  * with all ASCII whitespace removed, records separated; anything before the first header is

@@ -202,6 +202,7 @@ KPAL_API int kpal_dev_free(kpal_ctx *ctx, void *dev)
 {
     CTX_ENTER(ctx);
     if (!dev) return KPAL_OK;
+    if (ctx->counting) CHK(table_ready(ctx));   // (a pending finalisation may still want to read a fed buffer: kpal_quads2.hip, FRESH)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(dev));
     return KPAL_OK;

@@ -180,7 +180,8 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     const TableOnly table = {(unsigned long long *)ctx->table.p};   // counts that bypass the records: atomics into the (zeroed) table
     // (input chunks are requested S steps ahead; at k <= 11 with eight steps that ring costs the registers the kernel does not have --
-    // 12 spilled, and a kernel that uses scratch memory at all ran ~10 % slower in same-box comparisons -- so four steps ahead there)
+    // 12 spilled, and a kernel that uses scratch memory at all ran ~10 % slower in same-box comparisons -- so four steps ahead there;
+    // k = 12 fits its 128 registers either way and a four-step ring changed nothing: 7.44 vs 7.40 ms)
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
     LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 && K != 12 ? 4 : S)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
            error, table)

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct_body<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
     __syncthreads();
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
         const QuadHot h = hot[i];
