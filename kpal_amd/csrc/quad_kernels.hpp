@@ -604,9 +604,9 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             // raw[] in a tile with s_waitcnt vmcnt(0) (the loads were issued a tile ago, under conditions it cannot count) --
             // with a record store issued just before, every wave of the workgroup waited out that store's round trip at the
             // top of every tile, right after the barrier, all at the same time
-            if (have_rec) {
+            if (have_rec) {   // FI / STEPS records per step; the FI % STEPS left over went out with the flush itself
 #pragma unroll
-                for (int i = st; i < FI; i += STEPS) store_rec(i);
+                for (int i = st * (FI / STEPS); i < (st + 1) * (FI / STEPS); ++i) store_rec(i);
             }
             {
                 uint32_t l16 = lane16;
@@ -652,12 +652,16 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         } else {
             have_rec = true;
             ++round;
+            // (records the next tile's steps do not take -- 16 records over 7, 6 or 3 steps -- leave now: steps that store one
+            // record more than others cost those variants spilled registers)
+#pragma unroll
+            for (int i = STEPS * (FI / STEPS); i < FI; ++i) store_rec(i);
         }
         lds_barrier();                           // every wave has its records in registers: the rows are free
     }
     if (have_rec) {
 #pragma unroll
-        for (int i = 0; i < FI; ++i) store_rec(i);
+        for (int i = 0; i < STEPS * (FI / STEPS); ++i) store_rec(i);
     }
     if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
     // what is still carried over, then the table of hot items: into the count table
@@ -798,6 +802,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     constexpr int LPR = S / 4;
     constexpr int NVEC = NB * LPR;
     constexpr int FI = NVEC / THREADS;          // 16
+    constexpr int DEFER = FI / STEPS;           // records a step of the next tile stores
     uint4 rec[FI];
     bool have_rec = false;
     const uint32_t wg = coarse * gridDim.x + blockIdx.x;
@@ -829,12 +834,9 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
             }
             asm volatile("" ::"v"(row[0]), "v"(item[0]));   // (the step's records are in use before the stores below are issued: see quad_scatter_kernel)
             if (have_rec) {
-                // step st stores the records [lo, hi): FI / STEPS each, the first FI % STEPS steps one more (consecutive records: one
-                // address stride; dealt st, st + STEPS, ... the 7- and 6-step variants needed 20 more registers than there are)
-                const int lo = st * (FI / STEPS) + (st < FI % STEPS ? st : FI % STEPS);   // (compile-time after unrolling)
-                const int hi = lo + FI / STEPS + (st < FI % STEPS ? 1 : 0);
+                // step st stores FI / STEPS records; the FI % STEPS left over (7- and 6-step tiles) went out with the flush itself
 #pragma unroll
-                for (int i = lo; i < hi; ++i) store_rec(i);
+                for (int i = st * DEFER; i < (st + 1) * DEFER; ++i) store_rec(i);
             }
             if (more) raw[st] = fetch_next();
             quad_place<K, false, 2, 4, TableSinkRef>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
@@ -863,12 +865,16 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         } else {
             have_rec = true;
             ++round;
+            // the records that the next tile's steps do not take (uneven split: steps that store three records instead of two cost
+            // the 7- and 6-step variants 18 spilled registers) leave now
+#pragma unroll
+            for (int i = STEPS * DEFER; i < FI; ++i) store_rec(i);
         }
         lds_barrier();
     }
     if (have_rec) {
 #pragma unroll
-        for (int i = 0; i < FI; ++i) store_rec(i);
+        for (int i = 0; i < STEPS * DEFER; ++i) store_rec(i);
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
