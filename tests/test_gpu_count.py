@@ -552,8 +552,9 @@ def test_two_level_k15_against_oracle(mode):
 def test_count_balance_fused_with_the_finalisation():
     """kpal_count_balance (count + balance, the unit of the north-star metric).  On the two-level quad pipeline the balance
     is fused into the pass that adds the staged forms to the table (quad2_finalize_kernel<K, true>): against
-    oracle.balance(oracle.count) for k = 13 and 14 (even k: finalisation sets that are their own reverse complement) on
-    noisy reads, one unbroken sequence and skewed composition; with two feeds (the first one's forms are flushed
+    oracle.balance(oracle.count) for k = 13 (k = 14 -- even k: finalisation sets that are their own reverse complement -- in
+    test_fresh_table_of_the_two_level_quad_pipeline) on one unbroken sequence and skewed composition, fed from the HOST (classic
+    finalisation: the table is zeroed and read); with two feeds (the first one's forms are flushed
     unbalanced, the second's finalisation balances the sum); with entries beyond 32 bits already in the table; through
     kpal_balance_device on the table pointer; and on the pipelines without a staged finalisation (k = 5, 12: the
     stand-alone balance kernel).  k = 15 / 16 (8 / 32 GiB tables): test_full_size_k15, test_count_balance_fused_k16_on_device."""
@@ -565,8 +566,8 @@ def test_count_balance_fused_with_the_finalisation():
     skew = np.frombuffer(b'ACGT', dtype=np.uint8)[rs.choice(4, size=4 << 20, p=[.4, .1, .1, .4])].copy()
     skew[1 << 20:(1 << 20) + 500000] = ord('A')
     try:
-        for k in (13, 14):
-            for data in (seq, skew) if k == 13 else (buf,):
+        for k in (13,):
+            for data in (seq, skew):
                 want = oracle.balance(oracle.count_flat(data, k, threads=8), k)
                 c2.count_begin(k, 'partition2_quads')
                 c2.count_feed(data)
