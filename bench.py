@@ -64,8 +64,9 @@ def _load_profile(name):
 
 def _kernel_row(prof, kernel, k):
     """The row of `kernel` (bench's short name, e.g. quad_scatter) in a per-kernel profile."""
+    base = kernel[:-len('_balanced')] if kernel.endswith('_balanced') else kernel   # (quad2_finalize_kernel<K, true, ...> is timed as quad2_finalize_balanced)
     for name, rec in prof['kernels'].items():
-        if ('::%s_kernel' % kernel) in name and (('<%d' % k) in name or '<' not in name):
+        if ('::%s_kernel' % base) in name and (('<%d' % k) in name or '<' not in name):
             return rec
     return None
 
@@ -92,9 +93,18 @@ def pmc_traffic(kernels, dom, k, input_bytes_per_step):
         row = _kernel_row(prof, name, k)
         if row is None:
             continue
-        # bytes that scale with the input (pools) and bytes that do not (tables) are not separated by the counters: the profile
-        # is taken at --reads 20 M (k = 12) / 40 M (k = 15) and scaled linearly -- table terms are over-scaled, noted in DESIGN
-        per_kernel[name] = row['hbm_bytes_per_dispatch_corrected'] * row['dispatches'] / max(prof['launches'], 1) * scale
+        # the profile is taken on a smaller input (--reads 20 M at k = 12, 40 M at k = 15) and scaled to this run: bytes that follow the
+        # input (the scatters' reads and record writes, the histogram's record reads) by the ratio of the input bytes, bytes that follow
+        # the 4^k table (the histogram's merge / staging writes, the finalisation, the balance) not at all
+        read = 2.0 * row.get('FETCH_SIZE', 0.0) * 1024.0     # gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md)
+        written = row.get('WRITE_SIZE', 0.0) * 1024.0
+        if 'scatter' in name or name == 'quad_sample':
+            per_dispatch = (read + written) * scale
+        elif name.endswith('_hist'):
+            per_dispatch = read * scale + written
+        else:
+            per_dispatch = read + written
+        per_kernel[name] = per_dispatch * row['dispatches'] / max(prof['launches'], 1)
         total += per_kernel[name]
     if dom in per_kernel:
         launches_per_step = kernels[dom][1]

@@ -52,7 +52,7 @@ for f in ('pmc_lds_quad.json', 'pmc_lds_quad_k15.json'):
     continue
   print(f)
   for k, v in c['kernels'].items():
-    if 'quad' in k and v.get('SQ_WAVE_CYCLES'):
+    if 'quad' in k and v.get('SQ_WAVE_CYCLES') and v.get('SQ_LDS_IDX_ACTIVE'):
         cyc = v['SQ_BUSY_CYCLES'] / 32
         print('    %-44s VALU/KiB %.0f  LDS/KiB %.1f  VALU issue %.1f %% of wave cycles  waiting %.0f %%  LDS busy %.0f %% (%.0f %% conflicts)' % (
             k[:44], v['SQ_INSTS_VALU'] / 2.95e6, v['SQ_INSTS_LDS'] / 2.95e6, 100 * v['SQ_ACTIVE_INST_VALU'] / v['SQ_WAVE_CYCLES'],
