@@ -620,11 +620,26 @@ def main():
     reducer = None
     library = args.reduce_via == 'library'
     pipelined = library and not args.serial_reduce
+    library_error = None
+    if library:
+        # Every rank first proves that it can bind RCCL (an id of its own, thrown away on ranks > 0): ncclCommInitRank is a
+        # collective, a rank that failed before it would leave the others waiting.  Any failure -> all ranks take the
+        # torch.distributed reducer and the line says so.
+        try:
+            my_id = _native.comm_unique_id()
+        except Exception as e:
+            my_id, library_error = None, '%s: %s' % (type(e).__name__, e)
+        able = torch.tensor([0 if my_id is None else 1], dtype=torch.int32, device='cuda')
+        td.all_reduce(able, op=td.ReduceOp.MIN)
+        if int(able.item()) == 0:
+            library, pipelined = False, False
+            library_error = library_error or 'another rank could not bind RCCL'
+            args.reduce_via = 'torch'
     if library:
         # the communicator of the library: rank 0's id reaches the others through the process group torch.distributed.run set up
         ident = torch.zeros(_native.COMM_ID_BYTES, dtype=torch.uint8, device='cuda')
         if rank == 0:
-            ident.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
+            ident.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
         td.broadcast(ident, src=0)
         torch.cuda.synchronize()
         ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
@@ -693,6 +708,8 @@ def main():
             'checksum_ok': ok, 'rccl_ranks': td.get_world_size(), 'reduce_via': args.reduce_via, 'pipelined_reduce': pipelined,
             'src_sha': source_sha(), 'roofline': roofline,
         }
+        if library_error:
+            line['library_rccl_error'] = library_error
         print(json.dumps(line), flush=True)
 
     ctx.free(dev_buf)
