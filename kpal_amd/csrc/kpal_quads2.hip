@@ -54,7 +54,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     // capacity (stride) of a level-1 workgroup's run of records per row: rounded up so that a unit of level 2 is a whole
     // number of KiB -- a wave-step of quad2_scatter_kernel then never straddles two units
     const uint64_t per_kib = 1024 / (S1 * 4);                                   // records per KiB: 2 (8 at k = 16)
-    const uint64_t cap1 = (tpb1 + per_kib - 1) / per_kib * per_kib;
+    const uint64_t cap1 = (tpb1 + 1 + per_kib - 1) / per_kib * per_kib;     // (+ 1: the tail round of what the last tile carried over)
     if ((size_t)kQuadRowWords * 4 * G1 * cap1 > ctx->quad_pool_max && s.nchunks > 64) return kSplitBatch;
     CHK(ensure(ctx, ctx->residuals, (size_t)kQuadRowWords * 4 * G1 * cap1));
     uint32_t *pool1 = (uint32_t *)ctx->residuals.p;
@@ -97,7 +97,8 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     ctx->plan_steps2 = steps2;
     const uint64_t tile2_bytes = (uint64_t)kWaves2 * steps2 * 1024;
     const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
-    CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * tiles2));
+    const uint64_t cap2 = tiles2 + 1;                                           // rounds per level-2 workgroup: its tiles + the tail round
+    CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * cap2));
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
     // the staged forms of the histogram stage (four 16-bit counts per table entry: 8.6 GB at k = 15) reuse the level-1 pool's buffer:
     // level 2 has read it completely before the histogram kernel starts (same stream)
@@ -124,7 +125,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     }
 #define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
     LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
-           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)tiles2, nrounds2, error, table2)
+           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)cap2, nrounds2, error, table2)
     DISPATCH_K_13_16(ctx->k, {
         if (steps1 == 8)
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, KPAL_L1_DEPTH8, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
@@ -144,7 +145,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
         }
 
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K, TableSink>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
-               G2, (uint32_t)tiles2, table_h, stage);
+               G2, (uint32_t)cap2, table_h, stage);
     });
 #undef KPAL_QUAD2_LAUNCH
     // The staged forms are added to the table by quad2_finalize_kernel -- LATER: kpal_count_balance fuses Profile.balance into

@@ -582,6 +582,10 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool) + sc + o) = rec[i];
 #endif
     };
+    auto store_rec_at = [&](int i, const uint4 &v) {   // record vector i of round `round`, i not a compile-time constant
+        const uint64_t sc = (uint64_t)i * (uint64_t)(THREADS / (LPR * PAIR)) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap + (round - 1u)) * (uint64_t)(S * 4 * PAIR);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool) + sc + thread_off) = v;
+    };
     for (uint64_t j = 0; tile_exists(j); ++j) {   // block-uniform
         const uint64_t first = tile_step(j);
         const bool more = tile_exists(j + 1);
@@ -662,6 +666,33 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     if (have_rec) {
 #pragma unroll
         for (int i = 0; i < STEPS * (FI / STEPS); ++i) store_rec(i);
+    }
+    if constexpr (kLists) {
+        // ---- tail round (two-level path): what the last tile left in the spill list goes through the rows once more and leaves as
+        // one more round of (mostly empty) records -- 128 KiB per workgroup -- instead of entry by entry into the table or, FRESH,
+        // into the list that quad2_apply_list_kernel works off with atomics (k = 15: 0.6 ms for ~5 M entries, nearly all from here)
+        if (round > 0u && round < rounds_cap) {   // block-uniform (no vote on whether anything is carried: at steady state something always is)
+            static_assert(!C::kItem3, "plain four-byte slots");
+#pragma unroll
+            for (int c = 0; c < CARRY; ++c)
+                if (carry_item[c]) {             // (the rows are empty: an item that finds its row full all the same stays carried and is counted below)
+                    const uint32_t off = atomicAdd(&pos[carry_row[c]], 4u);
+                    if (off < (uint32_t)S * 4u) {
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + carry_row[c] * (uint32_t)(S * 4) + off) = carry_item[c];
+                        carry_item[c] = 0;
+                    }
+                }
+            lds_barrier();
+            const uint4 *rv = reinterpret_cast<const uint4 *>(rows);
+            ++round;
+#pragma unroll 1
+            for (int h = 0; h < FI; h += 4) {    // (a few records at a time: nothing here may cost the main loop registers)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rec[i] = rv[threadIdx.x + (uint32_t)(h + i) * THREADS];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) store_rec_at(h + i, rec[i]);
+            }
+        }
     }
     if (threadIdx.x == 0) nrounds[blockIdx.x] = min(round, rounds_cap);
     // what is still carried over, then the table of hot items: into the count table
@@ -815,6 +846,10 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         const uint64_t sc = ((uint64_t)coarse * NB + (uint64_t)(i * (THREADS / LPR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)(S * 4);
         *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool2) + sc + o) = rec[i];
     };
+    auto store_rec_at = [&](int i, const uint4 &v) {   // record vector i of round `round`, i not a compile-time constant
+        const uint64_t sc = ((uint64_t)coarse * NB + (uint64_t)i * (uint64_t)(THREADS / LPR)) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)(S * 4);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool2) + sc + thread_off) = v;
+    };
     const uint64_t tile_bytes = (uint64_t)WAVES * STEPS * 1024;
     for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
         const bool more = j + 1 < tiles_per_block && (j + 1) * tile_bytes < (uint64_t)stream;
@@ -875,6 +910,30 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     if (have_rec) {
 #pragma unroll
         for (int i = 0; i < STEPS * DEFER; ++i) store_rec(i);
+    }
+    {
+        // ---- tail round: see quad_scatter_kernel
+        if (round > 0u && round < rounds_cap2) {   // block-uniform
+#pragma unroll
+            for (int c = 0; c < CARRY; ++c)
+                if (carry_item[c]) {
+                    const uint32_t off = atomicAdd(&pos[carry_row[c]], 4u);
+                    if (off < (uint32_t)S * 4u) {
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + carry_row[c] * (uint32_t)(S * 4) + off) = carry_item[c];
+                        carry_item[c] = 0;
+                    }
+                }
+            lds_barrier();
+            const uint4 *rv = reinterpret_cast<const uint4 *>(rows);
+            ++round;
+#pragma unroll 1
+            for (int h = 0; h < FI; h += 4) {    // (a few records at a time: nothing here may cost the main loop registers)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rec[i] = rv[threadIdx.x + (uint32_t)(h + i) * THREADS];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) store_rec_at(h + i, rec[i]);
+            }
+        }
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
