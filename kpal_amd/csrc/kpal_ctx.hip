@@ -114,9 +114,13 @@ static int ctx_init(kpal_ctx *ctx, int device)
     if (const char *e = getenv("KPAL_QUAD_STEPS")) ctx->quad_steps_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_STEPS2")) ctx->quad_steps2_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_VERBOSE")) ctx->quad_verbose = atoi(e) != 0;
+    if (const char *e = getenv("KPAL_HIST_PACKED")) ctx->quad_hist_unpacked = atoi(e) == 0;
     if (const char *e = getenv("KPAL_DIRECT_SEG")) {   // tests: tiny TableSink segments force the overflow fallback of the FRESH mode
         const long v = atol(e);
-        if (v >= 1 && v <= (1 << 20)) ctx->direct_seg = (uint32_t)v;
+        if (v >= 1 && v <= (1 << 20)) {
+            ctx->direct_seg = (uint32_t)v;
+            ctx->direct_seg_forced = true;
+        }
     }
     if (const char *e = getenv("KPAL_SPLIT_ABOVE")) {   // tests: exercise the batch-halving path on small inputs
         unsigned long long v = strtoull(e, nullptr, 10);

@@ -102,6 +102,9 @@ struct kpal_ctx {
     Span fresh_span = {};                    // the piece of a FRESH finalisation (re-run classically if a list overflowed)
     DevBuf direct_list, direct_meta;         // TableSink segments ((index << 32) | count entries); per-segment counts + overflow word
     uint32_t direct_seg = 16384;             // entries per segment (KPAL_DIRECT_SEG: tests force the overflow path)
+    bool quad_hist_unpacked = false;         // KPAL_HIST_PACKED=0: the 128 KiB histogram at every k (A/B, tests)
+    bool direct_seg_forced = false;          // ... then the histogram stage's segment is as small
+    uint32_t direct_seg_hist = 16384;        // entries of the last segment (histogram stage, shared) of the current lists
     uint32_t direct_nseg = 0;                // segments in use by the pending finalisation
     int level2_mode = 2;                     // level 2 of the two-level path (KPAL_LEVEL2): 0 count + exact offsets, 1 chunked per-tile runs, 2 chunked aligned lines (default)
     alignas(16) unsigned char chunk_pool_sent[96] = {};   // (ChunkPool) what the device copy of the pool descriptor holds

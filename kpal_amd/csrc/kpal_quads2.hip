@@ -100,9 +100,9 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     const uint64_t cap2 = tiles2 + 1;                                           // rounds per level-2 workgroup: its tiles + the tail round
     CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * cap2));
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
-    // the staged forms of the histogram stage (four 16-bit counts per table entry: 8.6 GB at k = 15) reuse the level-1 pool's buffer:
+    // the staged forms of the histogram stage (four 8-bit counts per table entry: 4.3 GB at k = 15) reuse the level-1 pool's buffer:
     // level 2 has read it completely before the histogram kernel starts (same stream)
-    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 8)));
+    CHK(ensure(ctx, ctx->residuals, std::max<size_t>((size_t)kQuadRowWords * 4 * G1 * cap1, (size_t)ctx->bins * 4 * sizeof(quad2_stage_t))));
     pool1 = (uint32_t *)ctx->residuals.p;
     uint32_t *stage = pool1;
     uint32_t *pool2 = (uint32_t *)ctx->keys.p;
@@ -113,15 +113,19 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     TableSink table = {(unsigned long long *)ctx->table.p, nullptr, nullptr, 0u, nullptr};
     TableSink table2 = table, table_h = table;
     if (fresh) {
+        // the histogram stage's shared segment also takes every count that does not fit a staged form (>= 256 within one form and
+        // piece: repeats of real genomes): room for 4 M entries (unless the tests force small segments)
         const uint32_t seg = ctx->direct_seg;
-        CHK(ensure(ctx, ctx->direct_list, (size_t)nseg * seg * sizeof(unsigned long long)));
+        const uint32_t seg_h = ctx->direct_seg_forced ? seg : std::max<uint32_t>(seg, 1u << 22);
+        ctx->direct_seg_hist = seg_h;
+        CHK(ensure(ctx, ctx->direct_list, ((size_t)(nseg - 1) * seg + seg_h) * sizeof(unsigned long long)));
         CHK(ensure(ctx, ctx->direct_meta, ((size_t)nseg + 4) * sizeof(uint32_t)));
         unsigned long long *list = (unsigned long long *)ctx->direct_list.p;
         uint32_t *counts = (uint32_t *)ctx->direct_meta.p, *overflow = counts + nseg;
         HIPCHK(hipMemsetAsync(counts, 0, ((size_t)nseg + 4) * sizeof(uint32_t), ctx->stream));
         table = TableSink{nullptr, list, counts, seg, overflow};                                             // (the kernels add their workgroup's offset)
         table2 = TableSink{nullptr, list + (size_t)G1 * seg, counts + G1, seg, overflow};
-        table_h = TableSink{nullptr, list + (size_t)(nseg - 1) * seg, counts + (nseg - 1), seg, overflow};   // global counter
+        table_h = TableSink{nullptr, list + (size_t)(nseg - 1) * seg, counts + (nseg - 1), seg_h, overflow};   // global counter
     }
 #define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
     LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
@@ -144,8 +148,13 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
         default: KPAL_QUAD2_LAUNCH(2); break;
         }
 
-        LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K, TableSink>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
-               G2, (uint32_t)cap2, table_h, stage);
+        // (packed bins: two forms per word, two workgroups per CU -- safe while a histogram workgroup's stream holds < 2^16 item slots)
+        if (K >= 15 && (uint64_t)G2 * cap2 * 64 < 65536 && !ctx->quad_hist_unpacked)
+            LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K, TableSink, true>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
+                   G2, (uint32_t)cap2, table_h, stage);
+        else
+            LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K, TableSink, false>), dim3(512, NB1), dim3(1024), (const uint32_t *)pool2, (const uint32_t *)nrounds2,
+                   G2, (uint32_t)cap2, table_h, stage);
     });
 #undef KPAL_QUAD2_LAUNCH
     // The staged forms are added to the table by quad2_finalize_kernel -- LATER: kpal_count_balance fuses Profile.balance into
@@ -196,7 +205,7 @@ int quad2_finalize(kpal_ctx *ctx, bool balance)
             fresh = false;
         }
     }
-    const uint16_t *stage = (const uint16_t *)ctx->finalize_stage;
+    const quad2_stage_t *stage = (const quad2_stage_t *)ctx->finalize_stage;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {
         if (balance && fresh)
@@ -208,8 +217,9 @@ int quad2_finalize(kpal_ctx *ctx, bool balance)
         else
             LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
         if (fresh)
-            LAUNCH(ctx, "quad2_apply_list", (quad2_apply_list_kernel<K>), dim3(ctx->direct_nseg), dim3(256), (const unsigned long long *)ctx->direct_list.p,
-                   (const uint32_t *)ctx->direct_meta.p, ctx->direct_seg, balance ? 1u : 0u, table);
+            LAUNCH(ctx, "quad2_apply_list", (quad2_apply_list_kernel<K>), dim3(ctx->direct_nseg - 1 + kQuad2ListTailBlocks), dim3(256),
+                   (const unsigned long long *)ctx->direct_list.p, (const uint32_t *)ctx->direct_meta.p, ctx->direct_seg, ctx->direct_nseg - 1,
+                   ctx->direct_seg_hist, balance ? 1u : 0u, table);
     });
     return KPAL_OK;
 }

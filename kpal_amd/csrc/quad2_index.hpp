@@ -9,17 +9,19 @@
 // and the k-mer was histogrammed by the workgroup of the SCRAMBLED bucket (coarse ^ smask1(t), fine ^ smask(t)) in bin
 // local = hipart << s | lopart (quad_bin_index).
 //
-// STAGING LAYOUT (16-bit counts).  A histogram workgroup stores its four planes of 8192 bins as ONE contiguous 64 KiB block
-// (scattered 1 KiB pieces cost the histogram kernel 20 % at k = 15), each plane ordered t-major:
+// STAGING LAYOUT (8-bit counts, quad2_stage_t; a count >= kQuad2StageLimit bypasses the staging: TableSink).  A histogram workgroup
+// stores its four planes of 8192 bins as ONE contiguous 32 KiB block (scattered pieces cost the histogram kernel 20 % at k = 15),
+// each plane ordered t-major:
 //        pos = ((scrambled coarse * 512 + scrambled fine) * 4 + i) * 8192 + t * 512 + hipart * 2^(s-4) + (lopart mod 2^(s-4)).
 // The bins of one t are the bins of ONE true bucket, so a reader that lets the low bits of idx and its top bits run finds
-// every form in pieces of 256 bytes (form 3) to 1 KiB: the scrambling (which exists to spread compositional skew over the
-// scatter rows) only decides which block a piece lies in.
+// every form in pieces of 128 (form 3) to 512 counts: the scrambling (which exists to spread compositional skew over the
+// scatter rows) only decides which block a piece lies in.  Sixteen aligned consecutive positions are two groups of eight
+// consecutive table entries (stream_entry).
 //
 // SETS.  Finalisation workgroup R owns the 2^14 entries whose bits outside FREE equal R's, FREE = the low 7 bits
 // (digits 0..2 and the low bit of digit 3) and their reverse-complement image (the top 6 bits and bit 2K-8).  The
 // reverse complement maps set R onto set R' = rc(R): balancing (out[i] = v[i] + v[rc(i)]) needs the pair (R, R') and
-// nothing else, the table is read and written in runs of 1 KiB, the forms in pieces of 256 B .. 1 KiB.
+// nothing else, the table is read and written in runs of 1 KiB, the forms in pieces of 128 .. 512 B.
 #pragma once
 #include <stdint.h>
 
@@ -30,6 +32,9 @@
 #endif
 
 namespace kpal {
+
+typedef uint8_t quad2_stage_t;                      // one staged count (per table entry and form)
+constexpr uint32_t kQuad2StageLimit = 256u;         // counts >= this go to the table / the FRESH list directly and are staged as zero
 
 template <int K>
 struct Quad2Index {
@@ -44,7 +49,7 @@ struct Quad2Index {
     static constexpr KPAL_HD uint32_t smask1(uint32_t t) { return (CB > 4 ? ((t << (CB - 4)) ^ t) : t) & kCoarseMask; }      // = QuadCfg<K>::smask1
 
     // ---- staging
-    // position (in 16-bit words) of form i of table entry idx
+    // position (in counts) of form i of table entry idx
     static KPAL_HD uint64_t stage_pos(int i, uint64_t idx)
     {
         const int s = 7 + 2 * i;

@@ -975,15 +975,23 @@ __device__ __forceinline__ uint64_t quad_bin_index(uint32_t row, uint32_t coarse
 // Q2: histogram of one bucket's records, merged into the table.  hist[i * 2^L + local]: k-mer position i.
 // Same hot-key guard as part_hist_kernel: per form the wave counts the occurrences of its first lane's bin
 // with a ballot, those lanes add to private dummy words instead (64 adds to one LDS address serialise).
-template <int K, typename SINK = TableOnly>
+// PACKED (two-level path, chosen by the host for k = 15, 16 when a workgroup's record stream holds fewer than 2^16 item slots -- no
+// bin can then reach 2^16): forms i and i + 2 share a word (low / high half), the histogram is 64 KiB instead of 128 and TWO
+// workgroups fit a CU -- at k = 15 a workgroup streams only ~120 KB of records between zeroing its bins and staging them, and with
+// one workgroup per CU nothing ran during those phases (and during the latency of the first loads).
+template <int K, typename SINK = TableOnly, bool PACKED = false>
 __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restrict__ pool, const uint32_t *__restrict__ nrounds,
                                                          uint32_t G, uint32_t rounds_cap, SINK table,
                                                          uint32_t *__restrict__ stage)
 {
     using C = QuadCfg<K>;
+    static_assert(!PACKED || C::kTwoLevel, "packed bins are staged, not merged");
     // k = 13..16: blockIdx.y is the (scrambled) coarse bucket, blockIdx.x the fine row of level 2 (512 rows of 64 slots)
     constexpr int L = C::kLowBits, BINS = C::kFormBins, S = C::kTwoLevel ? 64 : C::kSlots;
-    __shared__ __attribute__((aligned(16))) uint32_t hist[4 * BINS + 64];
+    constexpr int PLANES = PACKED ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) uint32_t hist[PLANES * BINS + 64];
+    auto plane_of = [](int i) -> uint32_t { return (uint32_t)(PACKED ? (i & 1) : i) * (uint32_t)BINS; };   // word offset of form i's plane
+    auto shift_of = [](int i) -> int { return PACKED ? 16 * (i >> 1) : 0; };                                // ... and its half of the word
     // kPairRows: rows 2j and 2j+1 share every 128-byte line of their records.  Workgroups b and b + 8 are dispatched to
     // the same XCD (round-robin over eight) at nearly the same time: they take such a pair, so the second reader of a
     // line finds it in that XCD's L2 (or, drifting apart, in the memory-side cache).
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #endif
     const uint32_t row_linear = coarse * (C::kTwoLevel ? 512u : 0u) + row;
     nrounds += (size_t)coarse * G;
-    for (int i = threadIdx.x; i < 4 * BINS + 64; i += blockDim.x) hist[i] = 0;
+    for (int i = threadIdx.x; i < PLANES * BINS + 64; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Fast path: one ds_add per k-mer.  GUARD = true (skewed input only, chosen per 16-byte load when the wave's
@@ -1016,7 +1024,8 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         return local;
 #endif
         if constexpr (C::kTwoLevel) {
-            if (i == 0) return local ^ (((local >> 7) & 7u) << 3);                                   // hipart[2:0] -> bits 5:3 (t's low bits)
+            if (i == 0) return local ^ (((local >> 8) & 7u) << 3);                                   // hipart[3:1] -> bits 5:3 (t's low bits); a
+                                                                                                      // staging lane reads hipart 2j and 2j+1
             if (i == 1) return local ^ (((local >> 9) & 1u) << 5) ^ (((local >> 10) & 3u) << 3);   // hipart[0] -> bit 5, hipart[2:1] -> bits 4:3
         }
         return local;
@@ -1033,10 +1042,10 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                 const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
                 const bool eq = counted && local == hot;
                 const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
-                atomicAdd(&hist[eq ? (uint32_t)(4 * BINS + lane) : (uint32_t)(i * BINS) + local], counted);
-                if (same && lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[(uint32_t)(i * BINS) + hot], same);
+                atomicAdd(&hist[eq ? (uint32_t)(PLANES * BINS + lane) : plane_of(i) + local], counted << shift_of(i));
+                if (same && lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[plane_of(i) + hot], same << shift_of(i));
             } else {
-                atomicAdd(&hist[(uint32_t)(i * BINS) + local], counted);
+                atomicAdd(&hist[plane_of(i) + local], counted << shift_of(i));
             }
         }
     };
@@ -1128,39 +1137,48 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     __syncthreads();
     if (stage) {
         // two-level path: every table entry would receive four atomic adds (one per form, from four different
-        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are staged instead, as 16-bit counts, and
-        // quad2_finalize_kernel gathers the four of every entry.  Layout (quad2_index.hpp): the workgroup's four planes as one
-        // contiguous 64 KiB block, each plane t-major -- the bins of one t (the top four bits of the low part, which select
-        // the scramble mask) are the bins of one true bucket, so the finalisation reads them as one piece of 1 KiB.  A count
-        // that does not fit 16 bits (a k-mer seen 65536 times in one batch within ONE of its four positions) goes to the
-        // table directly and is staged as zero.
+        // workgroups: 4 x 4^k atomics, 28 ms at k = 15).  The forms are staged instead, as 8-bit counts (4.3 GB at k = 15; as
+        // 16-bit counts this kernel wrote and the finalisation read twice that), and quad2_finalize_kernel gathers the four of
+        // every entry.  Layout (quad2_index.hpp): the workgroup's four planes as one contiguous 32 KiB block, each plane
+        // t-major -- the bins of one t (the top four bits of the low part, which select the scramble mask) are the bins of one
+        // true bucket, so the finalisation reads them as one piece of 512 B.  A count that does not fit (a k-mer seen 256 times
+        // in one batch within ONE of its four positions) goes to the table / the FRESH list directly and is staged as zero.
         if constexpr (C::kTwoLevel) {
             using Q = Quad2Index<K>;
-            uint16_t *dst = reinterpret_cast<uint16_t *>(stage);
-            for (int j = threadIdx.x; j < 4 * BINS / 8; j += blockDim.x) {
-                const int i = j >> 10;                                     // plane (form)
-                const uint32_t o = ((uint32_t)j & 1023u) * 8u;           // first of eight words of the plane
-#if defined(KPAL_AB_STAGE_LINEAR)   // A/B timing (wrong counts): the planes stored in bin order, as round 2 did
-                const uint32_t local = o;
-#else
-                const uint32_t local = Q::bin_of_word(i, o);              // ... which are eight consecutive bins
-#endif
-                const uint32_t phys = stage_swizzle(i, local) & ~7u;     // (aligned blocks of eight stay together; the mask only tells the
-                                                                          // compiler so: without it the two reads become four ds_read2_b32)
-                const uint4 *src = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(&hist[i * BINS + phys], 16));
-                const uint4 a = src[0];
-                const uint4 b = src[1];
-                uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                if (__builtin_expect(((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) >> 16) != 0u, 0)) {
+            quad2_stage_t *dst = reinterpret_cast<quad2_stage_t *>(stage);
+            for (int j = threadIdx.x; j < 4 * BINS / 16; j += blockDim.x) {
+                const int i = j / (BINS / 16);                             // plane (form)
+                const uint32_t o = ((uint32_t)j % (uint32_t)(BINS / 16)) * 16u;   // first of sixteen words of the plane
+                uint32_t c[16];
+                uint32_t any = 0;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (c[e] >> 16) {
-                            sink_add(table, quad_bin_index<K>(row, coarse, i, local + (uint32_t)e), (unsigned long long)c[e]);
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t local = Q::bin_of_word(i, o + 8u * (uint32_t)h);   // eight consecutive words are eight consecutive bins
+                    const uint32_t phys = stage_swizzle(i, local) & ~7u;   // (aligned blocks of eight stay together; the mask only tells the
+                                                                            // compiler so: without it the two reads become four ds_read2_b32)
+                    const uint4 *src = reinterpret_cast<const uint4 *>(__builtin_assume_aligned(&hist[plane_of(i) + phys], 16));
+                    const uint4 a = src[0];
+                    const uint4 b = src[1];
+                    c[8 * h + 0] = a.x, c[8 * h + 1] = a.y, c[8 * h + 2] = a.z, c[8 * h + 3] = a.w;
+                    c[8 * h + 4] = b.x, c[8 * h + 5] = b.y, c[8 * h + 6] = b.z, c[8 * h + 7] = b.w;
+                }
+                if constexpr (PACKED) {
+                    const int sh = shift_of(i);                        // (wave-uniform: a plane is 512 vectors)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) c[e] = (c[e] >> sh) & 0xFFFFu;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) any |= c[e];
+                if (__builtin_expect(any >= kQuad2StageLimit, 0)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (c[e] >= kQuad2StageLimit) {
+                            sink_add(table, quad_bin_index<K>(row, coarse, i, Q::bin_of_word(i, o + (uint32_t)(e & 8)) + (uint32_t)(e & 7)), (unsigned long long)c[e]);
                             c[e] = 0;
                         }
                 }
-                *reinterpret_cast<uint4 *>(dst + Q::word_pos(i, coarse, row, o)) =
-                    make_uint4(c[0] | (c[1] << 16), c[2] | (c[3] << 16), c[4] | (c[5] << 16), c[6] | (c[7] << 16));
+                auto pack = [&](int w) { return c[4 * w] | (c[4 * w + 1] << 8) | (c[4 * w + 2] << 16) | (c[4 * w + 3] << 24); };
+                *reinterpret_cast<uint4 *>(dst + Q::word_pos(i, coarse, row, o)) = make_uint4(pack(0), pack(1), pack(2), pack(3));
             }
         }
         return;
@@ -1168,11 +1186,13 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #if defined(KPAL_AB_HIST_NO_MERGE)   // A/B timing builds (wrong counts): what the merge into the table costs
     return;
 #endif
+    if constexpr (!PACKED) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
-            const uint32_t c = hist[i * BINS + local];
-            if (c) atomicAdd(&table.table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
+        for (int i = 0; i < 4; ++i) {
+            for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
+                const uint32_t c = hist[i * BINS + local];
+                if (c) atomicAdd(&table.table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
+            }
         }
     }
 }
@@ -1193,11 +1213,15 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 //   FRESH: the table holds nothing yet (first piece of a count; it was neither zeroed nor does it hold direct adds -- those wait in
 // the TableSink lists): it is not read, only written -- 8.6 GB less to move at k = 15, on top of the 8.6 GB the skipped memset saves.
 template <int K, bool BALANCE, bool FRESH>
-__global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__restrict__ stage, unsigned long long *__restrict__ table)
+__global__ __launch_bounds__(1024) void quad2_finalize_kernel(const quad2_stage_t *__restrict__ stage, unsigned long long *__restrict__ table)
 {
     using Q = Quad2Index<K>;
     constexpr int RS = Q::kRowStride;
-    __shared__ unsigned long long acc[128 * RS];
+    // FRESH: an entry is the sum of at most eight staged counts (four forms of the entry and of its reverse complement), so 32-bit
+    // accumulators do: half the LDS -- TWO workgroups per CU, one streaming while the other zeroes, waits at its barrier or writes out
+    using acc_t = typename std::conditional<FRESH, uint32_t, unsigned long long>::type;
+    static_assert(!FRESH || 8u * (kQuad2StageLimit - 1u) < 0xFFFFFFFFu, "accumulator width");
+    __shared__ acc_t acc[128 * RS];
     // Which set a workgroup takes.  Plain: blockIdx (neighbours in the dispatch order touch adjacent 1 KiB runs).  Balancing: a set's
     // 128 table runs lie 128 MiB apart and its partner's runs somewhere else entirely -- with R's low bits running fastest every
     // workgroup in flight has partner runs in pages of its own (the partner's page number is the reverse complement of R's LOW
@@ -1220,7 +1244,7 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
     if (BALANCE && base > pbase) return;                        // block-uniform
     const bool self = BALANCE && base == pbase;
     const bool pair = BALANCE && base != pbase;
-    for (int i = threadIdx.x; i < 128 * RS; i += 1024) acc[i] = 0ull;
+    for (int i = threadIdx.x; i < 128 * RS; i += 1024) acc[i] = 0;
     __syncthreads();
     // Entry (lo7, hi7) of set R lives at acc[hi7][lo7 ^ swizzle]: a lane that unpacks eight consecutive 16-bit counts adds to
     // eight consecutive entries while its neighbours add 8 entries further on -- unswizzled, the lanes of a 32-lane group
@@ -1229,10 +1253,10 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
     auto at = [&](uint32_t hi7, uint32_t lo7) -> uint32_t { return hi7 * RS + (lo7 ^ ((lo7 >> 3) & 7u)); };
     // a value of set R at (lo7, hi7) -> acc[hi7][lo7]; of the partner set (or, self-paired, once more) -> the transposed place
     auto add_own = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
-        if (v) atomicAdd(&acc[at(hi7, lo7)], v);
+        if (v) atomicAdd(&acc[at(hi7, lo7)], (acc_t)v);
     };
     auto add_partner = [&](uint32_t lo7, uint32_t hi7, unsigned long long v) {
-        if (v) atomicAdd(&acc[at(Q::partner_hi7(lo7), Q::partner_lo7(hi7))], v);
+        if (v) atomicAdd(&acc[at(Q::partner_hi7(lo7), Q::partner_lo7(hi7))], (acc_t)v);
     };
     // ---- the table itself: 8192 vectors of two entries per set (four loads in flight per thread at a time: with all eight
     // live next to the partner arithmetic the balancing form needed more than the 128 registers a 1024-thread workgroup has)
@@ -1265,32 +1289,31 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
             }
         }
     }
-    // ---- the four forms: 2048 vectors of eight 16-bit counts per form and set (two forms = four loads per batch)
+    // ---- the four forms: 1024 vectors of sixteen 8-bit counts per form and set -- one load per form and thread; a vector is two
+    // groups of eight consecutive entries (stream positions q and q + 8)
+    static_assert(sizeof(quad2_stage_t) == 1, "sixteen counts per 16-byte vector");
 #pragma unroll 1
     for (int half = 0; half < (pair ? 2 : 1); ++half) {
         const uint64_t b = half ? pbase : base;
+        const uint32_t q = 16u * threadIdx.x;
+        uint4 f[4];
+#pragma unroll
+        for (int form = 0; form < 4; ++form) {
+            uint32_t lo7, hi7;
+            Q::stream_entry(form, q, lo7, hi7);
+            f[form] = *reinterpret_cast<const uint4 *>(stage + Q::stage_pos(form, Q::entry(b, lo7, hi7)));
+        }
+#pragma unroll
+        for (int form = 0; form < 4; ++form) {
+            if ((f[form].x | f[form].y | f[form].z | f[form].w) == 0u) continue;
 #pragma unroll 1
-        for (int batch = 0; batch < 2; ++batch) {
-            uint4 f[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int form = 2 * batch + (j >> 1);
-                const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(j & 1));
+            for (int g = 0; g < 2; ++g) {        // (not unrolled: 64 adds with their partner arithmetic side by side cost the balancing form spilled registers)
+                const uint32_t w[2] = {g ? f[form].z : f[form].x, g ? f[form].w : f[form].y};
                 uint32_t lo7, hi7;
-                Q::stream_entry(form, q, lo7, hi7);
-                f[j] = *reinterpret_cast<const uint4 *>(stage + Q::stage_pos(form, Q::entry(b, lo7, hi7)));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int form = 2 * batch + (j >> 1);
-                const uint32_t q = 8u * (threadIdx.x + 1024u * (uint32_t)(j & 1));
-                uint32_t lo7, hi7;
-                Q::stream_entry(form, q, lo7, hi7);
-                if ((f[j].x | f[j].y | f[j].z | f[j].w) == 0u) continue;
-                const uint32_t w[4] = {f[j].x, f[j].y, f[j].z, f[j].w};
+                Q::stream_entry(form, q + 8u * (uint32_t)g, lo7, hi7);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const unsigned long long v = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                    const unsigned long long v = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
                     if (half == 0) add_own(lo7 + (uint32_t)e, hi7, v);
                     if (half == 1 || self) add_partner(lo7 + (uint32_t)e, hi7, v);
                 }
@@ -1323,14 +1346,20 @@ __global__ __launch_bounds__(1024) void quad2_finalize_kernel(const uint16_t *__
 
 // FRESH finalisation, second step: the counts that bypassed the records (TableSink lists) are added to the finished table --
 // balanced: to the entry and to its reverse complement (a palindrome receives both adds: Profile.balance doubles it).
-// Segment g holds count[g] entries of (index << 32) | count.
+// Segment g < nseg holds count[g] entries of (index << 32) | count, `cap` apart; the LAST segment (the histogram stage's, shared by
+// all its workgroups: `cap_last` entries) is worked off by kQuad2ListTailBlocks workgroups together.
+constexpr uint32_t kQuad2ListTailBlocks = 256;
 template <int K>
 __global__ __launch_bounds__(256) void quad2_apply_list_kernel(const unsigned long long *__restrict__ list, const uint32_t *__restrict__ count,
-                                                               uint32_t cap, uint32_t balance, unsigned long long *__restrict__ table)
+                                                               uint32_t cap, uint32_t nseg, uint32_t cap_last, uint32_t balance,
+                                                               unsigned long long *__restrict__ table)
 {
-    const uint32_t n = min(count[blockIdx.x], cap);
-    const unsigned long long *seg = list + (size_t)blockIdx.x * cap;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const bool last = blockIdx.x >= nseg;
+    const uint32_t n = last ? min(count[nseg], cap_last) : min(count[blockIdx.x], cap);
+    const unsigned long long *seg = list + (size_t)(last ? nseg : blockIdx.x) * cap;
+    const uint32_t first = last ? (blockIdx.x - nseg) * blockDim.x + threadIdx.x : threadIdx.x;
+    const uint32_t step = last ? kQuad2ListTailBlocks * blockDim.x : blockDim.x;
+    for (uint32_t i = first; i < n; i += step) {
         const unsigned long long e = seg[i];
         const uint64_t idx = e >> 32;
         const unsigned long long c = e & 0xFFFFFFFFull;

@@ -105,6 +105,8 @@ static int check_properties(int sample_sets)
                 const uint64_t p = Q::revcomp(idx);
                 CHECK(p == Q::entry(pbase, Q::partner_lo7(hi7), Q::partner_hi7(lo7)), "partner position");
                 const uint64_t addr = src < 4 ? Q::stage_pos(src, idx) : idx;
+                if (src < 4 && (q & 15u) == 0) CHECK((addr & 15u) == 0, "a vector of sixteen staged counts is not aligned (source %d)", src);
+                if (src < 4 && (q & 15u) != 0) CHECK(addr == prev + 1, "the sixteen counts of a vector are not consecutive (source %d)", src);
                 if (q && addr != prev + 1) ++breaks;
                 prev = addr;
             }
@@ -133,16 +135,16 @@ static int emulate()
 {
     using Q = Quad2Index<K>;
     const uint64_t n = 1ull << (2 * K);
-    std::vector<uint16_t> F[4];
-    std::vector<uint16_t> stage(4 * n, 0);
+    std::vector<quad2_stage_t> F[4];
+    std::vector<quad2_stage_t> stage(4 * n, 0);
     std::vector<int64_t> T(n, 0), out(n, 0), plain(n, 0);
     for (int i = 0; i < 4; ++i) F[i].assign(n, 0);
     for (uint64_t e = 0; e < n / 3; ++e) {   // a third of the entries touched, per form
-        for (int i = 0; i < 4; ++i) F[i][rnd() & (n - 1)] = (uint16_t)(1 + (rnd() % 9));
+        for (int i = 0; i < 4; ++i) F[i][rnd() & (n - 1)] = (quad2_stage_t)(1 + (rnd() % 9));
     }
     for (uint64_t e = 0; e < n / 50; ++e) T[rnd() & (n - 1)] = (int64_t)(rnd() % 1000);
     T[rnd() & (n - 1)] = (int64_t)1 << 40;   // counts beyond 32 bits stay exact
-    for (int e = 0; e < 1000; ++e) F[rnd() & 3][rnd() & (n - 1)] = 65535;
+    for (int e = 0; e < 1000; ++e) F[rnd() & 3][rnd() & (n - 1)] = (quad2_stage_t)(kQuad2StageLimit - 1);   // the largest staged count
     // ---- staging, the way quad_hist_kernel does it: workgroup (sc, sf), plane i, word o <- its bin bin_of_word(i, o)
     for (uint32_t sc = 0; sc <= Q::kCoarseMask; ++sc)
         for (uint32_t sf = 0; sf < 512; ++sf)
