@@ -98,7 +98,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     const uint64_t tile2_bytes = (uint64_t)kWaves2 * steps2 * 1024;
     const uint64_t tiles2 = ((uint64_t)upw * unit_cap + tile2_bytes - 1) / tile2_bytes;
     const uint64_t cap2 = tiles2 + 1;                                           // rounds per level-2 workgroup: its tiles + the tail round
-    CHK(ensure(ctx, ctx->keys, (size_t)kQuadRowWords * 4 * NB1 * G2 * cap2));
+    CHK(ensure(ctx, ctx->keys, (size_t)512 * kQuadPackedRecordBytes * NB1 * G2 * cap2));   // level-2 records: 64 items packed into 192 bytes
     CHK(ensure(ctx, ctx->quad_meta2, (size_t)NB1 * G2 * sizeof(uint32_t)));
     // the staged forms of the histogram stage (four 8-bit counts per table entry: 4.3 GB at k = 15) reuse the level-1 pool's buffer:
     // level 2 has read it completely before the histogram kernel starts (same stream)

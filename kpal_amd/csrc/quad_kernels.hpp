@@ -140,6 +140,32 @@ __device__ __forceinline__ uint32_t quad_kmer(uint32_t row, uint32_t item, int i
     return (uint32_t)((x >> (6 - 2 * i)) & ((1ull << (2 * K)) - 1ull));
 }
 
+// Items of at most 23 bits (level 2 of the two-level path) leave the CU PACKED: the four items of a 16-byte LDS vector as three
+// dwords, a 64-item record as 192 bytes instead of 256 -- done on the way out, in registers, so the rows in LDS stay plain
+// dword slots (the k = 12 one-level path packs in LDS instead, with riders: its rows are short).  Rows 2j and 2j+1 share a
+// 384-byte piece (three whole lines) of the pool.
+struct QuadPacked {
+    uint32_t a, b, c;
+};
+__device__ __forceinline__ QuadPacked quad_pack3(const uint4 &v)
+{
+    QuadPacked r;
+    r.a = v.x | (v.y << 23);
+    r.b = (v.y >> 9) | (v.z << 14);
+    r.c = (v.z >> 18) | (v.w << 5);
+    return r;
+}
+__device__ __forceinline__ uint4 quad_unpack3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint4 v;
+    v.x = a & 0x7FFFFFu;
+    v.y = __builtin_amdgcn_alignbit(b, a, 23) & 0x7FFFFFu;
+    v.z = __builtin_amdgcn_alignbit(c, b, 14) & 0x7FFFFFu;
+    v.w = (c >> 5) & 0x7FFFFFu;
+    return v;
+}
+constexpr int kQuadPackedRecordBytes = 192;   // 64 items
+
 struct QuadSpill {
     uint32_t row, item;
 };
@@ -834,21 +860,24 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     constexpr int NVEC = NB * LPR;
     constexpr int FI = NVEC / THREADS;          // 16
     constexpr int DEFER = FI / STEPS;           // records a step of the next tile stores
-    uint4 rec[FI];
+    static_assert(S == 64 && LPR == 16, "packed records of 64 items");
+    QuadPacked rec[FI];                         // (packed: 48 instead of 64 registers)
     bool have_rec = false;
     const uint32_t wg = coarse * gridDim.x + blockIdx.x;
-    // (see quad_scatter_kernel: per-thread 32-bit offset + scalar base)
-    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap2 * (uint64_t)(S * 4);
-    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / LPR) * row_bytes) + (threadIdx.x % LPR) * 16u;
+    // (see quad_scatter_kernel: per-thread 32-bit offset + scalar base.)  pool2[coarse][row / 2][workgroup][round][row % 2][48 dwords]:
+    // thread t holds vector t % 16 of row t / 16 (+ 64 i), i.e. 12 bytes of the 384-byte piece of row pair t / 32 (+ 32 i)
+    constexpr uint32_t PIECE = 2u * (uint32_t)kQuadPackedRecordBytes;
+    const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap2 * (uint64_t)PIECE;      // per row PAIR
+    const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / (2 * LPR)) * row_bytes) + (threadIdx.x % (2 * LPR)) * 12u;
     auto store_rec = [&](int i) {
         uint32_t o = thread_off;
         asm volatile("" : "+v"(o));
-        const uint64_t sc = ((uint64_t)coarse * NB + (uint64_t)(i * (THREADS / LPR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)(S * 4);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool2) + sc + o) = rec[i];
+        const uint64_t sc = ((uint64_t)coarse * (NB / 2) + (uint64_t)(i * (THREADS / (2 * LPR)))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)PIECE;
+        *reinterpret_cast<QuadPacked *>(reinterpret_cast<char *>(pool2) + sc + o) = rec[i];
     };
-    auto store_rec_at = [&](int i, const uint4 &v) {   // record vector i of round `round`, i not a compile-time constant
-        const uint64_t sc = ((uint64_t)coarse * NB + (uint64_t)i * (uint64_t)(THREADS / LPR)) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)(S * 4);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(pool2) + sc + thread_off) = v;
+    auto store_rec_at = [&](int i, const QuadPacked &v) {   // record vector i of round `round`, i not a compile-time constant
+        const uint64_t sc = ((uint64_t)coarse * (NB / 2) + (uint64_t)i * (uint64_t)(THREADS / (2 * LPR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap2 + (round - 1u)) * (uint64_t)PIECE;
+        *reinterpret_cast<QuadPacked *>(reinterpret_cast<char *>(pool2) + sc + thread_off) = v;
     };
     const uint64_t tile_bytes = (uint64_t)WAVES * STEPS * 1024;
     for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
@@ -887,10 +916,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
                 const uint4 v = rv[threadIdx.x + (uint32_t)i * THREADS];
-                rec[i].x = v.x;
-                rec[i].y = v.y;
-                rec[i].z = v.z;
-                rec[i].w = v.w;
+                rec[i] = quad_pack3(v);
                 rv[threadIdx.x + (uint32_t)i * THREADS] = zero4;
             }
             for (int i = threadIdx.x * 4; i < NB; i += THREADS * 4) *reinterpret_cast<uint4 *>(&pos[i]) = zero4;
@@ -929,7 +955,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
 #pragma unroll 1
             for (int h = 0; h < FI; h += 4) {    // (a few records at a time: nothing here may cost the main loop registers)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rec[i] = rv[threadIdx.x + (uint32_t)(h + i) * THREADS];
+                for (int i = 0; i < 4; ++i) rec[i] = quad_pack3(rv[threadIdx.x + (uint32_t)(h + i) * THREADS]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) store_rec_at(h + i, rec[i]);
             }
@@ -995,18 +1021,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     // kPairRows: rows 2j and 2j+1 share every 128-byte line of their records.  Workgroups b and b + 8 are dispatched to
     // the same XCD (round-robin over eight) at nearly the same time: they take such a pair, so the second reader of a
     // line finds it in that XCD's L2 (or, drifting apart, in the memory-side cache).
-#if defined(KPAL_AB_HIST_ORBIT)   // A/B: the 16 workgroups of a scramble orbit dispatched next to each other (their staged pieces complete whole planes)
-    uint32_t row = C::kPairRows ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
-    uint32_t coarse = blockIdx.y;
-    if constexpr (C::kTwoLevel) {
-        const uint32_t lin = blockIdx.y * 512u + blockIdx.x, m = lin & 15u, rest = lin >> 4;
-        row = ((rest & 31u) << 4) ^ C::smask(m);
-        coarse = (rest >> 5) ^ C::smask1(m);
-    }
-#else
-    const uint32_t row = C::kPairRows ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
+    // (the two-level path's packed records: rows 2j and 2j+1 share the middle line of every 384-byte piece -- the same pairing)
+    constexpr bool PACK3 = C::kTwoLevel;
+    constexpr bool SIBLINGS = C::kPairRows || PACK3;
+    const uint32_t row = SIBLINGS ? (((blockIdx.x >> 4) << 4) | ((blockIdx.x & 7u) << 1) | ((blockIdx.x >> 3) & 1u)) : blockIdx.x;
     const uint32_t coarse = blockIdx.y;
-#endif
     const uint32_t row_linear = coarse * (C::kTwoLevel ? 512u : 0u) + row;
     nrounds += (size_t)coarse * G;
     for (int i = threadIdx.x; i < PLANES * BINS + 64; i += blockDim.x) hist[i] = 0;
@@ -1096,6 +1115,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     const uint32_t g_first = G >= 16u ? (uint32_t)wave : (uint32_t)wave % G;
     const uint32_t part = G >= 16u ? 0u : (uint32_t)wave / G;
     for (uint32_t g = g_first; g < G && part < parts; g += 16) {   // wave-uniform
+        // PACK3: the run of (row, g) is one 192-byte record (16 vectors of 12 bytes) in every 384-byte piece of its row pair
+        const uint32_t *src3 = pool + ((uint64_t)((row_linear >> 1) * G + g) * rounds_cap) * (uint64_t)(2 * kQuadPackedRecordBytes / 4) +
+                               (row_linear & 1u) * (uint32_t)(kQuadPackedRecordBytes / 4);
         const uint4 *src = C::kPairRows
                                ? reinterpret_cast<const uint4 *>(pool + ((uint64_t)((row_linear >> 1) * G + g) * rounds_cap) * (2 * S) + (row_linear & 1u) * S)
                                : reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
@@ -1107,7 +1129,14 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         // iteration paid a full memory latency and the LDS idled 43 % of the time.
         auto fetch = [&](uint32_t at) -> uint4 {
             const uint32_t a = min(at, nvec - 1u);
-            uint4 r = src[C::kPairRows ? ((a >> 2) * 8u + (a & 3u)) : a];   // (pairs: the row's half of every 128-byte line)
+            uint4 r;
+            if constexpr (PACK3) {
+                const uint32_t *p3 = src3 + (a >> 4) * (uint32_t)(2 * kQuadPackedRecordBytes / 4) + (a & 15u) * 3u;
+                const QuadPacked w = *reinterpret_cast<const QuadPacked *>(p3);
+                r = quad_unpack3(w.a, w.b, w.c);
+            } else {
+                r = src[C::kPairRows ? ((a >> 2) * 8u + (a & 3u)) : a];   // (pairs: the row's half of every 128-byte line)
+            }
             const uint32_t keep = at < nvec ? 0xFFFFFFFFu : 0u;
             r.x &= keep;
             r.y &= keep;
