@@ -663,6 +663,62 @@ def test_fresh_table_of_the_two_level_quad_pipeline(seg):
         c2.close()
 
 
+def test_staged_counts_beyond_eight_bits():
+    """The histogram stage of the two-level quad pipeline stages 8-bit counts; a k-mer seen >= 256 times within ONE of its four
+    item positions bypasses the staging (FRESH: the histogram stage's list segment; classic: atomic adds).  Input: a 300-base
+    sequence repeated 1500 times (every k-mer ~375 times per position), one repeated 400 times (staged: ~100 per position) and one
+    repeated 300 000 times (beyond 16 bits per position), shuffled among random reads.  k = 13 against the oracle
+    (fresh, classic = second feed, balanced), k = 15 (packed histogram bins) against the global-atomic kernel on the device."""
+    torch = pytest.importorskip('torch')
+    from kpal_amd import _native, dist
+    rs = np.random.RandomState(41)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    blocks = [acgt[rs.randint(0, 4, size=300)].tobytes() for _ in range(2)]
+    short = acgt[rs.randint(0, 4, size=40)].tobytes()
+    reads = [blocks[0]] * 1500 + [blocks[1]] * 400 + [short] * 300000 + [acgt[rs.randint(0, 4, size=150)].tobytes() for _ in range(20000)]
+    order = rs.permutation(len(reads))
+    data = np.frombuffer(b'\n'.join(reads[i] for i in order), dtype=np.uint8)
+    c2 = _native.Context(_native.default_device())
+    other = _native.Context(_native.default_device())
+    d = c2.alloc(data.size + 64)
+    try:
+        c2.h2d(d, data)
+        k = 13
+        want = oracle.count_flat(data, k, threads=8)
+        assert want.max() >= 300000 and np.count_nonzero((want >= 1024) & (want < 65536)) > 200
+        for balanced in (False, True):
+            c2.count_begin(k, 'partition2_quads')
+            c2.count_feed_device(d, data.size)                 # FRESH piece
+            if balanced:
+                c2.count_balance()
+            got = c2.count_finish()
+            assert np.array_equal(got, oracle.balance(want, k) if balanced else want), balanced
+        c2.count_begin(k, 'partition2_quads')
+        c2.count_feed_device(d, data.size)
+        c2.count_feed_device(d, data.size)                     # classic: adds to a real table
+        c2.count_balance()
+        assert np.array_equal(c2.count_finish(), oracle.balance(2 * want, k))
+        del want
+        k = 15
+        for feeds in (1, 2):
+            c2.count_begin(k, 'partition2_quads')
+            other.count_begin(k, 'global_atomic')
+            for _ in range(feeds):
+                c2.count_feed_device(d, data.size)
+                other.count_feed_device(d, data.size)
+            assert c2.count_last_plan()[0] == 'partition2_quads'
+            c2.count_finish(to_host=False)
+            other.count_finish(to_host=False)
+            c2.sync()
+            other.sync()
+            assert torch.equal(dist.table_as_tensor(c2), dist.table_as_tensor(other)), feeds
+            torch.cuda.synchronize()
+    finally:
+        c2.free(d)
+        c2.close()
+        other.close()
+
+
 def test_count_balance_fused_k16_on_device():
     """k = 16 (32 GiB table, self-paired finalisation sets exist for even k): the fused finalisation + balance against the
     plain finalisation followed by the stand-alone balance kernel, compared on the device; and the plain finalisation
