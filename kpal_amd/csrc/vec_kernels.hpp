@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void balance_inplace_kernel(int64_t *__restric
 // runs of 512 B, keeps them in LDS (rows padded to 65 to spread banks on the transposed read),
 // and writes out[i] = in[i] + in[rc(i)] for both tiles -- 16 B of HBM traffic per bin instead of
 // scattered 8-byte partner accesses.  in == out is allowed (all reads precede the barrier).
-__global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, int64_t *out, int k)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void balance_tiled_kernel(const int64_t *in, int64_t *out, int k)
 {
     constexpr int T = 3, S = 64;
     __shared__ unsigned long long A[S][S + 1];
@@ -109,8 +109,19 @@ __global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, 
     unsigned long long *uout = reinterpret_cast<unsigned long long *>(out);
     // persistent workgroups over the canonical tile pairs (M <= rc(M)); the next pair's eight values
     // per thread are loaded before the current pair is exchanged through LDS and written back
-    auto canonical_from = [&](uint64_t m) {
-        while (m < nM && md > 0 && m > revcomp(m, md)) m += gridDim.x;
+    // ORDER of the tile pairs (k >= 13).  A tile's 64 runs lie 4^(k-3) entries apart -- 64 pages whatever M is -- and the partner's
+    // page numbers are the reverse complement of M's LOW digits: with M counting up, every workgroup in flight had 64 partner pages
+    // of its own and the kernel ran at 2.9 TB/s (k = 15) -- address translation, as in quad2_finalize_kernel.  So the sequence
+    // number m is mapped to M with the bits that are page bits on NEITHER side (M bits 2 md - 12 .. 11: index bits below 18 here and
+    // in the partner) running fastest: tiles worked on at the same time share their pages on both sides.
+    const int lo = 2 * md - 12 > 0 ? 2 * md - 12 : 0, hi = 2 * md - 1 < 11 ? 2 * md - 1 : 11;
+    const int nn = hi - lo + 1;
+    auto tile_of = [&](uint64_t m) -> uint64_t {
+        if (lo == 0 || nn <= 0) return m;
+        return ((m & ((1ULL << nn) - 1ULL)) << lo) | ((m >> nn) & ((1ULL << lo) - 1ULL)) | ((m >> (nn + lo)) << (nn + lo));
+    };
+    auto canonical_from = [&](uint64_t m) {     // m: sequence number; the tile is tile_of(m)
+        while (m < nM && md > 0 && tile_of(m) > revcomp(tile_of(m), md)) m += gridDim.x;
         return m;
     };
     auto fetch = [&](uint64_t M, unsigned long long (&a)[4], unsigned long long (&b)[4]) {
@@ -123,11 +134,12 @@ __global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, 
         }
     };
     unsigned long long a[4], b[4], na[4], nb[4];
-    uint64_t M = canonical_from(blockIdx.x);
-    if (M < nM) fetch(M, a, b);
-    while (M < nM) {
-        const uint64_t Mn = canonical_from(M + gridDim.x);
-        if (Mn < nM) fetch(Mn, na, nb);
+    uint64_t seq = canonical_from(blockIdx.x);
+    if (seq < nM) fetch(tile_of(seq), a, b);
+    while (seq < nM) {
+        const uint64_t M = tile_of(seq);
+        const uint64_t seqn = canonical_from(seq + gridDim.x);
+        if (seqn < nM) fetch(tile_of(seqn), na, nb);
         const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
         const bool self = M == Mr;
 #pragma unroll
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(1024) void balance_tiled_kernel(const int64_t *in, 
             a[q] = na[q];
             b[q] = nb[q];
         }
-        M = Mn;
+        seq = seqn;
     }
 }
 
