@@ -42,6 +42,8 @@ def lib():
         L.kpal_oracle_reverse_complement.restype = ctypes.c_uint64
         L.kpal_oracle_balance.argtypes = [_c_i64p, ctypes.c_int]
         L.kpal_oracle_balance.restype = None
+        L.kpal_oracle_balance_mt.argtypes = [_c_i64p, ctypes.c_int, ctypes.c_int]
+        L.kpal_oracle_balance_mt.restype = None
         L.kpal_oracle_split.argtypes = [_c_i64p, ctypes.c_int, _c_i64p, _c_i64p]
         L.kpal_oracle_split.restype = ctypes.c_size_t
         L.kpal_oracle_multiset_i64.argtypes = [_c_i64p, _c_i64p, ctypes.c_size_t, ctypes.c_int, _c_i64p]
@@ -132,10 +134,16 @@ def reverse_complement(number, length):
     return int(lib().kpal_oracle_reverse_complement(number, length))
 
 
-def balance(counts, length):
-    """Restates Profile.balance (klib.py:285-298); returns a balanced COPY."""
+def balance(counts, length, threads=None):
+    """Restates Profile.balance (klib.py:285-298); returns a balanced COPY.  Tables of k >= 11 are dealt to host threads by
+    index range (the same statement per pair; ``threads=1`` is the plain loop)."""
     c = np.array(counts, dtype=np.int64, copy=True)
-    lib().kpal_oracle_balance(c.ctypes.data_as(_c_i64p), length)
+    if threads is None:
+        threads = min(16, os.cpu_count() or 1) if length >= 11 else 1
+    if threads > 1:
+        lib().kpal_oracle_balance_mt(c.ctypes.data_as(_c_i64p), length, threads)
+    else:
+        lib().kpal_oracle_balance(c.ctypes.data_as(_c_i64p), length)
     return c
 
 
