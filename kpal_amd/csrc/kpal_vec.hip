@@ -360,6 +360,16 @@ int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, 
             HIPCHK(hipStreamSynchronize(ctx->stream));   // (also: `supers` was read by the asynchronous copy above)
             rdiff_done = saw_big == 0;
         }
+        if (metric == 1 && allow_rdiff) {   // multiset 'sum' with the reciprocals of the denominators from a table (matrix_rsum_kernel)
+            uint32_t *big = (uint32_t *)((int2 *)ctx->scratch[3].p + nsuper);
+            HIPCHK(hipMemsetAsync(big, 0, sizeof(uint32_t), ctx->stream));
+            HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));
+            LAUNCH(ctx, "matrix_rsum", matrix_rsum_kernel, dim3(gx * nsuper), dim3(256), prof, P, n, dt, nsuper, pp, big);
+            uint32_t saw_big = 0;
+            HIPCHK(hipMemcpyAsync(&saw_big, big, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            rdiff_done = saw_big == 0;
+        }
         if (rdiff_done) {
         } else if (metric == 0) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<0>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);
         else if (metric == 1) LAUNCH(ctx, "matrix_super", (matrix_super_kernel<1>), dim3(gx, nsuper), dim3(256), prof, P, n, dt, pp);

@@ -912,4 +912,135 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     }
 }
 
+// Multiset with the 'sum' pairwise function, |x - y| / (x + y + 1) (metrics.py:101-123, 159-162): no difference form as for
+// 'prod', but the denominator is a small integer -- its reciprocal comes from a table in LDS, R[s] = 1 / (s + 1) for
+// s = x + y < kRsumTable, and a term is v_sad_u32 (|x - y|), v_add_lshl_u32 (the table offset), one ds_read_b64, a conversion
+// and one fused multiply-add (matrix_super_kernel<1>: the two conversions, the sum and a ~10-instruction division).  Profiles of
+// one sample have counts within a narrow range, so the 64 lanes of a table read touch a few dozen consecutive entries: few bank
+// conflicts.  Same super-tile structure, loader, zero masks / popcounts for the term count and partial layout as
+// matrix_rdiff_kernel; the staged values are the counts themselves as 32-bit integers (16 KiB instead of 32).
+//   A count >= kRsumTable / 2 anywhere raises *big and the caller reruns matrix_super_kernel<1> (an inline second path for
+// such stages cost the kernel its occupancy: 200 registers).
+//   Accuracy: R within 1 ulp, |x - y| exact: a term within 1.5 ulp of the correctly rounded quotient the reference computes.
+constexpr int kRsumTable = 2048;
+__global__ __launch_bounds__(256) void matrix_rsum_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                          const int2 *__restrict__ supers, uint32_t nsuper,
+                                                          Partial *__restrict__ partials, uint32_t *__restrict__ big)
+{
+    constexpr int TILE = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t cstage[2][32][kSuperBins];
+    __shared__ unsigned long long zmask[2][32];
+    __shared__ double rtable[kRsumTable];
+    for (int i = threadIdx.x; i < kRsumTable; i += 256) rtable[i] = rcp_counts((double)i + 1.0);
+    // (grid: see matrix_rdiff_kernel -- the workgroups that stage the same bins are neighbours on one XCD)
+    const uint32_t lin = blockIdx.x, xcd = lin & 7u, sidx = (lin >> 3) % nsuper, cgrp = (lin >> 3) / nsuper;
+    const uint32_t group = cgrp * 8u + xcd, ngroups = gridDim.x / nsuper;
+    const int si = supers[sidx].x, sj = supers[sidx].y;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int ti = si * 4 + (g >> 2), tj = sj * 4 + (g & 3);
+    const int side = (P + TILE - 1) / TILE;
+    const bool mine = ti < side && tj <= ti;
+    double s[TILE][TILE];
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) s[a][b] = 0.0;
+    uint32_t both_zero = 0;
+    bool saw_big = false;
+    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lcol = threadIdx.x & 63;
+    const int64_t *src[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 4 * q + lrow;
+        const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
+        src[q] = prof + (uint64_t)min(profile, P - 1) * n;
+    }
+    __syncthreads();
+    auto put = [&](int buf, uint32_t stage_no, int q, int64_t v) {
+        const int row = 4 * q + lrow;
+        saw_big |= (unsigned long long)v >= (unsigned long long)(kRsumTable / 2);   // (x + y must stay inside the table)
+        cstage[buf][row][lcol] = (uint32_t)v & (uint32_t)(kRsumTable / 2 - 1);   // (masked: a larger count only ever costs a rerun, never an out-of-range read)
+        const unsigned long long z = __builtin_amdgcn_ballot_w64(v == 0);
+        if (lcol == 0) zmask[buf][row] = z;
+    };
+    const uint64_t chunks = n / kSuperBins;
+    auto request = [&](int64_t (&dst)[8], uint64_t chunk) {
+        if (chunk < chunks) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = src[q][chunk * kSuperBins + lcol];
+        }
+    };
+    auto compute = [&](int cur, uint32_t stage_no) {
+        both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
+        if (!mine) return;
+        // lane l takes the bins 4l .. 4l+3 of every row: one 16-byte LDS read per row
+        uint4 cx[TILE], cy[TILE];
+#pragma unroll
+        for (int a = 0; a < TILE; ++a) {
+            cx[a] = *reinterpret_cast<const uint4 *>(&cstage[cur][4 * (g >> 2) + a][4 * l]);
+            cy[a] = *reinterpret_cast<const uint4 *>(&cstage[cur][16 + 4 * (g & 3) + a][4 * l]);
+        }
+        const char *tab = reinterpret_cast<const char *>(rtable);
+#pragma unroll
+        for (int a = 0; a < TILE; ++a)
+#pragma unroll
+            for (int b = 0; b < TILE; ++b) {
+                // one pair (four terms) at a time: everything a term needs before its table read depends only on the staged counts,
+                // and with the offsets and differences of all 64 terms computed up front the kernel needed 190 registers (two
+                // waves per SIMD); the other three waves of the SIMD cover the latency of the four reads
+                asm volatile("" : "+v"(cy[b].x), "+v"(cy[b].y), "+v"(cy[b].z), "+v"(cy[b].w));
+                const uint32_t x[4] = {cx[a].x, cx[a].y, cx[a].z, cx[a].w}, y[4] = {cy[b].x, cy[b].y, cy[b].z, cy[b].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t d;
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(x[e]), "v"(y[e]));   // |x - y|
+                    const double r = *reinterpret_cast<const double *>(tab + ((x[e] + y[e]) << 3));
+                    s[a][b] = fma((double)d, r, s[a][b]);
+                }
+            }
+    };
+    int64_t next[8];
+    uint64_t c = group;
+    uint64_t stages = 0;
+    request(next, c);
+    if (c < chunks) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) put(0, 0u, q, next[q]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; c < chunks; c += ngroups, ++stages) {
+        const bool more = c + ngroups < chunks;
+        request(next, c + ngroups);
+        compute(cur, (uint32_t)stages);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) put(cur ^ 1, (uint32_t)stages + 1u, q, next[q]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (saw_big) atomicOr(big, 1u);
+#pragma unroll
+    for (int a = 0; a < TILE; ++a)
+#pragma unroll
+        for (int b = 0; b < TILE; ++b) {
+            double ps = s[a][b];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 16);
+            if (mine && l == 0) {
+                const uint64_t t = (uint64_t)ti * (ti + 1) / 2 + tj;
+                partials[(t * TILE * TILE + a * TILE + b) * ngroups + group].s = ps;
+            }
+        }
+    {
+        const int i = si * 16 + (int)(threadIdx.x >> 4), j = sj * 16 + (int)(threadIdx.x & 15);
+        const int pti = i / TILE, ptj = j / TILE;
+        if (pti < side && ptj <= pti) {
+            const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
+            partials[(t * TILE * TILE + (i % TILE) * TILE + (j % TILE)) * ngroups + group].m = stages * kSuperBins - both_zero;
+        }
+    }
+}
+
 }  // namespace kpal

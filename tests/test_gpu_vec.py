@@ -194,12 +194,19 @@ def test_matrix_super_tiles(ctx):
     groups, several super-tiles); counts >= 2^31 in some bins (the difference-of-reciprocals kernel of multiset 'prod'
     reports them and the pair-of-counts kernel reruns: int64 path next to the float path) and the same shapes with every
     count below 2^20 (the difference-of-reciprocals kernel's own result: table and computed reciprocals, zero masks);
-    at k = 12 enough bins per thread for the packed byte counters of the term counts to be flushed."""
+    at k = 12 enough bins per thread for the packed byte counters of the term counts to be flushed; and (big = None) every
+    count below 1024: multiset 'sum' on its reciprocal-table kernel up to the last table entries."""
     rs = np.random.RandomState(17)
     for k, P, big in ((6, 9, True), (6, 16, True), (7, 17, True), (6, 33, True), (8, 20, True),
-                      (6, 9, False), (7, 17, False), (6, 33, False), (8, 20, False), (9, 64, False)):
+                      (6, 9, False), (7, 17, False), (6, 33, False), (8, 20, False), (9, 64, False),
+                      (6, 9, None), (7, 17, None), (8, 36, None)):
         profs = [rs.poisson(rs.choice([0.3, 5.0, 90.0]), 4 ** k).astype(np.int64) for _ in range(P)]
-        if big:
+        if big is None:
+            # multiset 'sum' stays on its table kernel (every count below 1024): the largest table entries, equal large counts
+            profs[P // 2][rs.randint(0, 4 ** k, 50)] = 1023 - rs.randint(0, 30, 50)
+            profs[0][5] = profs[1][5] = 1023
+            profs[2][5] = 1022
+        elif big:
             profs[P // 2][rs.randint(0, 4 ** k, 50)] = (1 << 31) + rs.randint(0, 1000, 50)     # beyond the float path
         else:
             # multiset 'prod' stays on the difference-of-reciprocals kernel (every count below 2^20): counts beyond its

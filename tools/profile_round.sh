@@ -57,8 +57,29 @@ python3 "$B" --workload matrix --metric euclidean --steps 5 --warmup 1 > "$OUT/m
 python3 "$B" --workload matrix --metric sum --steps 3 --warmup 1 > "$OUT/matrix_k12_P64_sum_bench.json" 2> "$OUT/matrix_sum.err"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix" -o m -- python3 "$B" --workload matrix --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_prod_under_rocprof.json" 2> "$OUT/stats_matrix.err"
 find "$OUT/stats_matrix" -name '*kernel_stats.csv' -exec cp {} "$OUT/matrix_k12_P64_prod_kernel_stats.csv" \;
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix_s" -o m -- python3 "$B" --workload matrix --metric sum --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_sum_under_rocprof.json" 2> "$OUT/stats_matrix_s.err"
+find "$OUT/stats_matrix_s" -name '*kernel_stats.csv' -exec cp {} "$OUT/matrix_k12_P64_sum_kernel_stats.csv" \;
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_matrix_e" -o m -- python3 "$B" --workload matrix --metric euclidean --steps 5 --warmup 1 --no-cpu > "$OUT/matrix_k12_P64_euclidean_under_rocprof.json" 2> "$OUT/stats_matrix_e.err"
 find "$OUT/stats_matrix_e" -name '*kernel_stats.csv' -exec cp {} "$OUT/matrix_k12_P64_euclidean_kernel_stats.csv" \;
+# ---- config 5 counters: where the staged loads of the matrix kernel come from (HBM bytes; L2 requests / hits / misses)
+M5="--workload matrix --steps 2 --warmup 1 --no-cpu"
+cd /tmp
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_fetch_matrix.err"
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_write_matrix.err"
+python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_matrix" "$OUT/pmc_write_matrix" 0 \
+  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around python3 bench.py $M5 (64 profiles, k = 12, multiset prod); gfx950 correction: FETCH_SIZE x2" matrix_rdiff > "$OUT/pmc_hbm_traffic_matrix.json"
+rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d "$OUT/pmc_l2_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_l2_matrix.err"
+python3 - "$OUT/pmc_l2_matrix" > "$OUT/pmc_l2_matrix.json" <<'PY'
+import collections, csv, json, os, sys
+per = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+for d, _, files in os.walk(sys.argv[1]):
+    for f in files:
+        if f.endswith('counter_collection.csv'):
+            for row in csv.DictReader(open(os.path.join(d, f))):
+                name = row['Kernel_Name'].split('(')[0].replace('void ', '')
+                per[name][row['Counter_Name']] += float(row['Counter_Value']); disp[name].add(row['Dispatch_Id'])
+json.dump({n: dict({k: v / len(disp[n]) for k, v in c.items()}, dispatches=len(disp[n])) for n, c in per.items() if 'matrix' in n}, sys.stdout, indent=1)
+PY
 # ---- skewed inputs
 cd "$ROOT"
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
