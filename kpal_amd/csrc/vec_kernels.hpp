@@ -808,36 +808,44 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         for (int b = 0; b < TILE; ++b) s[a][b] = 0.0;
     uint32_t both_zero = 0;                            // pair (row threadIdx.x >> 4, column threadIdx.x & 15) of the super-tile
     bool saw_big = false;
-    // loader: value q of thread t is bin (t & 63) of staged row 4 q + (t >> 6): a wave reads one 512-byte run.  The row
-    // addresses are wave-uniform (scalar registers; a load is saddr + lane * 8).
-    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lcol = threadIdx.x & 63;
-    const int64_t *src[8];
+    // loader: values 2 q', 2 q' + 1 of thread t are the bins 2 (t & 31), 2 (t & 31) + 1 of staged row 8 q' + (t >> 5): a wave reads
+    // two 512-byte runs with 16-byte loads (as 8-byte loads the 43 GB of staged reads moved at 0.6 of the rate: MI355X_MICROARCH.md).
+    // The row addresses of a wave's two halves are scalar; a lane selects its half's.
+    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lhalf = (threadIdx.x >> 5) & 1, lcol = threadIdx.x & 31;
+    const int64_t *src[4][2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = 4 * q + lrow;                    // 0..15 rows of the super-tile, 16..31 its columns
-        const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
-        src[q] = prof + (uint64_t)min(profile, P - 1) * n;   // (uniform)
-    }
-    __syncthreads();                                   // the table
-    auto put = [&](int buf, int q, int64_t v) {
-        const int row = 4 * q + lrow;
-        double r;
-        if (__all((unsigned long long)v < (unsigned long long)kRdiffTable)) {   // wave-uniform
-            r = rtable[(uint32_t)v];
-        } else {
-            saw_big |= (unsigned long long)v >= (1ull << 20);
-            r = (unsigned long long)v < (unsigned long long)kRdiffTable ? rtable[(uint32_t)v & (kRdiffTable - 1)]
-                                                                         : rcp_counts((double)(uint32_t)v + 1.0);
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 8 * q + 2 * lrow + h;            // 0..15 rows of the super-tile, 16..31 its columns
+            const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
+            src[q][h] = prof + (uint64_t)min(profile, P - 1) * n;   // (uniform)
         }
-        rstage[buf][row][lcol] = r;
-        const unsigned long long z = __builtin_amdgcn_ballot_w64(v == 0);
-        if (lcol == 0) zmask[buf][row] = z;
+    __syncthreads();                                   // the table
+    auto recip = [&](int64_t v, bool all_small) -> double {
+        if (all_small) return rtable[(uint32_t)v];
+        saw_big |= (unsigned long long)v >= (1ull << 20);
+        return (unsigned long long)v < (unsigned long long)kRdiffTable ? rtable[(uint32_t)v & (kRdiffTable - 1)] : rcp_counts((double)(uint32_t)v + 1.0);
+    };
+    auto put = [&](int buf, int q, const longlong2 &v) {
+        const int row = 8 * q + 2 * lrow + lhalf;
+        const bool all_small = __all((unsigned long long)v.x < (unsigned long long)kRdiffTable && (unsigned long long)v.y < (unsigned long long)kRdiffTable);   // wave-uniform
+        double2 r;
+        r.x = recip(v.x, all_small);
+        r.y = recip(v.y, all_small);
+        *reinterpret_cast<double2 *>(&rstage[buf][row][2 * lcol]) = r;
+        // zero masks: bit c = bin 2c, bit 32 + c = bin 2c + 1 (the same permutation of the bins in every row)
+        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(v.x == 0), z1 = __builtin_amdgcn_ballot_w64(v.y == 0);
+        if (lcol == 0) zmask[buf][row] = lhalf ? ((z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull)) : ((z0 & 0xFFFFFFFFull) | (z1 << 32));
     };
     const uint64_t chunks = n / kSuperBins;
-    auto request = [&](int64_t (&dst)[8], uint64_t chunk) {
+    auto request = [&](longlong2 (&dst)[4], uint64_t chunk) {
         if (chunk < chunks) {                          // block-uniform
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = src[q][chunk * kSuperBins + lcol];
+            for (int q = 0; q < 4; ++q) {
+                const int64_t *p = lhalf ? src[q][1] : src[q][0];
+                dst[q] = *reinterpret_cast<const longlong2 *>(p + chunk * kSuperBins + 2 * lcol);
+            }
         }
     };
     auto compute = [&](int cur) {
@@ -866,13 +874,13 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     // the values of the next stage are requested before this stage's arithmetic and staged after it.  (Requesting TWO stages
     // ahead -- a stage's arithmetic takes ~0.3 us, a load 1-2 us -- needs 16 more registers than four waves per SIMD leave:
     // the compiler parked the prefetched values in scratch memory and the kernel was slower.)
-    int64_t next[8];
+    longlong2 next[4];
     uint64_t c = group;
     uint64_t stages = 0;
     request(next, c);
     if (c < chunks) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) put(0, q, next[q]);
+        for (int q = 0; q < 4; ++q) put(0, q, next[q]);
     }
     __syncthreads();
     int cur = 0;
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
         compute(cur);
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) put(cur ^ 1, q, next[q]);
+            for (int q = 0; q < 4; ++q) put(cur ^ 1, q, next[q]);
         }
         __syncthreads();
         cur ^= 1;
@@ -947,30 +955,38 @@ __global__ __launch_bounds__(256) void matrix_rsum_kernel(const int64_t *__restr
         for (int b = 0; b < TILE; ++b) s[a][b] = 0.0;
     uint32_t both_zero = 0;
     bool saw_big = false;
-    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lcol = threadIdx.x & 63;
-    const int64_t *src[8];
+    // (loader: see matrix_rdiff_kernel -- 16-byte loads, two rows per wave)
+    const int lrow = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lhalf = (threadIdx.x >> 5) & 1, lcol = threadIdx.x & 31;
+    const int64_t *src[4][2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int r = 4 * q + lrow;
-        const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
-        src[q] = prof + (uint64_t)min(profile, P - 1) * n;
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 8 * q + 2 * lrow + h;
+            const int profile = r < 16 ? si * 16 + r : sj * 16 + (r - 16);
+            src[q][h] = prof + (uint64_t)min(profile, P - 1) * n;
+        }
     __syncthreads();
-    auto put = [&](int buf, uint32_t stage_no, int q, int64_t v) {
-        const int row = 4 * q + lrow;
-        saw_big |= (unsigned long long)v >= (unsigned long long)(kRsumTable / 2);   // (x + y must stay inside the table)
-        cstage[buf][row][lcol] = (uint32_t)v & (uint32_t)(kRsumTable / 2 - 1);   // (masked: a larger count only ever costs a rerun, never an out-of-range read)
-        const unsigned long long z = __builtin_amdgcn_ballot_w64(v == 0);
-        if (lcol == 0) zmask[buf][row] = z;
+    auto put = [&](int buf, int q, const longlong2 &v) {
+        const int row = 8 * q + 2 * lrow + lhalf;
+        saw_big |= (unsigned long long)v.x >= (unsigned long long)(kRsumTable / 2) || (unsigned long long)v.y >= (unsigned long long)(kRsumTable / 2);   // (x + y must stay inside the table)
+        // (masked: a larger count only ever costs a rerun, never an out-of-range read)
+        *reinterpret_cast<uint2 *>(&cstage[buf][row][2 * lcol]) =
+            make_uint2((uint32_t)v.x & (uint32_t)(kRsumTable / 2 - 1), (uint32_t)v.y & (uint32_t)(kRsumTable / 2 - 1));
+        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(v.x == 0), z1 = __builtin_amdgcn_ballot_w64(v.y == 0);
+        if (lcol == 0) zmask[buf][row] = lhalf ? ((z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull)) : ((z0 & 0xFFFFFFFFull) | (z1 << 32));
     };
     const uint64_t chunks = n / kSuperBins;
-    auto request = [&](int64_t (&dst)[8], uint64_t chunk) {
+    auto request = [&](longlong2 (&dst)[4], uint64_t chunk) {
         if (chunk < chunks) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = src[q][chunk * kSuperBins + lcol];
+            for (int q = 0; q < 4; ++q) {
+                const int64_t *p = lhalf ? src[q][1] : src[q][0];
+                dst[q] = *reinterpret_cast<const longlong2 *>(p + chunk * kSuperBins + 2 * lcol);
+            }
         }
     };
-    auto compute = [&](int cur, uint32_t stage_no) {
+    auto compute = [&](int cur) {
         both_zero += (uint32_t)__popcll(zmask[cur][threadIdx.x >> 4] & zmask[cur][16 + (threadIdx.x & 15)]);
         if (!mine) return;
         // lane l takes the bins 4l .. 4l+3 of every row: one 16-byte LDS read per row
@@ -999,23 +1015,23 @@ __global__ __launch_bounds__(256) void matrix_rsum_kernel(const int64_t *__restr
                 }
             }
     };
-    int64_t next[8];
+    longlong2 next[4];
     uint64_t c = group;
     uint64_t stages = 0;
     request(next, c);
     if (c < chunks) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) put(0, 0u, q, next[q]);
+        for (int q = 0; q < 4; ++q) put(0, q, next[q]);
     }
     __syncthreads();
     int cur = 0;
     for (; c < chunks; c += ngroups, ++stages) {
         const bool more = c + ngroups < chunks;
         request(next, c + ngroups);
-        compute(cur, (uint32_t)stages);
+        compute(cur);
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) put(cur ^ 1, (uint32_t)stages + 1u, q, next[q]);
+            for (int q = 0; q < 4; ++q) put(cur ^ 1, q, next[q]);
         }
         __syncthreads();
         cur ^= 1;
