@@ -387,3 +387,27 @@ def test_command_line_surface_without_gpu(tmp_path, monkeypatch):
         files.ProfileFileType('r')('counted.k8')
     with pytest.raises(Exception, match='file exists'):
         files.FileType('w')('a_1.fa')
+
+
+def test_bench_traffic_comes_from_the_committed_profiles():
+    """bench.py reports roofline.traffic from profiles/r3/pmc_hbm_traffic*.json only while those were taken on the kernel sources
+    it runs (src_sha); bytes that follow the input are scaled by the input, bytes that follow the 4^k table are not, and every
+    kernel of the step -- the balancing finalisation included -- is found in the profile."""
+    import bench
+    nbytes = 100_000_000 * 151
+    here = bench.source_sha()
+    for k, names in ((12, ('quad_sample', 'quad_scatter', 'quad_hist', 'balance_tiled')),
+                     (15, ('quad_sample', 'quad_scatter', 'quad2_scatter', 'quad_hist', 'quad2_finalize_balanced', 'quad2_apply_list'))):
+        kernels = {n: (1.0, 1) for n in names}
+        info = bench.pmc_traffic(kernels, 'quad_scatter', k, nbytes)
+        if info['traffic_profile_src_sha'] != here:
+            assert info['traffic'] is None and info['traffic_step'] is None      # a stale profile is never quoted
+            continue
+        per = info['traffic_by_kernel_per_step']
+        assert set(per) == set(names), (k, sorted(per))
+        assert 1.9 * nbytes < info['traffic'] < 2.2 * nbytes                     # the scatter reads the input once and writes as much
+        table = 8 * 4 ** k
+        if k == 15:
+            assert 1.4 * table < per['quad2_finalize_balanced'] < 1.6 * table    # forms read (4 B per entry), table written: not scaled
+        assert info['traffic_step'] == pytest.approx(sum(per.values()))
+        assert 2.5 * nbytes < info['traffic_step'] < 7 * nbytes
