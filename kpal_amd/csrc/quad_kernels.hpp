@@ -344,9 +344,17 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
             for (int q = 0; q < N; ++q)
                 if ((riders >> q) & 1u) {
                     uint32_t *p = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(rows) + row[q] * RB + (off[q] - RB) * 4u);
+#if defined(KPAL_AB_RIDER_OR)    // A/B: three read-modify-writes (the round-2 form; same-box 7.45 against 7.28 ms for the scatter)
                     atomicOr(p, item[q] << 24);
                     atomicOr(p + 1, (item[q] << 16) & 0xFF000000u);
                     atomicOr(p + 2, (item[q] << 8) & 0xFF000000u);
+#else
+                    // byte stores: nobody else writes these bytes, and an LDS read-modify-write of a dword's low bytes (the OR of
+                    // its own item, above) is indivisible against them
+                    reinterpret_cast<unsigned char *>(p)[3] = (unsigned char)item[q];
+                    reinterpret_cast<unsigned char *>(p)[7] = (unsigned char)(item[q] >> 8);
+                    reinterpret_cast<unsigned char *>(p)[11] = (unsigned char)(item[q] >> 16);
+#endif
                 }
         }
     }
@@ -384,20 +392,24 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
         // one LDS atomic per call reserves the list entries of all the wave's overflowed items (a lane finds its own
         // with ballots and lane counts)
         uint32_t base = 0;
+        unsigned long long bq[N];                    // (scalar registers: who overflowed at position q)
+#pragma unroll
+        for (int q = 0; q < N; ++q) bq[q] = __builtin_amdgcn_ballot_w64((over >> q) & 1u);
         if constexpr (!direct) {
             uint32_t total = 0;
 #pragma unroll
-            for (int q = 0; q < N; ++q) total += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((over >> q) & 1u));
+            for (int q = 0; q < N; ++q) total += (uint32_t)__popcll(bq[q]);
             uint32_t got = 0;
             if ((threadIdx.x & 63u) == 0u) got = atomicAdd(spill_n, total);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
         }
 #pragma unroll
         for (int q = 0; q < N; ++q) {
+            if (bq[q] == 0ull) continue;             // wave-uniform: at the usual fill a position overflows in one wave-step of three
             const bool ov = (over >> q) & 1u;
             bool listed = false;
             if constexpr (!direct) {
-                const unsigned long long b = __builtin_amdgcn_ballot_w64(ov);
+                const unsigned long long b = bq[q];
                 const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
                 listed = ov && at < cap;
                 if (listed) spill[at] = QuadSpill{row[q], item[q]};
