@@ -42,6 +42,7 @@ namespace kpal {
 
 constexpr int kQuadSpillCap = 2048;           // spilled items a round may carry over (16 KiB of LDS)
 constexpr int kQuadRowWords = 32768;          // 128 KiB of rows
+constexpr int kQuadDummyWords = 4;            // words behind the rows that lanes without a slot write to
 
 template <int K>
 struct QuadCfg {
@@ -392,6 +393,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
         // one LDS atomic per call reserves the list entries of all the wave's overflowed items (a lane finds its own
         // with ballots and lane counts)
         uint32_t base = 0;
+        bool list_full = true;                       // (wave-uniform) something may be left to count directly
         unsigned long long bq[N];                    // (scalar registers: who overflowed at position q)
 #pragma unroll
         for (int q = 0; q < N; ++q) bq[q] = __builtin_amdgcn_ballot_w64((over >> q) & 1u);
@@ -402,6 +404,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
             uint32_t got = 0;
             if ((threadIdx.x & 63u) == 0u) got = atomicAdd(spill_n, total);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            list_full = base + total > cap;          // (one scalar test instead of a ballot per position below)
         }
 #pragma unroll
         for (int q = 0; q < N; ++q) {
@@ -416,7 +419,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
                 base += (uint32_t)__popcll(b);
             }
             // carried items that still do not fit, and whatever the list cannot hold: counted now
-            if (__any(ov && !listed)) quad_items_direct<K, LEVEL, SINK>(ov && !listed, row[q], item[q], table, hot, coarse);
+            if (list_full && __any(ov && !listed)) quad_items_direct<K, LEVEL, SINK>(ov && !listed, row[q], item[q], table, hot, coarse);
         }
     }
     return over;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     constexpr int CARRY = kQuadSpillCap / THREADS;      // carried items per thread
     constexpr uint32_t CAP = CARRY * THREADS;           // spill list entries in use
     static_assert((WAVES == 8 || WAVES == 16) && STEPS % DEPTH == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + kQuadDummyWords];
     __shared__ __attribute__((aligned(16))) uint32_t pos[NB];   // BYTES in use per row
     __shared__ QuadSpill spill[kQuadSpillCap];
     __shared__ uint32_t spill_cnt[2];           // appended-entries counter of even / odd tiles: the one of tile j is read by every
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
+    for (int i = threadIdx.x; i < kQuadRowWords + kQuadDummyWords; i += THREADS) rows[i] = 0;
     for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
     if (threadIdx.x == 0) {
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     static_assert(WAVES == 8 || WAVES == 16, "tile shape");
     constexpr int CARRY = kQuadSpillCap / THREADS;
     constexpr uint32_t CAP = CARRY * THREADS;
-    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[kQuadRowWords + kQuadDummyWords];
     __shared__ __attribute__((aligned(16))) uint32_t pos[NB];   // BYTES in use per row
     __shared__ QuadSpill spill[kQuadSpillCap];
     __shared__ uint32_t spill_cnt[2];
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     const TableSinkRef table = {&sink_lds};
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t coarse = blockIdx.y;
-    for (int i = threadIdx.x; i < kQuadRowWords + 4; i += THREADS) rows[i] = 0;
+    for (int i = threadIdx.x; i < kQuadRowWords + kQuadDummyWords; i += THREADS) rows[i] = 0;
     for (int i = threadIdx.x; i < NB; i += THREADS) pos[i] = 0;
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) hot[i] = QuadHot{0ull, 0u, 0u};
     for (uint32_t i = threadIdx.x; i < 256u; i += THREADS) nr1[i] = i < G1 ? nrounds1[i] : 0u;
