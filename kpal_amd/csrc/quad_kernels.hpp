@@ -1083,14 +1083,22 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             }
         }
     };
-    auto add4 = [&](const uint4 q) {
+    // low-complexity sequence repeats whole items across the lanes of a load: tested on the FIRST of the four vectors a lane
+    // counts per iteration (runs of a repeated item span many records; per vector the test cost the k = 12 histogram 3 %)
+    auto repeats = [&](const uint4 q) -> bool {
+#if defined(KPAL_AB_HIST_NO_SKEWCHECK)   // A/B timing: what the test for repeated items costs
+        return false;
+#endif
+        const uint32_t it = C::kItem3 ? (q.x & 0xFFFFFFu) : q.x;
+        const uint32_t first = __builtin_amdgcn_readfirstlane(it);
+        return first != 0u && __popcll(__builtin_amdgcn_ballot_w64(it == first)) >= 8;   // wave-uniform
+    };
+    auto add4 = [&](const uint4 q, const bool skew) {
         if constexpr (C::kItem3) {   // four 3-byte items + a fifth in the top bytes
             // (the bit-fields add_item reads lie below bit 23: the rider's byte above an item does not matter; an item is
             // null iff its mask nibble is zero)
             const uint32_t i0 = q.x, i1 = q.y, i2 = q.z, i3 = q.w;
             const uint32_t i4 = __builtin_amdgcn_perm(q.z, __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0703u), 0x0c070100u);   // the top bytes of x, y, z
-            const uint32_t first = __builtin_amdgcn_readfirstlane(i0) & 0xFFFFFFu;
-            const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64((i0 & 0xFFFFFFu) == first)) >= 8;   // wave-uniform
             if (__builtin_expect(skew, 0)) {
                 if (i0 & 15u) add_item(i0, std::true_type{});
                 if (i1 & 15u) add_item(i1, std::true_type{});
@@ -1108,9 +1116,6 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             }
             return;
         }
-        // low-complexity sequence repeats whole items across the lanes of a load
-        const uint32_t first = __builtin_amdgcn_readfirstlane(q.x);
-        const bool skew = first != 0u && __popcll(__builtin_amdgcn_ballot_w64(q.x == first)) >= 8;   // wave-uniform
         if (__builtin_expect(skew, 0)) {
             if (q.x) add_item(q.x, std::true_type{});
             if (q.y) add_item(q.y, std::true_type{});
@@ -1167,10 +1172,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #if defined(KPAL_AB_HIST_NO_ADD)     // A/B timing builds (wrong counts): the record stream alone
             asm volatile("" ::"v"(q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w ^ q2.x ^ q2.y ^ q2.z ^ q2.w ^ q3.x ^ q3.y ^ q3.z ^ q3.w));
 #else
-            add4(q0);
-            add4(q1);
-            add4(q2);
-            add4(q3);
+            const bool skew = repeats(q0);
+            add4(q0, skew);
+            add4(q1, skew);
+            add4(q2, skew);
+            add4(q3, skew);
 #endif
             q0 = n0;
             q1 = n1;
