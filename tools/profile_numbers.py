@@ -51,13 +51,14 @@ for f in ('pmc_lds_quad.json', 'pmc_lds_quad_k15.json'):
   except OSError:
     continue
   print(f)
+  kib = (6.04e9 if 'k15' in f else 3.02e9) / 1024.0     # input per launch of the counter passes (tools/profile_round.sh: 40 M / 20 M reads)
   for k, v in c['kernels'].items():
     if 'quad' in k and v.get('SQ_WAVE_CYCLES') and v.get('SQ_LDS_IDX_ACTIVE'):
         cyc = v['SQ_BUSY_CYCLES'] / 32
         print('    %-44s VALU/KiB %.0f  LDS/KiB %.1f  VALU issue %.1f %% of wave cycles  waiting %.0f %%  LDS busy %.0f %% (%.0f %% conflicts)' % (
-            k[:44], v['SQ_INSTS_VALU'] / 2.95e6, v['SQ_INSTS_LDS'] / 2.95e6, 100 * v['SQ_ACTIVE_INST_VALU'] / v['SQ_WAVE_CYCLES'],
+            k[:44], v['SQ_INSTS_VALU'] / kib, v['SQ_INSTS_LDS'] / kib, 100 * v['SQ_ACTIVE_INST_VALU'] / v['SQ_WAVE_CYCLES'],
             100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES'], 100 * v['SQ_LDS_IDX_ACTIVE'] / 256 / cyc, 100 * v['SQ_LDS_BANK_CONFLICT'] / v['SQ_LDS_IDX_ACTIVE']))
-for f in ('bench_k12_kernel_stats.csv', 'bench_k15_kernel_stats.csv', 'matrix_k12_P64_prod_kernel_stats.csv', 'matrix_k12_P64_euclidean_kernel_stats.csv'):
+for f in ('bench_k12_kernel_stats.csv', 'bench_k15_kernel_stats.csv', 'matrix_k12_P64_prod_kernel_stats.csv', 'matrix_k12_P64_sum_kernel_stats.csv', 'matrix_k12_P64_euclidean_kernel_stats.csv'):
     if not os.path.exists(os.path.join(d, f)):
         continue
     print(f)
