@@ -180,6 +180,9 @@ def cpu_baseline(k, read_len, budget_reads):
     return {
         'value': bases / t1 / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
         'sample': '%d synthetic %d bp reads, k=%d, oracle/kpal_oracle.c (1 thread: %.2f s)' % (budget_reads, read_len, k, t1),
+        # the same figures as scalars (the driver's record keeps scalars only): all host cores, and the reference's own speed class
+        'all_cores_value': bases / tn / 1e9, 'all_cores_threads': best_threads, 'host_cores': cores,
+        'python_loop_value': 1.5e6 / tp / 1e9, 'python_loop_sample': 'BASELINE config 1 (10000 reads, k=9), pure-Python restatement of klib.py:149-170, 1 core',
         'all_cores': {'value': bases / tn / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn,
                       'per_thread_efficiency': (bases / tn) / (bases / t1) / best_threads,
                       'seconds_by_threads': tried,
@@ -454,7 +457,18 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# launcher + ranks
+# launcher, rank supervisors, workers
+#
+#   python bench.py --gpus N                   plain command: launch_ranks() starts torch.distributed.run (never touches a GPU)
+#     -> torch.distributed.run -> N ranks     each rank is a SUPERVISOR (supervise_rank): it never touches a GPU either, starts
+#       -> bench.py --worker --attempt 1      the worker that does the GPU work, and watches it: no start / no end within the
+#       -> bench.py --worker --attempt 2      limits, a non-zero exit, or a peer's failure flag -> the worker's process group is
+#                                              killed and a FRESH worker runs the conservative mode (torch.distributed reduce,
+#                                              serial).  The driver starts the ranks through torch.distributed.run itself: the
+#                                              same supervisors run there, so a hang of the first multi-GPU run still ends in a line.
+# Supervisors of one job share a directory of flag files (KPAL_BENCH_RUN_DIR, or one named after MASTER_PORT and the common
+# parent process): a<attempt>.started.<rank>, a<attempt>.failed.<rank>, a<attempt>.line (rank 0's JSON line as soon as the
+# headline mode is measured and verified: it survives a hang in a later mode), a<attempt>.done.
 # ----------------------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -464,40 +478,181 @@ def free_port():
     return port
 
 
+def kill_group(proc):
+    """End the process group a child was started in (start_new_session=True); never a pattern kill."""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        if proc.poll() is not None:
+            return
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            return
+        try:
+            proc.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            pass
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` (N > 1) as a plain command: start the N ranks as a fresh child process group BEFORE this
-    process touches the GPU (it never does), relay rank 0's JSON line, exit with the child's status."""
+    process touches the GPU (it never does), relay rank 0's JSON line, exit with the child's status.  A wall-clock limit
+    (KPAL_BENCH_LAUNCH_TIMEOUT, default 2400 s: both attempts of the rank supervisors fit) ends a job that never returns."""
+    import tempfile
+    run_dir = tempfile.mkdtemp(prefix='kpal_bench_')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
+    env = dict(os.environ, KPAL_BENCH_RUN_DIR=run_dir)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL across processes)
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
-    last = None
-    for raw in p.stdout:
-        text = raw.decode('utf-8', 'replace').rstrip('\n')
-        try:
-            obj = json.loads(text)
-            if isinstance(obj, dict) and 'metric' in obj:
-                last = text
-                continue
-        except ValueError:
-            pass
-        print(text, file=sys.stderr, flush=True)
-    rc = p.wait()
-    if last is not None:
-        print(last, flush=True)
-    sys.exit(rc if rc else (0 if last is not None else 1))
+    limit = float(os.environ.get('KPAL_BENCH_LAUNCH_TIMEOUT', '2400'))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    last = [None]
+
+    def relay():
+        for raw in p.stdout:
+            text = raw.decode('utf-8', 'replace').rstrip('\n')
+            try:
+                obj = json.loads(text)
+                if isinstance(obj, dict) and 'metric' in obj:
+                    last[0] = text
+                    continue
+            except ValueError:
+                pass
+            print(text, file=sys.stderr, flush=True)
+
+    import threading
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    try:
+        rc = p.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print('bench.py: the ranks did not finish within %.0f s: killing them' % limit, file=sys.stderr, flush=True)
+        kill_group(p)
+        rc = 124
+    reader.join(timeout=10)
+    import shutil
+    shutil.rmtree(run_dir, ignore_errors=True)
+    if last[0] is not None:
+        print(last[0], flush=True)
+    sys.exit(rc if rc else (0 if last[0] is not None else 1))
+
+
+def bench_run_dir():
+    """Directory of the flag files the supervisors (and workers) of one job share."""
+    import tempfile
+    d = os.environ.get('KPAL_BENCH_RUN_DIR')
+    if not d:   # started by somebody else's torch.distributed.run (the driver): all ranks have the same parent and port
+        d = os.path.join(tempfile.gettempdir(), 'kpal_bench_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid()))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def flag_path(attempt, what, rank=None):
+    return os.path.join(bench_run_dir(), 'a%d.%s%s' % (attempt, what, '' if rank is None else '.%d' % rank))
+
+
+def set_flag(attempt, what, rank=None, text=''):
+    path = flag_path(attempt, what, rank)
+    tmp = '%s.tmp%d' % (path, os.getpid())
+    with open(tmp, 'w') as fh:
+        fh.write(text)
+    os.replace(tmp, path)      # (atomic: a reader sees the whole text or no file)
+
+
+def supervise_rank(args):
+    """One rank of an N > 1 job, under torch.distributed.run: starts the worker process and watches it (see the head of this
+    section).  Never imports torch, never touches the GPU.  Exit status: 0 iff a verified line was printed."""
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    run_dir = bench_run_dir()
+    startup_limit = float(os.environ.get('KPAL_BENCH_STARTUP_TIMEOUT', '420'))   # a cold `import torch` takes 1-2 min on a fresh box
+    run_limit = float(os.environ.get('KPAL_BENCH_RUN_TIMEOUT', '300'))           # generate + warm-up + every mode + verification: well under a minute
+    reason = None
+    for attempt in (1, 2):
+        argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ['--worker', '--attempt', str(attempt)]
+        if attempt == 2:
+            argv += ['--reduce-via', 'torch', '--serial-reduce', '--fallback-reason', reason or 'attempt 1 failed']
+        child = subprocess.Popen(argv, env=dict(os.environ, KPAL_BENCH_RUN_DIR=run_dir), start_new_session=True)
+        t0 = time.time()
+        started_at, why = None, None
+        while True:
+            rc = child.poll()
+            if rc is not None:
+                why = None if rc == 0 else 'the worker of rank %d exited with status %d' % (rank, rc)
+                break
+            now = time.time()
+            if started_at is None and os.path.exists(flag_path(attempt, 'started', rank)):
+                started_at = now
+            peers = [r for r in range(world) if r != rank and os.path.exists(flag_path(attempt, 'failed', r))]
+            if peers:
+                try:
+                    with open(flag_path(attempt, 'failed', peers[0])) as fh:
+                        told = fh.read().strip()
+                except OSError:
+                    told = ''
+                why = 'rank %d gave up on attempt %d (%s)' % (peers[0], attempt, told or 'no reason given')
+            elif started_at is None and now - t0 > startup_limit:
+                why = 'the worker of rank %d did not start within %.0f s' % (rank, startup_limit)
+            elif started_at is not None and now - started_at > run_limit:
+                why = 'the worker of rank %d did not finish within %.0f s' % (rank, run_limit)
+            if why:
+                break
+            time.sleep(0.2)
+        if why is None:
+            return 0
+        # this attempt is over for every rank: say so, end the worker, keep what was measured
+        if not os.path.exists(flag_path(attempt, 'failed', rank)):
+            set_flag(attempt, 'failed', rank, why)
+        kill_group(child)
+        print('bench.py supervisor (rank %d, attempt %d): %s' % (rank, attempt, why), file=sys.stderr, flush=True)
+        if os.path.exists(flag_path(attempt, 'done')):
+            return 0                                   # rank 0 had printed its line: only the teardown failed
+        line_file = flag_path(attempt, 'line')
+        if os.path.exists(line_file):
+            if rank == 0:                              # the headline mode was measured and verified before the failure
+                with open(line_file) as fh:
+                    line = json.loads(fh.read())
+                line['later_modes_failed'] = why
+                print(json.dumps(line), flush=True)
+                set_flag(attempt, 'done')
+            return 0
+        reason = reason or why
+    return 1
+
+
+def join_process_group(backend, rank, world, attempt, device_id=None):
+    """The workers' process group.  Under torch.distributed.run the agent's store is used through a per-attempt prefix (keys of
+    a killed first attempt -- its ncclUniqueId -- must not be read by the second); without an agent rank 0's worker hosts the
+    store, on MASTER_PORT + attempt - 1."""
+    import datetime
+    import torch.distributed as td
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ['MASTER_PORT'])
+    timeout = datetime.timedelta(minutes=15)
+    if os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True':
+        store = td.PrefixStore('kpal_bench/a%d' % attempt, td.TCPStore(addr, port, world, False, timeout))
+    else:
+        store = td.TCPStore(addr, port + attempt - 1, world, rank == 0, timeout)
+    kw = {'device_id': device_id} if device_id is not None else {}
+    td.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=timeout, **kw)
 
 
 def stub_rank(args):
-    """--stub: the multi-process plumbing alone, on CPU (gloo) and WITHOUT any counting -- rendezvous, shard arithmetic, one
-    reduce(SUM) of int64 tables to rank 0, max-over-ranks timing, rank 0's JSON line.  Exists so that the launcher path of
-    `python bench.py --gpus N` can be tested where there is no GPU; `value` is null."""
+    """--stub: the multi-process plumbing alone, on CPU (gloo) and WITHOUT any counting -- supervisor, rendezvous, shard
+    arithmetic, one reduce(SUM) of int64 tables to rank 0 per step, max-over-ranks timing, the per-bin comparison of the merged
+    table with the single-stream one, rank 0's JSON line.  Exists so that the launcher / supervisor path of `python bench.py
+    --gpus N` can be tested where there is no GPU; `value` is null.  --stub-hang-attempt A: every worker of attempt A stops
+    responding after it has started; --stub-fail-rank R: rank R's worker of attempt 1 dies before the rendezvous."""
     import torch
     import torch.distributed as td
     from kpal_amd import dist as kdist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    td.init_process_group('gloo', rank=rank, world_size=world)
+    if args.worker:
+        set_flag(args.attempt, 'started', rank)
+    if args.attempt == 1 and args.stub_fail_rank == rank:
+        sys.exit(3)
+    if args.stub_hang_attempt == args.attempt:
+        time.sleep(3600)
+    join_process_group('gloo', rank, world, args.attempt)
     total = 1000 * world + 7
     first, n = kdist.shard_range(total, rank, world)
     table = torch.zeros(4 ** 4, dtype=torch.int64)
@@ -514,10 +669,216 @@ def stub_rank(args):
     if rank == 0:
         want = torch.zeros_like(table)
         want.index_add_(0, torch.arange(total) % table.numel(), torch.ones(total, dtype=torch.int64))
-        print(json.dumps({'metric': 'stub (plumbing only, no GPU work)', 'value': None, 'unit': 'Gbases/s', 'n_gpus': world, 'rccl_ranks': td.get_world_size(),
-                          'backend': 'gloo', 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(el.item()) / max(args.steps, 1) * 1e3,
-                          'checksum_ok': bool(torch.equal(t, want)), 'scaling': 'weak', 'data': 'synthetic'}), flush=True)
+        same = bool(torch.equal(t, want))
+        line = {'metric': 'stub (plumbing only, no GPU work)', 'value': None, 'unit': 'Gbases/s', 'n_gpus': world, 'rccl_ranks': td.get_world_size(),
+                'backend': 'gloo', 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(el.item()) / max(args.steps, 1) * 1e3,
+                'checksum_ok': same, 'merged_equals_single_stream': same, 'attempt': args.attempt, 'scaling': 'weak', 'data': 'synthetic'}
+        if args.fallback_reason:
+            line['fallback_reason'] = args.fallback_reason
+        print(json.dumps(line), flush=True)
+        if args.worker:
+            set_flag(args.attempt, 'done')
+    td.barrier()
     td.destroy_process_group()
+
+
+def multi_gpu_worker(args):
+    """One worker of an N > 1 job (BASELINE config 3): this rank's shard resident in HBM; per step zero + count + ONE reduce of
+    the 4^k tables to rank 0 + balance there.  Up to three reduce modes are measured in one invocation, each with its own
+    warm-up and EXACTLY --steps timed steps between barriers, max over the ranks: the in-library RCCL reduce pipelined with
+    the next count (the design default), the same serially, and torch.distributed's reduce serially.  After each mode rank 0
+    compares the merged + balanced table of its last step BIN FOR BIN with the single-stream count of all shards (recounted
+    on rank 0 into one table).  The headline is the first mode, in that order, whose table is right; the others are `extra`."""
+    import numpy as np
+    import torch
+    import torch.distributed as td
+    from kpal_amd import _native, dist as kdist
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU (no CPU fallback for the hot path)')
+    torch.cuda.set_device(local_rank)
+    ctx = _native.Context(local_rank)
+    if args.worker:
+        set_flag(args.attempt, 'started', rank)
+        join_process_group('nccl', rank, world, args.attempt, device_id=torch.device('cuda', local_rank))
+    else:   # a rank started without the supervisor (KPAL_BENCH_NO_SUPERVISOR=1)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    k, L = args.k, args.read_len
+    seed = 3                                            # SURVEY.md 8d config 3
+    if args.strong:
+        shards = [kdist.shard_range(args.reads, r, world) for r in range(world)]   # fixed total, contiguous shards
+    else:
+        shards = [(r * args.reads, args.reads) for r in range(world)]             # shard s = reads [s*R, (s+1)*R)
+    first_read, n_reads = shards[rank]
+    total_reads = sum(n for _, n in shards)
+    nbytes = n_reads * (L + 1)
+    dev_buf = ctx.alloc(max(n for _, n in shards) * (L + 1))
+    ctx.synth_reads_device(seed, first_read, n_reads, L, dev_buf)
+    ctx.sync()
+    ctx.count_begin(k, args.strategy)                   # allocates the table once
+    table_ptr, bins = ctx.count_table()
+
+    # ---- which reduce modes ------------------------------------------------------------------------------------------
+    library_error = None
+    library = args.reduce_via == 'library'
+    if library:
+        # Every rank first proves that it can bind RCCL -- rank 0 by creating the id, the others by loading the library alone
+        # (no id, no bootstrap listener): ncclCommInitRank is a collective, a rank that failed before it would leave the
+        # others waiting.  Any failure -> all ranks take the torch.distributed reducer and the line says so.
+        my_id = None
+        try:
+            if rank == 0:
+                my_id = _native.comm_unique_id()
+            else:
+                _native.comm_probe()
+        except Exception as e:
+            library_error = '%s: %s' % (type(e).__name__, e)
+        able = torch.tensor([0 if library_error else 1], dtype=torch.int32, device='cuda')
+        td.all_reduce(able, op=td.ReduceOp.MIN)
+        if int(able.item()) == 0:
+            library = False
+            library_error = library_error or 'another rank could not bind RCCL'
+    if library:
+        # the communicator of the library: rank 0's id reaches the others through the workers' process group
+        ident = torch.zeros(_native.COMM_ID_BYTES, dtype=torch.uint8, device='cuda')
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+        td.broadcast(ident, src=0)
+        torch.cuda.synchronize()
+        ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+    modes = []
+    if library:
+        modes = ['library_serial', 'library_pipelined'] if args.serial_reduce else ['library_pipelined', 'library_serial']
+    modes.append('torch_serial')
+    if args.only_headline_mode:
+        modes = modes[:1]
+
+    def fence():
+        ctx.sync()                                      # the context's streams (incl. a pipelined reduce)
+        torch.cuda.synchronize()
+        td.barrier()
+        torch.cuda.synchronize()
+
+    def measure(mode):
+        reducer = None
+        if mode == 'torch_serial':
+            reducer = kdist.TableReducer(kdist.table_as_tensor(ctx), sync=ctx.sync, balance=lambda t: ctx.balance_device(k, t.data_ptr()),
+                                         mode=args.reduce, overlap=args.overlap_reduce)
+        pipelined = mode == 'library_pipelined'
+
+        def step():
+            ctx.count_begin(k, args.strategy)           # zero the 4^k table
+            ctx.count_feed_device(dev_buf, nbytes)
+            if reducer is None:
+                # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step
+                ctx.comm_reduce_table(0, balance=True, pipelined=pipelined)
+                if not pipelined:
+                    ctx.sync()
+            else:
+                reducer.reduce_step()                   # torch.distributed.reduce(SUM) to rank 0 (+ balance on rank 0)
+                ctx.sync()
+
+        for _ in range(args.warmup):
+            step()
+        if reducer is not None:
+            reducer.drain()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if reducer is not None:
+            reducer.drain()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = ctx.prof_get()
+        ctx.prof_enable(False)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        merged = None
+        if rank == 0:
+            merged = np.empty(bins, dtype=np.int64)
+            ctx.d2h(merged, ctx.comm_merged_table()[0] if reducer is None else reducer.result_ptr())
+        return {'elapsed': float(t.item()), 'prof': {n: v for n, v in prof.items() if v[1] > 0}, 'merged': merged}
+
+    want = [None]
+
+    def single_stream():
+        """Rank 0: every shard counted into ONE table, one after the other, then Profile.balance -- what the merged table
+        must equal ('equals the single-stream count of all reads')."""
+        if want[0] is None:
+            ctx.count_begin(k, args.strategy)
+            for f, n in shards:
+                ctx.synth_reads_device(seed, f, n, L, dev_buf)
+                ctx.count_feed_device(dev_buf, n * (L + 1))
+            ctx.count_balance()
+            want[0] = ctx.count_finish()
+            ctx.synth_reads_device(seed, first_read, n_reads, L, dev_buf)      # this rank's own shard again
+            ctx.sync()
+        return want[0]
+
+    def make_line(mode, results):
+        r = results[mode]
+        steps = max(args.steps, 1)
+        ms = r['elapsed'] / steps * 1e3
+        lib = mode.startswith('library')
+        line = {
+            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': total_reads * L / (r['elapsed'] / steps) / 1e9, 'unit': 'Gbases/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
+            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+RCCL reduce+balance' % (k, n_reads, L),
+                       'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy,
+                       'parallelism': 'reads sharded x%d, 1 ncclReduce(int64 sum) of the 4^k table to rank 0 per step' % world,
+                       'reduce_mode': mode, 'attempt': args.attempt, 'merged_equals_single_stream': r['same']},
+            'checksum_ok': r['sum_ok'], 'merged_equals_single_stream': r['same'], 'rccl_ranks': td.get_world_size(),
+            'reduce_via': 'library' if lib else 'torch', 'pipelined_reduce': mode == 'library_pipelined', 'reduce_mode': mode, 'attempt': args.attempt,
+            'src_sha': source_sha(), 'roofline': count_roofline(r['prof'], k, nbytes, bins, steps, ms, fused_balance=False),
+        }
+        extra = {}
+        for other, o in results.items():
+            key = {'library_pipelined': 'pipelined_reduce', 'library_serial': 'serial_reduce', 'torch_serial': 'torch_reduce'}[other]
+            extra[key] = {'ms_per_step': o['elapsed'] / steps * 1e3, 'value': total_reads * L / (o['elapsed'] / steps) / 1e9,
+                          'merged_equals_single_stream': o['same'], 'checksum_ok': o['sum_ok'],
+                          'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(o['prof'].items())}}
+            line['config'][key + '_ms_per_step'] = extra[key]['ms_per_step']       # (scalars: the driver's record keeps them)
+        line['extra'] = extra
+        if library_error:
+            line['library_rccl_error'] = library_error
+        if args.fallback_reason:
+            line['fallback_reason'] = args.fallback_reason
+            line['config']['fallback_reason'] = args.fallback_reason[:100]
+        return line
+
+    results, headline = {}, None
+    for mode in modes:
+        r = measure(mode)
+        if rank == 0:
+            w = single_stream()
+            r['same'] = bool(np.array_equal(r.pop('merged'), w))
+            r['sum_ok'] = int(w.sum()) == 2 * total_reads * (L - k + 1)
+            results[mode] = r
+            if headline is None and r['same'] and r['sum_ok']:
+                headline = mode
+            if headline is not None and args.worker:
+                set_flag(args.attempt, 'line', text=json.dumps(make_line(headline, results)))
+    ok = True
+    if rank == 0:
+        ok = headline is not None
+        print(json.dumps(make_line(headline or modes[0], results)), flush=True)
+        if args.worker:
+            set_flag(args.attempt, 'done')
+    fence()
+    ctx.free(dev_buf)
+    ctx.close()
+    td.destroy_process_group()
+    if not ok:
+        sys.exit('the merged table differs from the single-stream count')
 
 
 def main():
@@ -532,190 +893,75 @@ def main():
     ap.add_argument('--strategy', default='auto')
     ap.add_argument('--cpu-reads', type=int, default=4_000_000, help='reads in the CPU-baseline sample')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='N=1: skip BASELINE configs 4 / 5 and the end-to-end figure after the headline')
+    ap.add_argument('--no-extra', action='store_true', help='N=1: skip BASELINE configs 4 / 5 and the end-to-end figures after the headline')
     ap.add_argument('--strong', action='store_true',
                     help='strong scaling: --reads is the TOTAL, split over the GPUs (default: weak, --reads per GPU)')
     ap.add_argument('--reduce-via', default='library', choices=['library', 'torch'],
-                    help='N>1: who issues the RCCL reduce -- libkpal_hip.so on its own streams (default), or torch.distributed (kpal_amd.dist.TableReducer)')
+                    help='N>1: who issues the RCCL reduce of the headline -- libkpal_hip.so on its own streams (default; the torch.distributed '
+                         'reduce is measured as well, as `extra`), or torch.distributed only (kpal_amd.dist.TableReducer)')
     ap.add_argument('--serial-reduce', action='store_true',
-                    help='N>1, library: count -> reduce -> balance in ONE stream per step instead of the pipelined default (the reduce + balance of '
-                         'step i run on a copy of the table and a second stream while step i+1 counts)')
-    ap.add_argument('--reduce', default='int64', choices=['int64', 'u32'], help='N>1, --reduce-via torch only: dtype moved by the reduce')
-    ap.add_argument('--overlap-reduce', action='store_true', help='N>1, --reduce-via torch only: reduce on a second buffer while the next step counts')
-    ap.add_argument('--stub', action='store_true', help='plumbing self-test on CPU/gloo, no counting (tests of the launcher)')
+                    help='N>1, library: the headline is count -> reduce -> balance in ONE stream per step instead of the pipelined default (the reduce + '
+                         'balance of step i run on a copy of the table and a second stream while step i+1 counts); the other form is measured as `extra`')
+    ap.add_argument('--only-headline-mode', action='store_true', help='N>1: measure the headline reduce mode only')
+    ap.add_argument('--reduce', default='int64', choices=['int64', 'u32'], help='N>1, torch reduce only: dtype moved by the reduce')
+    ap.add_argument('--overlap-reduce', action='store_true', help='N>1, torch reduce only: reduce on a second buffer while the next step counts')
+    ap.add_argument('--stub', action='store_true', help='plumbing self-test on CPU/gloo, no counting (tests of the launcher and the supervisors)')
+    ap.add_argument('--stub-hang-attempt', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--stub-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)           # set by supervise_rank
+    ap.add_argument('--attempt', type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument('--fallback-reason', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--profiles', type=int, default=64, help='matrix workload: number of profiles')
     ap.add_argument('--profile-reads', type=int, default=2_000_000, help='matrix workload: reads per profile')
     ap.add_argument('--metric', default='prod', choices=['prod', 'sum', 'euclidean'])
     ap.add_argument('--balance', action='store_true')
     args = ap.parse_args()
 
-    # ---- launcher: nothing above or in here imports torch.cuda, the native library or anything else that opens the GPU
+    # ---- launcher and supervisors: nothing above or in here imports torch.cuda, the native library or anything else that opens the GPU
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return launch_ranks(args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1 and not args.worker and os.environ.get('KPAL_BENCH_NO_SUPERVISOR', '') != '1':
+        sys.exit(supervise_rank(args))
     if args.stub:
         return stub_rank(args)
     if args.workload == 'matrix':
         return matrix_workload(args)
-
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     args.gpus = world
-
-    import numpy as np
-    import torch
-    import torch.distributed as td
-    from kpal_amd import _native, dist as kdist
-
-    if not torch.cuda.is_available():
-        sys.exit('bench.py needs a GPU (no CPU fallback for the hot path)')
-    torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        return multi_gpu_worker(args)
 
-    ctx = _native.Context(local_rank)
+    import numpy as np   # noqa: F401
+    from kpal_amd import _native
+
+    if _native.device_count() < 1:
+        sys.exit('bench.py needs a GPU (no CPU fallback for the hot path)')
+    ctx = _native.Context(int(os.environ.get('LOCAL_RANK', '0')))
     k, L = args.k, args.read_len
-    seed = 2 if world == 1 else 3
-    if args.strong:
-        first_read, n_reads = kdist.shard_range(args.reads, rank, world)   # fixed total, contiguous shards
-        total_reads = args.reads
-    else:
-        n_reads = args.reads
-        first_read = rank * n_reads                     # shard s = reads [s*R, (s+1)*R)
-        total_reads = world * n_reads
+    n_reads = args.reads
     nbytes = n_reads * (L + 1)
     dev_buf = ctx.alloc(nbytes)
-    ctx.synth_reads_device(seed, first_read, n_reads, L, dev_buf)
+    ctx.synth_reads_device(2, 0, n_reads, L, dev_buf)     # seed 2
     ctx.sync()
-
-    if world == 1:
-        r = count_measure(ctx, k, dev_buf, nbytes, n_reads, L, args.strategy, args.steps, args.warmup)
-        line = {
-            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': r['value'], 'unit': 'Gbases/s',
-            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
-            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+balance' % (k, n_reads, L),
-                       'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy, 'pipeline': r['plan'],
-                       'parallelism': 'one GPU'},
-            'checksum_ok': r['checksum_ok'], 'rccl_ranks': 1, 'src_sha': source_sha(), 'roofline': r['roofline'],
-        }
-        ok = r['checksum_ok']
-        if not args.no_cpu:
-            line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
-        if not args.no_extra and k == 12 and args.strategy == 'auto':
-            line['extra'] = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
-        print(json.dumps(line), flush=True)
-        ctx.free(dev_buf)
-        ctx.close()
-        if not ok:
-            sys.exit('checksum mismatch')
-        return
-
-    # ------------------------------------------------------------------------------------------------------------------
-    # N > 1: one rank per GPU
-    # ------------------------------------------------------------------------------------------------------------------
-    ctx.count_begin(k, args.strategy)                   # allocates the table once
-    table_ptr, bins = ctx.count_table()
-    reducer = None
-    library = args.reduce_via == 'library'
-    pipelined = library and not args.serial_reduce
-    library_error = None
-    if library:
-        # Every rank first proves that it can bind RCCL (an id of its own, thrown away on ranks > 0): ncclCommInitRank is a
-        # collective, a rank that failed before it would leave the others waiting.  Any failure -> all ranks take the
-        # torch.distributed reducer and the line says so.
-        try:
-            my_id = _native.comm_unique_id()
-        except Exception as e:
-            my_id, library_error = None, '%s: %s' % (type(e).__name__, e)
-        able = torch.tensor([0 if my_id is None else 1], dtype=torch.int32, device='cuda')
-        td.all_reduce(able, op=td.ReduceOp.MIN)
-        if int(able.item()) == 0:
-            library, pipelined = False, False
-            library_error = library_error or 'another rank could not bind RCCL'
-            args.reduce_via = 'torch'
-    if library:
-        # the communicator of the library: rank 0's id reaches the others through the process group torch.distributed.run set up
-        ident = torch.zeros(_native.COMM_ID_BYTES, dtype=torch.uint8, device='cuda')
-        if rank == 0:
-            ident.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
-        td.broadcast(ident, src=0)
-        torch.cuda.synchronize()
-        ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
-    else:
-        reducer = kdist.TableReducer(kdist.table_as_tensor(ctx), sync=ctx.sync,
-                                     balance=lambda t: ctx.balance_device(k, t.data_ptr()),
-                                     mode=args.reduce, overlap=args.overlap_reduce)
-
-    def step():
-        ctx.count_begin(k, args.strategy)               # zero the 4^k table
-        ctx.count_feed_device(dev_buf, nbytes)
-        if library:
-            # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step
-            ctx.comm_reduce_table(0, balance=True, pipelined=pipelined)
-            if not pipelined:
-                ctx.sync()
-        else:
-            reducer.reduce_step()                       # torch.distributed.reduce(SUM) to rank 0 (+ balance on rank 0)
-            ctx.sync()
-
-    def fence():
-        ctx.sync()                                      # the context's streams (incl. a pipelined reduce)
-        torch.cuda.synchronize()
-        td.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    if reducer is not None:
-        reducer.drain()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if reducer is not None:
-        reducer.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.prof_get()
-    ctx.prof_enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    td.all_reduce(t, op=td.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    # sanity: the last step's merged + balanced table has exactly 2 * (#k-mers) counts
-    ok = True
-    if rank == 0:
-        out = np.empty(bins, dtype=np.int64)
-        ctx.d2h(out, ctx.comm_merged_table()[0] if library else reducer.result_ptr())
-        ok = int(out.sum()) == 2 * total_reads * (L - k + 1)
-        steps = max(args.steps, 1)
-        ms_per_step = elapsed / steps * 1e3
-        kern = {n: v for n, v in prof.items() if v[1] > 0}
-        roofline = count_roofline(kern, k, nbytes, bins, steps, ms_per_step, fused_balance=False)
-        line = {
-            'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': total_reads * L / (elapsed / steps) / 1e9, 'unit': 'Gbases/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
-            'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+RCCL reduce+balance' % (k, n_reads, L),
-                       'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy,
-                       'parallelism': 'reads sharded x%d, 1 ncclReduce(int64 sum) of the 4^k table to rank 0 per step, issued by %s%s' % (
-                           world, 'libkpal_hip.so' if library else 'torch.distributed',
-                           ' on a second stream, overlapped with the next count' if pipelined else '')},
-            'checksum_ok': ok, 'rccl_ranks': td.get_world_size(), 'reduce_via': args.reduce_via, 'pipelined_reduce': pipelined,
-            'src_sha': source_sha(), 'roofline': roofline,
-        }
-        if library_error:
-            line['library_rccl_error'] = library_error
-        print(json.dumps(line), flush=True)
-
+    r = count_measure(ctx, k, dev_buf, nbytes, n_reads, L, args.strategy, args.steps, args.warmup)
+    line = {
+        'metric': 'Gbases/s k-mer counted (k=%d, %dbp synthetic)' % (k, L), 'value': r['value'], 'unit': 'Gbases/s',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
+        'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+balance' % (k, n_reads, L),
+                   'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy, 'pipeline': r['plan'],
+                   'parallelism': 'one GPU'},
+        'checksum_ok': r['checksum_ok'], 'rccl_ranks': 1, 'src_sha': source_sha(), 'roofline': r['roofline'],
+    }
+    ok = r['checksum_ok']
+    if not args.no_cpu:
+        line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
+    if not args.no_extra and k == 12 and args.strategy == 'auto':
+        line['extra'] = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
+    print(json.dumps(line), flush=True)
     ctx.free(dev_buf)
     ctx.close()
-    td.destroy_process_group()
-    if rank == 0 and not ok:
+    if not ok:
         sys.exit('checksum mismatch')
 
 

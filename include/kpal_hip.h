@@ -83,8 +83,9 @@ int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, size_t nb
 int kpal_count_begin(kpal_ctx *ctx, int k);            /* klib.py:149-151: zeroed 4^k table */
 int kpal_count_set_strategy(kpal_ctx *ctx, int strategy);
 int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);        /* klib.py:154-168 */
-int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous: dev_buf must stay valid
-                                                                                     * and unchanged until kpal_sync / kpal_count_finish / kpal_count_table returns */
+int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous and stream-ordered: work queued on
+                                                                                     * the context afterwards (kpal_memcpy_*, kpal_synth_reads_device, the next feed) may
+                                                                                     * reuse dev_buf; anything outside the context's stream waits for kpal_sync first */
 /* FASTA text of whole records (Profile.from_fasta, klib.py:97-112; tokenising the reference
  * delegates to Bio.SeqIO.parse, klib.py:111): header lines dropped, the lines of a record joined
  * with all ASCII whitespace removed, records separated; anything before the first header is
@@ -122,13 +123,17 @@ int kpal_synth_reads_device(kpal_ctx *ctx, uint64_t seed, uint64_t first_read, u
  * bit-exact for any reduction order.  RCCL is bound at run time: rccl_library names the librccl.so to load (NULL: the
  * KPAL_RCCL_LIBRARY environment variable, then the loader's search path); inside a PyTorch process pass PyTorch's copy.
  *   rank 0:      kpal_comm_unique_id(lib, id)          -> hand the 128 bytes to the other ranks (MPI, a file, torch.distributed ...)
+ *   other ranks: kpal_comm_probe(lib)                  -> can RCCL be bound here?  (no id, no bootstrap listener; agree on the answer
+ *                                                         BEFORE the collective kpal_comm_init: a rank that cannot join leaves the others waiting)
  *   every rank:  kpal_comm_init(ctx, lib, rank, world, id)
  *   per job:     kpal_count_begin / feed ...; kpal_comm_reduce_table(ctx, root, balance); kpal_count_finish(root's host buffer)
  * kpal_comm_reduce_table: ncclReduce(int64, sum) of the count table onto `root` and, if balance != 0, Profile.balance there -- all
  * queued on the context's stream, no host synchronisation.  kpal_comm_reduce_table_async: the same on a copy of the table and on a
  * second stream, so that the next kpal_count_begin / feed overlaps it (throughput pipelines; two extra tables of HBM); the merged table
- * is then read with kpal_comm_merged_table (valid until the reduce after next) after kpal_sync. */
+ * is then read with kpal_comm_merged_table (valid until the reduce after next, or until a kpal_count_begin that changes k or -- serial
+ * form, where the merged table IS the count table -- starts the next count) after kpal_sync. */
 #define KPAL_COMM_ID_BYTES 128
+int kpal_comm_probe(const char *rccl_library);
 int kpal_comm_unique_id(const char *rccl_library, uint8_t *id_out /* KPAL_COMM_ID_BYTES */);
 int kpal_comm_init(kpal_ctx *ctx, const char *rccl_library, int rank, int world, const uint8_t *id);
 int kpal_comm_destroy(kpal_ctx *ctx);
@@ -137,7 +142,8 @@ int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance);
 int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins);
 /* kdistlib.distance_matrix (kdistlib.py:164-186) over several GPUs, sharded by BIN RANGE: every rank holds the same bins
  * [first, first + bin_count) of all P profiles (dev_slices: int64[P][bin_count] on the device, profile-major; ranges of different
- * ranks tile 0 .. 4^k; a multiple of 64 bins lets the LDS-staged kernels run), computes every pair's partial sum / term count / dot
+ * ranks tile 0 .. 4^k; the LDS-staged and matrix-core kernels run when EVERY rank's range is a multiple of 64 bins and >= 4096 -- the
+ * ranks agree on that with one 4-byte all-reduce before anything else, a ragged range anywhere puts all of them on the plain kernels), computes every pair's partial sum / term count / dot
  * product over its bins, and ONE all-reduce (two calls: fp64 sums, 64-bit counts -- 32 KB at P = 64) gives every rank the finished lower
  * triangle.  metric: prod / sum / euclidean; balancing needs whole profiles (kpal_balance_device before slicing). */
 int kpal_comm_distance_matrix_device(kpal_ctx *ctx, int P, uint64_t bin_count, const int64_t *dev_slices, int metric,

@@ -72,6 +72,7 @@ SIGNATURES = {
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_balance': (ctypes.c_int, [_vp]),
     'kpal_count_last_plan': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'kpal_comm_probe': (ctypes.c_int, [ctypes.c_char_p]),
     'kpal_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, _vp]),
     'kpal_comm_init': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp]),
     'kpal_comm_destroy': (ctypes.c_int, [_vp]),
@@ -204,6 +205,12 @@ def comm_unique_id():
     buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
     _check(load().kpal_comm_unique_id(rccl_library(), buf))
     return bytes(buf)
+
+
+def comm_probe():
+    """Can libkpal_hip.so bind RCCL in this process (dlopen + symbols)?  Raises if not.  What ranks > 0 call instead of
+    ``comm_unique_id`` before the collective ``Context.comm_init``."""
+    _check(load().kpal_comm_probe(rccl_library()))
 
 
 def device_count():

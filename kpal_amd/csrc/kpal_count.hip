@@ -17,6 +17,11 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 {
     CTX_ENTER(ctx);
     if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    if (ctx->merged && (ctx->merged_bins != (1ULL << (2 * k)) || ctx->merged == ctx->table.p)) {
+        // another k, or the merged table WAS the count table (serial reduce) which is about to be zeroed / reallocated
+        ctx->merged = nullptr;
+        ctx->merged_bins = 0;
+    }
     ctx->k = k;
     ctx->bins = 1ULL << (2 * k);
     CHK(ensure(ctx, ctx->table, ctx->bins * sizeof(int64_t)));
@@ -482,9 +487,12 @@ KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t n
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_device before kpal_count_begin");
     if (nbytes == 0) return KPAL_OK;
     if (!dev_buf) return set_err(KPAL_E_INVALID, "dev_buf is NULL");
-    ctx->fresh_feed = true;   // (the caller keeps dev_buf alive until the stream has drained: a FRESH piece may be counted again)
-    const int rc = count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
+    ctx->fresh_feed = true;
+    int rc = count_device_range(ctx, (const uint8_t *)dev_buf, nbytes, 0);
     ctx->fresh_feed = false;
+    // a FRESH piece whose lists overflowed is counted again from dev_buf: settled here, so that the buffer is the caller's again
+    // (stream-ordered, as with every other pipeline) when this call returns
+    if (rc == KPAL_OK) rc = quad2_resolve_fresh(ctx);
     return rc;
 }
 

@@ -98,6 +98,7 @@ struct kpal_ctx {
     // then (finalize_fresh).  Every other consumer of the table materialises the zeros first (table_ready).
     bool table_zero_pending = false;
     bool finalize_fresh = false;
+    bool fresh_resolved = false;             // the overflow word of the pending FRESH piece has been read (quad2_resolve_fresh)
     bool fresh_feed = false;                 // set by kpal_count_feed_device around count_device_range: a whole device feed
     Span fresh_span = {};                    // the piece of a FRESH finalisation (re-run classically if a list overflowed)
     DevBuf direct_list, direct_meta;         // TableSink segments ((index << 32) | count entries); per-segment counts + overflow word
@@ -135,6 +136,7 @@ struct kpal_ctx {
     DevBuf side[2];
     int side_turn = 0;
     void *merged = nullptr;                  // where the last merged table lies (the count table or a side buffer)
+    uint64_t merged_bins = 0;                // ... and how many bins it has (kpal_count_begin with another k discards it)
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -258,7 +260,9 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
 double quad_expected_backlog(const std::vector<double> &mu, int slots);   // kpal_quads.hip
 constexpr double kQuadBacklogMax = 1500.0;   // quad_choose_steps: expected steady-state backlog a tile size may bring (list: 2048)
 int quad2_finalize(kpal_ctx *ctx, bool balance);                          // kpal_quads2.hip: no-op unless a finalisation is pending
+int quad2_resolve_fresh(kpal_ctx *ctx);                                   // kpal_quads2.hip: a FRESH piece whose lists overflowed is counted again (the fed buffer is read)
 int table_ready(kpal_ctx *ctx);                                           // kpal_quads2.hip: zeros materialised, pending finalisation done: the table is the table
 int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out);   // kpal_vec.hip
-int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce);   // kpal_vec.hip
+int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce,
+                         int tiled = -1);   // kpal_vec.hip (tiled: -1 decided from n; 0 / 1 agreed between the ranks)
 int comm_allreduce_partials(kpal_ctx *ctx, void *dev_partials, size_t count);   // kpal_multi.hip: {double sum, uint64 count} pairs added over the ranks, in place

@@ -69,6 +69,10 @@ int rccl_load(const char *path)
 
 static_assert(KPAL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "kpal_comm_unique_id hands out an ncclUniqueId");
 
+// Can this process bind RCCL at all (dlopen + every symbol)?  No communicator, no unique id, no bootstrap listener: what every
+// rank other than the one that creates the id calls before the collective kpal_comm_init.
+KPAL_API int kpal_comm_probe(const char *rccl_library) { return rccl_load(rccl_library); }
+
 KPAL_API int kpal_comm_unique_id(const char *rccl_library, uint8_t *id_out)
 {
     if (!id_out) return set_err(KPAL_E_INVALID, "id_out is NULL");
@@ -130,6 +134,7 @@ KPAL_API int kpal_comm_destroy(kpal_ctx *ctx)
         ctx->side[i] = DevBuf();
     }
     ctx->merged = nullptr;
+    ctx->merged_bins = 0;
     return KPAL_OK;
 }
 
@@ -146,6 +151,7 @@ KPAL_API int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance)
         NCCLCHK(g_rccl.Reduce(ctx->table.p, ctx->table.p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream));
     }
     ctx->merged = ctx->table.p;
+    ctx->merged_bins = ctx->bins;
     if (balance && ctx->comm_rank == root) CHK(launch_balance(ctx, ctx->k, (const int64_t *)ctx->table.p, (int64_t *)ctx->table.p));
     return KPAL_OK;
 }
@@ -163,7 +169,11 @@ KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
     ctx->side_turn ^= 1;
     const int t = ctx->side_turn;
     const size_t bytes = (size_t)ctx->bins * sizeof(int64_t);
-    if (ctx->side[t].cap < bytes && ctx->side_used[t]) HIPCHK(hipEventSynchronize(ctx->ev_side_free[t]));   // (re-allocation: its last reader is done)
+    if (ctx->side[t].cap < bytes && ctx->side_used[t]) {   // (re-allocation: its last reader -- on the communicator's stream -- is done)
+        HIPCHK(hipEventSynchronize(ctx->ev_side_free[t]));
+        ctx->side_used[t] = false;
+        if (ctx->merged == ctx->side[t].p) ctx->merged = nullptr, ctx->merged_bins = 0;
+    }
     CHK(ensure(ctx, ctx->side[t], bytes));
     // the buffer's previous content (the merged table of two steps ago) may go once its reduce + balance are done
     if (ctx->side_used[t]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side_free[t], 0));
@@ -184,15 +194,16 @@ KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
     HIPCHK(hipEventRecord(ctx->ev_side_free[t], ctx->comm_stream));
     ctx->side_used[t] = true;
     ctx->merged = ctx->side[t].p;
+    ctx->merged_bins = ctx->bins;
     return KPAL_OK;
 }
 
 KPAL_API int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (!ctx->merged) return set_err(KPAL_E_STATE, "no merged table (kpal_comm_reduce_table[_async])");
+    if (!ctx->merged) return set_err(KPAL_E_STATE, "no merged table (kpal_comm_reduce_table[_async]; a kpal_count_begin with another k discards it)");
     if (dev_table) *dev_table = ctx->merged;
-    if (n_bins) *n_bins = ctx->bins;
+    if (n_bins) *n_bins = ctx->merged_bins;
     return KPAL_OK;
 }
 
@@ -244,7 +255,16 @@ KPAL_API int kpal_comm_distance_matrix_device(kpal_ctx *ctx, int P, uint64_t bin
     if (P == 1) return KPAL_OK;
     if (!dev_slices || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
     if (bin_count == 0 || ((uintptr_t)dev_slices & 15)) return set_err(KPAL_E_INVALID, "every rank needs a non-empty, 16-byte aligned slice");
-    return distance_matrix_core(ctx, P, bin_count, dev_slices, metric, out_lower, true);
+    // The ranks must take the SAME kernel family: the Gram path all-reduces dot products, the others per-pair sums and counts.
+    // Which one a rank would take depends on its own slice (>= 4096 bins, a multiple of 64), so the choice is agreed first:
+    // the LDS-staged kernels only if EVERY rank's slice allows them (one 4-byte all-reduce(MIN)).
+    int tiled = bin_count >= 4096 && bin_count % 64 == 0;
+    CHK(ensure(ctx, ctx->result, 64));
+    HIPCHK(hipMemcpyAsync(ctx->result.p, &tiled, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(g_rccl.AllReduce(ctx->result.p, ctx->result.p, 1, ncclInt32, ncclMin, (ncclComm_t)ctx->comm, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&tiled, ctx->result.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return distance_matrix_core(ctx, P, bin_count, dev_slices, metric, out_lower, true, tiled);
 }
 
 // A scalar agreed on by all ranks (bench: the slowest rank's time; tests): max over the ranks, through the device.

@@ -163,6 +163,7 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     ctx->finalize_pending = true;
     ctx->finalize_stage = stage;
     ctx->finalize_fresh = fresh;
+    ctx->fresh_resolved = false;
     if (fresh) {
         ctx->table_zero_pending = false;   // the finalisation writes every entry
         ctx->fresh_span = s;
@@ -182,29 +183,37 @@ int table_ready(kpal_ctx *ctx)
     return quad2_finalize(ctx, false);
 }
 
+// A pending FRESH piece: did every bypassing count fit its list segment?  (One word; the host waits for the piece's kernels --
+// it would soon anyway: the finalisation is launched from the host.)  If not -- a heavily skewed piece; the lists are sized for
+// the usual few hundred entries per workgroup -- the classic way after all: zero the table, count the piece AGAIN with atomic
+// adds for what bypasses the records.  That re-reads the fed buffer, so kpal_count_feed_device calls this before it returns: the
+// caller's buffer is free again when the feed call is back, as with every other pipeline.
+int quad2_resolve_fresh(kpal_ctx *ctx)
+{
+    if (!ctx->finalize_pending || !ctx->finalize_fresh || ctx->fresh_resolved) return KPAL_OK;
+    uint32_t overflow = 0;
+    const uint32_t *word = (const uint32_t *)ctx->direct_meta.p + ctx->direct_nseg;
+    HIPCHK(hipMemcpyAsync(&overflow, word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->fresh_resolved = true;
+    if (overflow) {
+        ctx->finalize_pending = false;
+        ctx->finalize_fresh = false;
+        HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
+        const int rc = launch_partition2_quads(ctx, ctx->fresh_span, false);   // (classic: finalize_pending again, not fresh)
+        if (rc != KPAL_OK) return rc == kQuadsUseChunked || rc == kSplitBatch ? set_err(KPAL_E_HIP, "two-level quad pipeline: cannot repeat a piece") : rc;
+    }
+    return KPAL_OK;
+}
+
 // Adds the staged forms of the last two-level quad piece to the count table (and balances the table in the same pass).
 int quad2_finalize(kpal_ctx *ctx, bool balance)
 {
     if (!ctx->finalize_pending) return KPAL_OK;
+    CHK(quad2_resolve_fresh(ctx));
     ctx->finalize_pending = false;
-    bool fresh = ctx->finalize_fresh;
+    const bool fresh = ctx->finalize_fresh;
     ctx->finalize_fresh = false;
-    if (fresh) {
-        // did every bypassing count fit its list segment?  (one word; the host would wait for these kernels soon anyway)
-        uint32_t overflow = 0;
-        const uint32_t *word = (const uint32_t *)ctx->direct_meta.p + ctx->direct_nseg;
-        HIPCHK(hipMemcpyAsync(&overflow, word, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (overflow) {
-            // heavily skewed piece (the lists are sized for the usual few hundred entries per workgroup): the classic way after
-            // all -- zero the table, count the piece again with atomic adds for what bypasses the records
-            HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));
-            const int rc = launch_partition2_quads(ctx, ctx->fresh_span, false);
-            if (rc != KPAL_OK) return rc == kQuadsUseChunked || rc == kSplitBatch ? set_err(KPAL_E_HIP, "two-level quad pipeline: cannot repeat a piece") : rc;
-            ctx->finalize_pending = false;
-            fresh = false;
-        }
-    }
     const quad2_stage_t *stage = (const quad2_stage_t *)ctx->finalize_stage;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
     DISPATCH_K_13_16(ctx->k, {

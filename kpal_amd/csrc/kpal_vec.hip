@@ -286,8 +286,6 @@ static int gram_euclidean(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof,
     return KPAL_OK;
 }
 
-int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce);
-
 KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int64_t *dev_profiles, int metric,
                                          int do_balance, double *out_lower)
 {
@@ -311,9 +309,11 @@ KPAL_API int kpal_distance_matrix_device(kpal_ctx *ctx, int P, int k, const int6
 
 // The lower triangle over n bins per profile (profile p at prof + p * n).  allreduce: this rank holds a bin RANGE of every
 // profile -- the per-pair sums / term counts / dot products of all ranks are added (one all-reduce) before they are finished.
-int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce)
+int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, int metric, double *out_lower, bool allreduce, int tiled_agreed)
 {
-    const bool tiled = n >= 4096 && n % 64 == 0;   // (whole profiles: k >= 6) the LDS-staged kernels take 64 bins at a time
+    // (whole profiles: k >= 6) the LDS-staged kernels take 64 bins at a time.  Bin-range shards: the ranks agreed on it
+    // (kpal_comm_distance_matrix_device) -- the Gram path and the others all-reduce different things
+    const bool tiled = n >= 4096 && n % 64 == 0 && tiled_agreed != 0;
     // euclidean with enough profiles and bins: fp64 Gram matrix on the matrix cores (gram_kernels.hpp), exact
     // while every |x|^2 < 2^53 (checked on the result); KPAL_MATRIX_MFMA=0 forces the int64 kernels
     static const bool allow_mfma = [] { const char *e = getenv("KPAL_MATRIX_MFMA"); return !e || atoi(e) != 0; }();
@@ -347,7 +347,7 @@ int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, 
         Partial *pp = (Partial *)ctx->partials.p;
         const int2 *dt = (const int2 *)ctx->scratch[3].p;
         // multiset 'prod' as a difference of reciprocals (matrix_rdiff_kernel; KPAL_MATRIX_RDIFF=0 forces the pair-of-counts
-        // kernel): valid while every count is below 2^20 -- the kernel says whether it saw a larger one
+        // kernel): valid while every count is below 2^16 -- the kernel says whether it saw a larger one
         static const bool allow_rdiff = [] { const char *e = getenv("KPAL_MATRIX_RDIFF"); return !e || atoi(e) != 0; }();
         bool rdiff_done = false;
         if (metric == 0 && allow_rdiff) {

@@ -773,11 +773,15 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
 // time, so ONE ballot gives that row's zero mask, and the bins where BOTH profiles are zero are popcount(mask_i & mask_j),
 // two v_bcnt per pair and stage, accumulated by thread (i, j) of the 16 x 16 super-tile.
 //   Accuracy: r is within 1 ulp of 1 / (x + 1) (rcp_counts), so a term's error is at most 2^-52 (r_x + r_y) against a term
-// of at least r_x r_y (x != y: |x - y| >= 1): relative 2^-52 (x + y + 2) -- below 4.7e-10 while both counts are below 2^20,
+// of at least r_x r_y (x != y: |x - y| >= 1): relative 2^-52 (x + y + 2) -- below 2.9e-11 while both counts are below 2^16
+// (kRdiffMaxCount; at 2^20 the bound would be 4.7e-10, half the contract with nothing left for the accumulation),
 // and every term being non-negative that bounds the relative error of the sum as well; the contract for fp64 results is
-// 1e-9 (typical: 1e-15).  A count >= 2^20 (or negative) anywhere raises *big and the caller reruns the pair-of-counts kernel.
+// 1e-9 (typical: 1e-15; the cancellation-dominated worst case -- all counts just below the limit, differing by 1 -- is
+// tests/test_gpu_vec.py::test_matrix_rdiff_worst_case).  A count >= 2^16 (or negative) anywhere raises *big and the caller
+// reruns the pair-of-counts kernel.
 //   Reciprocals of counts below 512 come from a table in LDS (one ds_read_b64 instead of v_rcp_f64 + four fused
 // multiply-adds per staged value -- the loader would cost 60 % of the arithmetic otherwise); larger counts are computed.
+constexpr unsigned long long kRdiffMaxCount = 1ull << 16;   // counts the difference form is accurate for (see above)
 constexpr int kRdiffTable = 512;    // reciprocals 1 / (c + 1) of counts c < 512 (4 KiB: four workgroups per CU)
 constexpr int kRdiffRow = 64;       // staged row: 64 bins, unpadded -- with 16-byte reads a 16-lane group covers all 64 banks, and
                                     // rows a multiple of 8 doubles apart keep the lanes of two groups that share a read pass apart
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     __syncthreads();                                   // the table
     auto recip = [&](int64_t v, bool all_small) -> double {
         if (all_small) return rtable[(uint32_t)v];
-        saw_big |= (unsigned long long)v >= (1ull << 20);
+        saw_big |= (unsigned long long)v >= kRdiffMaxCount;
         return (unsigned long long)v < (unsigned long long)kRdiffTable ? rtable[(uint32_t)v & (kRdiffTable - 1)] : rcp_counts((double)(uint32_t)v + 1.0);
     };
     auto put = [&](int buf, int q, const longlong2 &v) {

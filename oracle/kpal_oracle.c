@@ -827,3 +827,105 @@ ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, in
     free(th);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------ *
+ * At-scale check of LARGE tables (k = 15: 8 GiB) without holding one on the host: the same rolling
+ * window (kpal/klib.py:157-168), but only the counts of SELECTED blocks of 2^block_bits consecutive
+ * table entries are kept.
+ *   plain [s * 2^block_bits + j] = counts[sel[s] * 2^block_bits + j]
+ *   mirror[s * 2^block_bits + j] = counts[rc(sel[s] * 2^block_bits + j)]    (rc: klib.py:394-412)
+ * so that Profile.balance of the selected entries (klib.py:285-298: counts[i] + counts[rc(i)]) is
+ * plain + mirror.  A k-mer x contributes to mirror iff rc(x) lies in a selected block; the top
+ * 2k - block_bits bits of rc(x) are the complemented, digit-reversed LOW bits of x, so the membership
+ * test is a table lookup on x's low bits and rc(x) itself is computed (by the restated
+ * reverse_complement above) only for the few k-mers that pass it.
+ * T threads, relaxed atomic adds into the two shared arrays (as count_flat_mt's shared table).
+ * block_bits must be even (whole 2-bit digits), 2 <= block_bits <= 2k.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *buf;
+    size_t begin, end;
+    int k, block_bits;
+    const int32_t *slot_of_block;    /* [2^(2k - block_bits)]: slot of a block, -1 = not selected */
+    const int32_t *slot_of_lowkey;   /* [2^(2k - block_bits)]: slot of the block rc(x) falls in, by x's low bits */
+    int64_t *plain, *mirror;
+} blocks_job;
+
+static void *blocks_worker(void *arg)
+{
+    blocks_job *j = (blocks_job *)arg;
+    const int k = j->k;
+    const uint64_t bitmask = (k >= 32) ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
+    const int nb = 2 * k - j->block_bits;
+    const uint64_t lowmask = ((uint64_t)1 << nb) - 1;
+    const uint64_t inblock = ((uint64_t)1 << j->block_bits) - 1;
+    size_t i = j->begin >= (size_t)(k - 1) ? j->begin - (size_t)(k - 1) : 0;
+    uint64_t binary = 0;
+    size_t run = 0;
+    for (; i < j->end; i++) {
+        int code = nucleotide_to_binary(j->buf[i]);
+        if (code < 0) { run = 0; binary = 0; continue; }
+        binary = ((binary << 2) | (uint64_t)code) & bitmask;
+        run++;
+        if (run >= (size_t)k && i >= j->begin) {
+            const int32_t s = j->slot_of_block[binary >> j->block_bits];
+            if (s >= 0) __atomic_fetch_add(&j->plain[((uint64_t)s << j->block_bits) | (binary & inblock)], 1, __ATOMIC_RELAXED);
+            const int32_t m = j->slot_of_lowkey[binary & lowmask];
+            if (m >= 0) {
+                const uint64_t rc = kpal_oracle_reverse_complement(binary, k);
+                __atomic_fetch_add(&j->mirror[((uint64_t)m << j->block_bits) | (rc & inblock)], 1, __ATOMIC_RELAXED);
+            }
+        }
+    }
+    return NULL;
+}
+
+ORACLE_API int kpal_oracle_count_blocks_mt(const uint8_t *buf, size_t n, int k, int block_bits, const uint64_t *sel, int nsel,
+                                           int threads, int64_t *plain, int64_t *mirror)
+{
+    if (k < 1 || k > 31 || threads < 1 || nsel < 1 || block_bits < 2 || block_bits > 2 * k || (block_bits & 1)) return -1;
+    const int nb = 2 * k - block_bits;
+    if (nb > 30) return -1;
+    const size_t nblocks = (size_t)1 << nb;
+    const int T = threads > 256 ? 256 : threads;
+    int rc = 0;
+    int32_t *slot_of_block = (int32_t *)malloc(nblocks * sizeof(int32_t));
+    int32_t *slot_of_lowkey = (int32_t *)malloc(nblocks * sizeof(int32_t));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
+    char *joinable = (char *)calloc(T, 1);
+    blocks_job *jobs = (blocks_job *)malloc(sizeof(blocks_job) * T);
+    if (!slot_of_block || !slot_of_lowkey || !th || !joinable || !jobs) rc = -2;
+    if (rc == 0) {
+        for (size_t b = 0; b < nblocks; b++) slot_of_block[b] = slot_of_lowkey[b] = -1;
+        for (int s = 0; s < nsel && rc == 0; s++) {
+            if (sel[s] >= nblocks || slot_of_block[sel[s]] >= 0) { rc = -1; break; }   /* out of range / listed twice */
+            slot_of_block[sel[s]] = s;
+            /* x with rc(x) in block sel[s]: the low nb bits of x are the reverse complement of the block number,
+             * read as a k-mer of nb/2 digits */
+            slot_of_lowkey[nb ? kpal_oracle_reverse_complement(sel[s], nb / 2) : 0] = s;
+        }
+    }
+    if (rc == 0) {
+        for (int t = 0; t < T; t++) {
+            jobs[t].buf = buf;
+            jobs[t].begin = n * (size_t)t / T;
+            jobs[t].end = n * (size_t)(t + 1) / T;
+            jobs[t].k = k;
+            jobs[t].block_bits = block_bits;
+            jobs[t].slot_of_block = slot_of_block;
+            jobs[t].slot_of_lowkey = slot_of_lowkey;
+            jobs[t].plain = plain;
+            jobs[t].mirror = mirror;
+            joinable[t] = pthread_create(&th[t], NULL, blocks_worker, &jobs[t]) == 0;
+            if (!joinable[t]) blocks_worker(&jobs[t]);
+        }
+        for (int t = 0; t < T; t++)
+            if (joinable[t]) pthread_join(th[t], NULL);
+    }
+    free(jobs);
+    free(joinable);
+    free(th);
+    free(slot_of_lowkey);
+    free(slot_of_block);
+    return rc;
+}

@@ -38,6 +38,9 @@ def lib():
         L.kpal_oracle_count_piece.restype = ctypes.c_int
         L.kpal_oracle_count_flat_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_i64p]
         L.kpal_oracle_count_flat_mt.restype = ctypes.c_int
+        L.kpal_oracle_count_blocks_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p]
+        L.kpal_oracle_count_blocks_mt.restype = ctypes.c_int
         L.kpal_oracle_reverse_complement.argtypes = [ctypes.c_uint64, ctypes.c_int]
         L.kpal_oracle_reverse_complement.restype = ctypes.c_uint64
         L.kpal_oracle_balance.argtypes = [_c_i64p, ctypes.c_int]
@@ -128,6 +131,22 @@ def count_flat(buf, length, threads=1):
     if rc:
         raise MemoryError('kpal_oracle_count_flat_mt failed (%d)' % rc)
     return counts
+
+
+def count_blocks(buf, length, block_bits, blocks, threads=1):
+    """Counts of SELECTED blocks of ``2**block_bits`` consecutive table entries of a flat byte stream, for tables too large
+    to hold on the host (k = 15: 8 GiB): -> (plain, mirror), int64[len(blocks), 2**block_bits] each, with
+    ``plain[s, j] = counts[blocks[s] * 2**block_bits + j]`` and ``mirror[s, j] = counts[rc(blocks[s] * 2**block_bits + j)]``,
+    so that ``plain + mirror`` is ``Profile.balance`` (klib.py:285-298) of the selected entries."""
+    b = _bytes_view(buf)
+    sel = np.ascontiguousarray(blocks, dtype=np.uint64)
+    plain = np.zeros((sel.size, 1 << block_bits), dtype=np.int64)
+    mirror = np.zeros_like(plain)
+    rc = lib().kpal_oracle_count_blocks_mt(b.ctypes.data, b.size, int(length), int(block_bits), sel.ctypes.data, int(sel.size),
+                                           int(max(threads, 1)), plain.ctypes.data_as(_c_i64p), mirror.ctypes.data_as(_c_i64p))
+    if rc:
+        raise ValueError('kpal_oracle_count_blocks_mt failed (%d)' % rc)
+    return plain, mirror
 
 
 def reverse_complement(number, length):

@@ -6,6 +6,7 @@ import os
 import re
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -228,10 +229,40 @@ def test_bench_launcher_spawns_the_ranks():
     assert len(lines) == 1, lines                      # ONE JSON line on stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['checksum_ok'] is True and line['steps'] == 3
-    # a failing rank fails the launcher
+    assert line['merged_equals_single_stream'] is True and line['attempt'] == 1
+    # a failing rank fails the launcher (both attempts of the supervisors: there is no GPU here)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=dict(env, HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES=''), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0
+
+
+@pytest.mark.parametrize('fault', ['hang', 'rank_dies'])
+def test_bench_supervisor_falls_back_to_a_fresh_worker(fault):
+    """A first multi-GPU attempt that never returns must still end in a line: every rank under torch.distributed.run is a
+    supervisor that starts the GPU worker as a child, and on a worker that does not finish in time (hang: every worker of
+    attempt 1 stops responding after start-up) or dies (rank_dies: rank 1's worker exits before the rendezvous while rank 0's
+    waits for it) ends the attempt on ALL ranks -- failure flags in the job's shared directory -- kills the workers' process
+    groups and starts FRESH workers in the conservative mode (--reduce-via torch --serial-reduce, a new rendezvous).  Driven
+    with the CPU/gloo stub."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(KPAL_BENCH_RUN_TIMEOUT='4', KPAL_BENCH_STARTUP_TIMEOUT='120')
+    extra = ['--stub-hang-attempt', '1'] if fault == 'hang' else ['--stub-fail-rank', '1']
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0', '--stub'] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode == 0, err[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['attempt'] == 2 and line['n_gpus'] == 2 and line['merged_equals_single_stream'] is True
+    if fault == 'hang':
+        assert 'did not finish within' in line['fallback_reason'], line
+    else:
+        assert 'exited with status 3' in line['fallback_reason'] or 'gave up on attempt 1' in line['fallback_reason'], line
+        assert time.time() - t0 < 120          # the peer's flag ends rank 0's wait at once, not its time limit
+    assert 'supervisor (rank' in err
 
 
 def test_kmer_caller_host_logic():

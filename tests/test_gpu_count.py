@@ -429,15 +429,29 @@ def test_full_size_k15(ctx):
     kpal_count_last_plan) -- the pipeline bench.py --k 15 measures.  Checked at 100 M reads: exact total, no negative bin, and
     the whole 8 GiB table bin for bin against the round-1 two-level pipeline ('partition2': coarse_scatter -> chunk_key_lines
     -> chunk_hist, independent kernels and data layout) run on the same buffer by a second context, compared on the device;
-    linearity over two half-shards.  With the quad pipeline FORCED on prefixes AUTO would hand to 'partition2': bin for bin
-    against the global-atomic kernel (10 M reads) and against the CPU oracle (2 M reads)."""
+    linearity over two half-shards.  AGAINST THE ORACLE AT FULL SIZE: the 15.1 GB of reads are downloaded and the all-cores
+    CPU oracle (oracle.count_blocks, pinned to the golden count by tests/test_oracle_golden.py) counts 64 blocks of 2^20
+    table entries -- the first and the last block, CCCCC / GGGGG, blocks together with the block of their reverse
+    complements, the rest spread over the table: 2^26 bins, 512 MiB -- plain AND balanced (Profile.balance = the block's
+    counts + the counts of the entries' reverse complements, which lie all over the table), compared with the tables the
+    benchmarked pipeline produced from the same 100 M reads (kpal_count_finish / kpal_count_balance: FRESH mode, packed
+    histogram bins, 8-bit staged forms, fused balance -- the regime bench.py --k 15 times).  With the quad pipeline FORCED
+    on prefixes AUTO would hand to 'partition2': bin for bin against the global-atomic kernel (10 M reads) and against the
+    CPU oracle on ALL bins (2 M reads)."""
     torch = pytest.importorskip('torch')
     from kpal_amd import _native, dist
     k, n_reads = 15, 100_000_000
     nbytes = n_reads * 151
     d = ctx.alloc(nbytes)
     other = _native.Context(ctx.device)
+    # blocks of 2^20 consecutive entries (a block = the k-mers with one 5-base prefix) the oracle counts at full size
+    block_bits = 20
+    rs = np.random.RandomState(15)
+    sel = [0, 1023, 341, 682, 27, oracle.reverse_complement(27, 5), 600, oracle.reverse_complement(600, 5), 1, 1022, 512, 511]
+    sel += [int(b) for b in rs.permutation(1024) if int(b) not in sel][:64 - len(sel)]
+    assert len(set(sel)) == 64
     try:
+        sel_t = torch.as_tensor(sel, device='cuda:%d' % ctx.device)
         ctx.synth_reads_device(4, 0, n_reads, 150, d)
         ctx.count_begin(k)
         ctx.count_feed_device(d, nbytes)
@@ -468,12 +482,14 @@ def test_full_size_k15(ctx):
         bal = dist.table_as_tensor(ctx)
         assert int(bal.sum()) == 2 * n_reads * (150 - k + 1)
         assert torch.equal(bal, dist.table_as_tensor(other))
+        bal_blocks = bal.view(-1, 1 << block_bits)[sel_t].cpu().numpy()
         torch.cuda.synchronize()
         ctx.count_begin(k)                       # the unbalanced table again, for the checks below
         ctx.count_feed_device(d, nbytes)
         ctx.count_finish(to_host=False)
         ctx.sync()
         full = dist.table_as_tensor(ctx)
+        full_blocks = full.view(-1, 1 << block_bits)[sel_t].cpu().numpy()
         # linearity: the two half-shards counted by the second context (quad pipeline) add up to the same table
         half = n_reads // 2
         other.count_begin(k)
@@ -513,6 +529,15 @@ def test_full_size_k15(ctx):
         want = oracle.count_flat(pre, k, threads=8)
         assert got.sum() == 2_000_000 * (150 - k + 1)
         assert np.array_equal(got, want)
+        del got, want, pre
+        # the oracle at FULL size on the selected blocks: all 100 M reads downloaded, counted on the host cores
+        host = np.empty(nbytes, dtype=np.uint8)
+        ctx.d2h(host, d)
+        plain, mirror = oracle.count_blocks(host, k, block_bits, sel, threads=min(32, os.cpu_count() or 1))
+        del host
+        assert int(plain.sum()) > 0.05 * n_reads * (150 - k + 1)      # 64 of 1024 blocks of uniform reads: ~6 % of the k-mers
+        np.testing.assert_array_equal(full_blocks, plain)
+        np.testing.assert_array_equal(bal_blocks, plain + mirror)
     finally:
         other.close()
         ctx.free(d)

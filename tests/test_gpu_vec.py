@@ -193,7 +193,7 @@ def test_matrix_super_tiles(ctx):
     """The LDS-staged 16 x 16 super-tile kernels (P > 8, k >= 6): ragged profile counts (clamped rows, idle
     groups, several super-tiles); counts >= 2^31 in some bins (the difference-of-reciprocals kernel of multiset 'prod'
     reports them and the pair-of-counts kernel reruns: int64 path next to the float path) and the same shapes with every
-    count below 2^20 (the difference-of-reciprocals kernel's own result: table and computed reciprocals, zero masks);
+    count below 2^16 (the difference-of-reciprocals kernel's own result: table and computed reciprocals, zero masks);
     at k = 12 enough bins per thread for the packed byte counters of the term counts to be flushed; and (big = None) every
     count below 1024: multiset 'sum' on its reciprocal-table kernel up to the last table entries."""
     rs = np.random.RandomState(17)
@@ -209,11 +209,11 @@ def test_matrix_super_tiles(ctx):
         elif big:
             profs[P // 2][rs.randint(0, 4 ** k, 50)] = (1 << 31) + rs.randint(0, 1000, 50)     # beyond the float path
         else:
-            # multiset 'prod' stays on the difference-of-reciprocals kernel (every count below 2^20): counts beyond its
-            # reciprocal table (2048) next to small ones, equal large counts, a count just below the limit
-            profs[P // 2][rs.randint(0, 4 ** k, 50)] = 2048 + rs.randint(0, 900000, 50)
-            profs[0][5] = profs[1][5] = 777777
-            profs[2][9] = (1 << 20) - 1
+            # multiset 'prod' stays on the difference-of-reciprocals kernel (every count below 2^16): counts beyond its
+            # reciprocal table (512) next to small ones, equal large counts, a count just below the limit
+            profs[P // 2][rs.randint(0, 4 ** k, 50)] = 512 + rs.randint(0, 60000, 50)
+            profs[0][5] = profs[1][5] = 55555
+            profs[2][9] = (1 << 16) - 1
         profs[1][::7] = 0
         for metric in ('prod', 'sum', 'euclidean'):
             code = ('prod', 'sum', 'euclidean').index(metric)
@@ -239,6 +239,24 @@ def test_matrix_super_tiles(ctx):
     metric = 'prod'
     for i, j in ((1, 0), (3, 2), (9, 3)):
         assert close(ctx.distance_matrix(profs, k, 0)[i * (i - 1) // 2 + j], oracle.distance(profs[i], profs[j], k, metric=metric))
+
+
+def test_matrix_rdiff_worst_case(ctx):
+    """The accuracy bound of multiset 'prod' as a difference of reciprocals (matrix_rdiff_kernel) where it is tightest: EVERY
+    count just below the kernel's limit of 2^16 and neighbours differing by 1 or 2 -- each term 1/(y+1) - 1/(x+1) cancels all
+    but the last ~16 bits of its operands.  Against the oracle (IEEE divisions of the integer formulation), 1e-9 relative; and
+    one count AT the limit must take the pair-of-counts kernel (same answer)."""
+    rs = np.random.RandomState(99)
+    for k, P in ((6, 12), (8, 20)):
+        profs = [((1 << 16) - 1 - rs.randint(0, 3, 4 ** k)).astype(np.int64) for _ in range(P)]
+        got = ctx.distance_matrix(profs, k, 0)
+        want = oracle.distance_matrix_values(profs, k, False, 'prod')
+        rel = np.abs(got - want) / np.abs(want)
+        assert rel.max() <= RTOL, (k, P, float(rel.max()))
+        profs[3][11] = 1 << 16
+        got = ctx.distance_matrix(profs, k, 0)
+        want = oracle.distance_matrix_values(profs, k, False, 'prod')
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)      # IEEE divisions: the pair-of-counts kernel ran
 
 
 def test_g4_tutorial_end_to_end(golden_scalars, tutorial_dir):
@@ -308,8 +326,9 @@ def test_config5_matrix_k12_64_profiles(ctx, n_reads):
     super-tile kernels; euclidean on the matrix cores) for prod / sum / euclidean with and without balancing
     (kdistlib.py:164-186):
       * ALL 2016 entries against the oracle (its pair function on every pair, dealt to the host's cores) for multiset prod,
-        the 276 entries of the first 24 profiles for the other combinations (dense: prod balanced, sum, euclidean; sparse: euclidean):
-        <= 1e-9 relative, euclidean bit-identical,
+        multiset sum and (dense) euclidean -- matrix_rdiff, matrix_rsum and gram_mfma at full P; the 276 entries of the first
+        24 profiles for the other combinations (dense: prod balanced; sparse: euclidean): <= 1e-9 relative, euclidean
+        bit-identical,
       * 60 entries against the pair kernel (IEEE divisions, another summation order),
       * the text of a 12-profile sub-matrix through kdistlib.distance_matrix against the oracle's text."""
     from kpal_amd import klib, kdistlib
@@ -334,11 +353,11 @@ def test_config5_matrix_k12_64_profiles(ctx, n_reads):
         pick = [pairs[t] for t in rs.choice(len(pairs), 60, replace=False)]
         # the oracle on ALL 2016 pairs for the default metric (both variants), on the 276 pairs of the first 24 profiles for the
         # other combinations (2016 pairs x 4^12 bins cost the host ~12 s each)
-        full = {('prod', False)}
+        full = {('prod', False), ('sum', False)} | ({('euclidean', False)} if n_reads == 2_000_000 else set())
         sub = 24
         combos = [('prod', False), ('prod', True), ('sum', False), ('euclidean', False)]   # (sum / euclidean with balancing: the smaller tests)
         if n_reads != 2_000_000:
-            combos = [('prod', False), ('euclidean', False)]
+            combos = [('prod', False), ('sum', False), ('euclidean', False)]
         for metric, bal in combos:
             code = ('prod', 'sum', 'euclidean').index(metric)
             if True:

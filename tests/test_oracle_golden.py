@@ -56,6 +56,36 @@ def test_g3_config1_and_generator(golden_synth):
         np.testing.assert_array_equal(pyref.from_sequences(seqs, k), oracle.from_sequences(seqs, k))
 
 
+def test_g3_block_counter_against_the_pinned_count(golden_synth):
+    """oracle.count_blocks (the at-scale checker of tables too large for the host, tests/test_gpu_count.py::test_full_size_k15)
+    against the golden-pinned count_flat / balance on BASELINE config 1 and on noisy reads: every geometry, selections that
+    include the first and the last block, a block together with the block of its reverse complements, palindromes (even k)."""
+    g = golden_synth['config1']
+    buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], g['read_len'])
+    noisy = oracle.synth_reads(7, 0, 3000, 150, noisy=True)
+    for data, k, block_bits, blocks, threads in (
+            (buf, g['k'], 10, [0, 255, 17, 128, 77], 1),       # k = 9: 256 blocks of 1024 entries; 255 = rc block of 0
+            (buf, g['k'], 10, [0, 255, 17, 128, 77], 4),
+            (buf, g['k'], 18, [0], 3),                          # one block = the whole table
+            (buf, g['k'], 2, list(range(0, 65536, 4099)) + [65535], 2),
+            (noisy, 8, 6, [0, 1023, 512, 300, 1, 682], 3),      # even k: palindromes; 682 = 0b1010101010 (GGGGG)
+            (noisy, 5, 4, [63, 0, 21], 2),
+            (noisy, 11, 12, [0, 1023, 5, 1000], 4)):
+        full = oracle.count_flat(data, k)
+        if k == g['k'] and data is buf:
+            assert sha(full) == g['sha256']
+        bal = oracle.balance(full, k, threads=1)
+        plain, mirror = oracle.count_blocks(data, k, block_bits, blocks, threads=threads)
+        size = 1 << block_bits
+        for s, b in enumerate(blocks):
+            np.testing.assert_array_equal(plain[s], full[b * size:(b + 1) * size])
+            np.testing.assert_array_equal(plain[s] + mirror[s], bal[b * size:(b + 1) * size])
+    with pytest.raises(ValueError):
+        oracle.count_blocks(buf, 9, 10, [0, 0])       # a block listed twice
+    with pytest.raises(ValueError):
+        oracle.count_blocks(buf, 9, 9, [0])           # not whole digits
+
+
 def test_g3_noisy_and_long(golden_synth):
     g = golden_synth['noisy']
     buf = oracle.synth_reads(g['seed'], 0, g['n_reads'], 150, noisy=True)
