@@ -36,6 +36,7 @@ extern "C" {
 #define KPAL_E_NOMEM (-2)   /* host or device allocation failed (-> MemoryError) */
 #define KPAL_E_HIP (-3)     /* HIP runtime error (-> RuntimeError) */
 #define KPAL_E_STATE (-4)   /* call sequence error, e.g. feed before begin (-> RuntimeError) */
+#define KPAL_E_IO (-5)      /* a file could not be opened or read (-> OSError) */
 
 /* metric selectors */
 #define KPAL_PAIRWISE_PROD 0 /* metrics.pairwise['prod'], metrics.py:160 */
@@ -89,8 +90,18 @@ int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);  
 /* FASTA text of whole records (Profile.from_fasta, klib.py:97-112; tokenising the reference
  * delegates to Bio.SeqIO.parse, klib.py:111): header lines dropped, the lines of a record joined
  * with all ASCII whitespace removed, records separated; anything before the first header is
- * ignored.  Flattened on the device, then counted like one kpal_count_feed_device call. */
+ * ignored.  The text goes to the device in 64 MiB chunks cut anywhere (pinned staging), is flattened there and counted; chunk
+ * i + 1 is read, copied and flattened while chunk i is counted; k-mer windows span the chunk seams (never a record boundary).
+ * Windows never span two CALLS: a call holds whole records -- or a record's tail / middle / head when the caller cuts one
+ * giant record into ranges and hands every range but the first the k - 1 bases before it as `prefix` (below). */
 int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);
+/* The same for the bytes [begin, end) of a FILE (end = 0: to its end), read by the library itself: parallel preads straight
+ * into the pinned staging buffers (KPAL_READ_THREADS, default 8) -- the path of `kpal count` on a FASTA file (kmer.py:112-146
+ * -> klib.py:97-112) and of one rank's shard of the input (byte ranges cut at record boundaries; for one giant
+ * record, ranges with a (k-1)-base read-only halo).  `prefix` (may be NULL): text that logically precedes the range -- for a
+ * range that begins inside a record: ">\n" + the last k - 1 sequence bytes before `begin`; the range itself must begin at a
+ * line start.  Without a prefix, text before the first header of the range is ignored, as at the start of a file. */
+int kpal_count_feed_fasta_file(kpal_ctx *ctx, const char *path, uint64_t begin, uint64_t end, const uint8_t *prefix, size_t prefix_len);
 /* The flattening alone (tests): host_out needs nbytes bytes; records are each preceded by '\n'. */
 int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out);
 /* Profile.from_fasta_by_record, klib.py:114-133, batched: host_flat holds n_records records,

@@ -18,7 +18,7 @@ PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN, COSINE = 0, 1, 2, 3
 SUMMARY_MIN, SUMMARY_AVERAGE, SUMMARY_MEDIAN = 0, 1, 2
 STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7}
 
-_E_INVALID, _E_NOMEM, _E_HIP, _E_STATE = -1, -2, -3, -4
+_E_INVALID, _E_NOMEM, _E_HIP, _E_STATE, _E_IO = -1, -2, -3, -4, -5
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -66,6 +66,7 @@ SIGNATURES = {
     'kpal_count_feed': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_device': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_fasta': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_count_feed_fasta_file': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_size_t]),
     'kpal_fasta_flatten': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
@@ -175,6 +176,8 @@ def _check(rc):
         raise ValueError(msg)
     if rc == _E_NOMEM:
         raise MemoryError(msg)
+    if rc == _E_IO:
+        raise OSError(msg)
     raise RuntimeError('kpal_hip error %d: %s' % (rc, msg))
 
 
@@ -302,6 +305,14 @@ class Context(object):
         a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
         if a.size:
             _check(self._L.kpal_count_feed_fasta(self._h, a.ctypes.data, a.size))
+
+    def count_feed_fasta_file(self, path, begin=0, end=0, prefix=b''):
+        """The bytes [begin, end) of a FASTA file (end = 0: to its end), read by the library itself (parallel preads into its
+        pinned staging buffers), flattened and counted on the GPU, chunks pipelined.  ``prefix``: text that logically precedes
+        the range (a shard that begins inside a record: ``b'>\\n'`` + the k - 1 bases before it)."""
+        prefix = bytes(prefix)
+        pbuf = (ctypes.c_uint8 * max(len(prefix), 1)).from_buffer_copy(prefix or b'\0')
+        _check(self._L.kpal_count_feed_fasta_file(self._h, os.fsencode(path), int(begin), int(end), pbuf, len(prefix)))
 
     def fasta_flatten(self, buf):
         """-> the flat byte stream the counting kernels see for this FASTA text (tests)."""

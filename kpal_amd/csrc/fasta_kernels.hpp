@@ -13,8 +13,11 @@
 //     joined record) spaces and line ends are dropped everywhere, other whitespace (\t, \v, \f, 0x1c..0x1f, 0x85, 0xa0)
 //     only where it trails its line; an interior tab stays and separates k-mer windows like any byte
 //     outside the alphabet (kpal/klib.py:152-156);
-//   * the buffer handed to these kernels starts at a header (the host skips anything before the
-//     first header, like Biopython does).
+//   * the text of one feed is handed to these kernels in chunks cut ANYWHERE (64 MiB pieces of a file); `start_state` says
+//     what the chunk's first byte continues: 0 = it is the first byte of a line (header iff '>'), 1 = the middle of a header
+//     line, 2 = the middle of a sequence line.  The first chunk of a feed starts at a header (the host skips anything before
+//     the first header, like Biopython does); a chunk never ends inside a run of blanks unless the text ends there (the host
+//     moves the cut), so "only whitespace follows on this line" can be decided inside the chunk.
 // Whether byte i is inside a header depends only on the first byte of its line, i.e. on the last
 // end-of-line before i: a prefix-max over the buffer.  Five small passes: per-block last EOL,
 // carry scan, per-block kept-byte count, offset scan, scatter (staged through LDS so the output
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void fa_carry_kernel(const long long *__restri
 }
 
 // Classify the thread's 16 bytes: bit j of `keep` set iff byte j is emitted; out[j] its value.
-__device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint64_t n, uint64_t i0, long long prev_eol,
+__device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint64_t n, uint64_t i0, long long prev_eol, int start_state,
                                             uint32_t &keep, uint8_t (&out)[kFaPerThread])
 {
     keep = 0;
@@ -116,11 +119,12 @@ __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint
         if (i >= n) break;
         const uint8_t c = in[i];
         if (!known) {            // first byte of this thread, or first byte after an EOL
-            header = in[last + 1] == '>';
+            // (no end of line yet in this chunk: the line began in the previous one, which knows what it is)
+            header = last < 0 && start_state != 0 ? start_state == 1 : in[last + 1] == '>';
             known = true;
         }
         if (header) {
-            if ((long long)i == last + 1) {   // the '>' itself: record separator
+            if ((long long)i == last + 1 && !(last < 0 && start_state == 1)) {   // the '>' itself: record separator
                 keep |= 1u << j;
                 out[j] = '\n';
             }
@@ -137,7 +141,7 @@ __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint
 
 // K3: kept bytes per block.
 __global__ __launch_bounds__(kFaThreads) void fa_count_kernel(const uint8_t *__restrict__ in, uint64_t n,
-                                                              const long long *__restrict__ carry,
+                                                              const long long *__restrict__ carry, int start_state,
                                                               uint32_t *__restrict__ kept)
 {
     __shared__ long long sh[4];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kFaThreads) void fa_count_kernel(const uint8_t *__r
     const long long prev = fa_block_exclusive_max(mine, carry[blockIdx.x], sh);
     uint32_t keep;
     uint8_t out[kFaPerThread];
-    fa_classify(in, n, i0, prev, keep, out);
+    fa_classify(in, n, i0, prev, start_state, keep, out);
     uint32_t c = __popc(keep);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void fa_offset_kernel(const uint32_t *__restri
 
 // K5: write the kept bytes of each block contiguously at offs[block].
 __global__ __launch_bounds__(kFaThreads) void fa_scatter_kernel(const uint8_t *__restrict__ in, uint64_t n,
-                                                                const long long *__restrict__ carry,
+                                                                const long long *__restrict__ carry, int start_state,
                                                                 const uint64_t *__restrict__ offs,
                                                                 uint8_t *__restrict__ flat)
 {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kFaThreads) void fa_scatter_kernel(const uint8_t *_
     const long long prev = fa_block_exclusive_max(mine, carry[blockIdx.x], sh);
     uint32_t keep;
     uint8_t out[kFaPerThread];
-    fa_classify(in, n, i0, prev, keep, out);
+    fa_classify(in, n, i0, prev, start_state, keep, out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = __popc(keep);
     uint32_t incl = c;

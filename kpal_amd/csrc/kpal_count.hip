@@ -8,6 +8,11 @@
 #include "chunk_kernels.hpp"
 #include "fasta_kernels.hpp"
 
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 static_assert(sizeof(ChunkPool) <= sizeof(kpal_ctx::chunk_pool_sent), "kpal_ctx::chunk_pool_sent holds a ChunkPool");
 
 // ----------------------------------------------------------------------------------------------
@@ -542,26 +547,6 @@ static int ensure_pinned(kpal_ctx *ctx)
     return KPAL_OK;
 }
 
-// Pageable host memory -> device through the two pinned staging buffers: the memcpy into one
-// overlaps the DMA out of the other.  ctx->stream waits for the last piece.
-static int h2d_staged(kpal_ctx *ctx, uint8_t *dev_dst, const uint8_t *host_src, size_t n)
-{
-    CHK(ensure_pinned(ctx));
-    const size_t stage = kpal_ctx::kStage;
-    int slot = 0, last = -1;
-    for (size_t off = 0; off < n; off += stage, slot ^= 1) {
-        const size_t len = std::min(stage, n - off);
-        if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // its previous DMA is done
-        staged_memcpy(ctx->pinned[slot], host_src + off, len);
-        HIPCHK(hipMemcpyAsync(dev_dst + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->copy_stream));
-        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
-        ctx->stage_used[slot] = true;
-        last = slot;
-    }
-    if (last >= 0) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[last], 0));
-    return KPAL_OK;
-}
-
 KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
 {
     CTX_ENTER(ctx);
@@ -595,50 +580,240 @@ KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbyt
     return KPAL_OK;
 }
 
-// Position of the first header ('>' at a line start) in a FASTA buffer, or nbytes if none.
-static size_t fasta_first_header(const uint8_t *buf, size_t nbytes)
+// ----------------------------------------------------------------------------------------------
+// FASTA ingest: text (a byte range of a file, or host memory) -> pinned staging -> device -> flattened on the device -> counted,
+// chunk i+1 being read, copied and flattened while chunk i is counted.  Nothing in the loop waits for the GPU except for the
+// flattened SIZE of the chunk before (read back asynchronously, needed on the host to launch its count), which is one whole
+// chunk old by then.
+// ----------------------------------------------------------------------------------------------
+static inline bool fa_host_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
+// blanks the flattening drops at the end of a line only (str.rstrip() of a latin-1 text handle), and the space it drops everywhere
+static inline bool fa_host_is_blank(uint8_t c) { return c == ' ' || c == 9 || c == 11 || c == 12 || (c >= 28 && c <= 31) || c == 0x85 || c == 0xA0; }
+
+// First byte of the first header line ('>' at a line start) of buf[0, n), or n.  at_line_start: buf[0] begins a line.
+static size_t fasta_first_header(const uint8_t *buf, size_t n, bool at_line_start)
 {
+    size_t next_cr = 0;        // position of the next '\r' at or after the scan position (n: none); found lazily, once per '\r'
+    bool cr_known = false;
+    auto next_eol = [&](size_t from) -> size_t {
+        if (!cr_known || next_cr < from) {
+            const void *cr = from < n ? memchr(buf + from, '\r', n - from) : nullptr;
+            next_cr = cr ? (size_t)((const uint8_t *)cr - buf) : n;
+            cr_known = true;
+        }
+        const size_t stop = next_cr;   // a '\n' beyond the next '\r' does not matter
+        const void *nl = from < stop ? memchr(buf + from, '\n', stop - from) : nullptr;
+        return nl ? (size_t)((const uint8_t *)nl - buf) : stop;
+    };
     size_t i = 0;
-    while (i < nbytes) {
-        if (buf[i] == '>') return i;
-        const void *nl = memchr(buf + i, '\n', nbytes - i);
-        const void *cr = memchr(buf + i, '\r', nbytes - i);
-        const uint8_t *e = (const uint8_t *)nl;
-        if (cr && (!e || (const uint8_t *)cr < e)) e = (const uint8_t *)cr;
-        if (!e) return nbytes;
-        i = (size_t)(e - buf) + 1;
+    if (!at_line_start) {
+        i = next_eol(0);
+        if (i >= n) return n;
+        ++i;
     }
-    return nbytes;
+    while (i < n) {
+        if (buf[i] == '>') return i;
+        i = next_eol(i);
+        if (i >= n) return n;
+        ++i;
+    }
+    return n;
 }
 
-// FASTA text (host) -> flat stream on the device: ctx->fa_flat holds *n_flat bytes afterwards.
-static int fasta_flatten_to_device(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint64_t *n_flat)
+struct FaSource {
+    int fd = -1;                       // a byte range [pos, end) of a file ...
+    const uint8_t *mem = nullptr;      // ... or of host memory (mem[pos .. end))
+    uint64_t pos = 0, end = 0;
+    const uint8_t *prefix = nullptr;   // text that logically precedes the range (a record's header and the bases before a cut)
+    size_t prefix_left = 0;
+    bool more() const { return prefix_left > 0 || pos < end; }
+};
+
+static bool pread_all(int fd, uint8_t *dst, size_t n, uint64_t off)
 {
-    *n_flat = 0;
-    const size_t first = fasta_first_header(host_buf, nbytes);
-    if (first >= nbytes) return KPAL_OK;   // no record: nothing to count (klib.py:111 yields nothing)
-    const uint64_t n = nbytes - first;
-    const uint32_t nblocks = (uint32_t)((n + kFaBlockBytes - 1) / kFaBlockBytes);
-    CHK(ensure(ctx, ctx->fa_raw, n + 64));
-    CHK(ensure(ctx, ctx->fa_flat, n + 64));
-    const size_t meta = (size_t)nblocks * (8 + 8 + 4) + (size_t)(nblocks + 1) * 8 + 64;
-    CHK(ensure(ctx, ctx->fa_meta, meta));
-    uint8_t *raw = (uint8_t *)ctx->fa_raw.p;
-    uint8_t *flat = (uint8_t *)ctx->fa_flat.p;
-    long long *last_eol = (long long *)ctx->fa_meta.p;
-    long long *carry = last_eol + nblocks;
-    uint64_t *offs = (uint64_t *)(carry + nblocks);
-    uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
-    // fa_raw is free: the previous call synchronised after its last reader (fa_scatter)
-    CHK(h2d_staged(ctx, raw, host_buf + first, n));
-    LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, last_eol);
-    LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
-    LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n, (const long long *)carry, kept);
-    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
-    LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, n,
-           (const long long *)carry, (const uint64_t *)offs, flat);
-    HIPCHK(hipMemcpyAsync(n_flat, offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    while (n) {
+        const ssize_t r = pread(fd, dst, n, (off_t)off);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;   // error, or the file is shorter than its size said
+        dst += r;
+        off += (uint64_t)r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+
+// The page cache hands a reader ~5-10 GB/s (one copy_to_user per thread); the link takes 55: the staging buffer is filled by
+// several readers at once.  KPAL_READ_THREADS (default 8, at most the hardware threads); pieces below 4 MiB are not split.
+static bool pread_parallel(int fd, uint8_t *dst, size_t n, uint64_t off)
+{
+    static const int configured = [] {
+        const char *e = getenv("KPAL_READ_THREADS");
+        int t = e ? atoi(e) : 8;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)t > hw) t = (int)hw;
+        return t < 1 ? 1 : (t > 64 ? 64 : t);
+    }();
+    const int parts = (int)std::min<size_t>((size_t)configured, n / ((size_t)4 << 20));
+    if (parts <= 1) return pread_all(fd, dst, n, off);
+    const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> workers;
+    std::vector<char> ok((size_t)parts, 1);
+    workers.reserve(parts - 1);
+    for (int i = 1; i < parts; ++i) {
+        const size_t o = (size_t)i * part;
+        if (o >= n) break;
+        const size_t len = std::min(part, n - o);
+        char *flag = &ok[(size_t)i];
+        try {
+            workers.emplace_back([=] { *flag = pread_all(fd, dst + o, len, off + o) ? 1 : 0; });
+        } catch (...) {   // no thread to be had: this part here (no exception may cross the C-ABI)
+            *flag = pread_all(fd, dst + o, len, off + o) ? 1 : 0;
+        }
+    }
+    ok[0] = pread_all(fd, dst, std::min(part, n), off) ? 1 : 0;
+    for (auto &w : workers) w.join();
+    for (char f : ok)
+        if (!f) return false;
+    return true;
+}
+
+// The next bytes of the source (at most `want`) into dst; returns how many (0: the end), -1 on a read error; *from_range = how
+// many of them came from [pos, end) (the others from the prefix).
+static long fa_fill(FaSource &s, uint8_t *dst, size_t want, size_t *from_range)
+{
+    size_t got = 0;
+    if (s.prefix_left) {
+        const size_t n = std::min(want, s.prefix_left);
+        memcpy(dst, s.prefix, n);
+        s.prefix += n;
+        s.prefix_left -= n;
+        got = n;
+    }
+    const size_t n = (size_t)std::min<uint64_t>(want - got, s.end - s.pos);
+    if (n) {
+        if (s.mem) staged_memcpy(dst + got, s.mem + s.pos, n);
+        else if (!pread_parallel(s.fd, dst + got, n, s.pos)) return -1;
+        s.pos += n;
+        got += n;
+    }
+    *from_range = n;
+    return (long)got;
+}
+
+// The pipeline.  count: the flattened chunks are counted into the running count (windows span chunk seams through the saved
+// tail of the chunk before, never a record boundary: every header leaves a '\n' in the stream); else they are copied to host_out.
+static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *host_out, uint64_t *n_out)
+{
+    const size_t stage = ctx->fa_chunk, pad = kpal_ctx::kStagePad;
+    const size_t km1 = count ? (size_t)ctx->k - 1 : 0;
+    CHK(ensure_pinned(ctx));
+    if (!ctx->fa_nflat_host) {
+        hipError_t e = hipHostMalloc((void **)&ctx->fa_nflat_host, 64, hipHostMallocDefault);
+        if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    CHK(ensure(ctx, ctx->fa_tail, 64));
+    const uint32_t max_blocks = (uint32_t)((stage + kFaBlockBytes - 1) / kFaBlockBytes);
+    for (int i = 0; i < 2; ++i) {
+        CHK(ensure(ctx, ctx->fa_raw[i], stage + 64));
+        CHK(ensure(ctx, ctx->fa_flat[i], stage + pad + 64));
+        CHK(ensure(ctx, ctx->fa_meta[i], (size_t)max_blocks * (8 + 8 + 4) + (size_t)(max_blocks + 1) * 8 + 64));
+    }
+    int state = 0;               // what the next chunk's first byte continues (fasta_kernels.hpp: 0 line start, 1 header, 2 sequence)
+    bool skipping = true;        // only text before the first header so far: dropped (klib.py:111: SeqIO starts at the first '>')
+    bool at_line_start = true;
+    int prev_slot = -1;          // the chunk that has been flattened but not consumed yet
+    uint64_t flat_total = 0;     // flattened bytes of the chunks consumed so far (this feed)
+    uint64_t out_total = 0;
+
+    auto consume = [&](int slot) -> int {
+        HIPCHK(hipEventSynchronize(ctx->ev_done[slot]));   // (its flattening finished about one chunk ago)
+        const uint64_t nf = ctx->fa_nflat_host[slot];
+        uint8_t *flat = (uint8_t *)ctx->fa_flat[slot].p + pad;
+        if (!count) {
+            if (nf) HIPCHK(hipMemcpyAsync(host_out + out_total, flat, nf, hipMemcpyDeviceToHost, ctx->stream));
+            out_total += nf;
+            return KPAL_OK;
+        }
+        const size_t h = (size_t)std::min<uint64_t>(km1, flat_total);    // flattened bytes of this feed that precede the chunk
+        if (h) HIPCHK(hipMemcpyAsync(flat - h, ctx->fa_tail.p, h, hipMemcpyDeviceToDevice, ctx->stream));
+        const size_t h2 = (size_t)std::min<uint64_t>(km1, h + nf);       // ... and the next one: the last bytes of [flat - h, flat + nf)
+        if (h2) HIPCHK(hipMemcpyAsync(ctx->fa_tail.p, flat + nf - h2, h2, hipMemcpyDeviceToDevice, ctx->stream));
+        if (nf) CHK(count_device_range(ctx, flat, (size_t)nf, h));
+        flat_total += nf;
+        return KPAL_OK;
+    };
+
+    int slot = 0;
+    while (src.more()) {
+        if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // the slot's previous DMA out of the pinned buffer
+        uint8_t *hp = (uint8_t *)ctx->pinned[slot];
+        size_t from_range = 0;
+        const long got = fa_fill(src, hp, stage, &from_range);
+        if (got < 0) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
+        if (got == 0) break;
+        size_t n = (size_t)got;
+        if (src.more()) {
+            // never cut inside a run of blanks: whether a blank trails its line is decided from the bytes that follow it
+            size_t t = n;
+            while (t > 0 && fa_host_is_blank(hp[t - 1])) --t;
+            if (t > 0 && n - t <= from_range) {
+                src.pos -= n - t;
+                n = t;
+            }
+        }
+        size_t first = 0;
+        if (skipping) {
+            first = fasta_first_header(hp, n, at_line_start);
+            if (first >= n) {
+                at_line_start = fa_host_is_eol(hp[n - 1]);
+                continue;               // (the pinned slot is reused: nothing was queued on it)
+            }
+            skipping = false;
+            state = 0;
+        }
+        const uint8_t *chunk = hp + first;
+        const size_t m = n - first;
+        // what the chunk after this one continues: the chunk's last line
+        int next_state;
+        {
+            size_t e = m;
+            while (e > 0 && !fa_host_is_eol(chunk[e - 1])) --e;      // e = one past the last end of line (0: none)
+            if (e == 0) next_state = state == 0 ? (chunk[0] == '>' ? 1 : 2) : state;
+            else if (e == m) next_state = 0;
+            else next_state = chunk[e] == '>' ? 1 : 2;
+        }
+        const uint32_t nblocks = (uint32_t)((m + kFaBlockBytes - 1) / kFaBlockBytes);
+        uint8_t *raw = (uint8_t *)ctx->fa_raw[slot].p;
+        uint8_t *flat = (uint8_t *)ctx->fa_flat[slot].p + pad;
+        long long *last_eol = (long long *)ctx->fa_meta[slot].p;
+        long long *carry = last_eol + nblocks;
+        uint64_t *offs = (uint64_t *)(carry + nblocks);
+        uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
+        // the device copy of the raw text is free once the flattening that read it is done (two chunks ago)
+        if (ctx->stage_used[slot]) HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[slot], 0));
+        HIPCHK(hipMemcpyAsync(raw, chunk, m, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+        LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, last_eol);
+        LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
+        LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)carry, state, kept);
+        LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
+        LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m,
+               (const long long *)carry, state, (const uint64_t *)offs, flat);
+        HIPCHK(hipMemcpyAsync(&ctx->fa_nflat_host[slot], offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
+        ctx->stage_used[slot] = true;
+        // the chunk before: its flattened size has long arrived; its count is queued behind this chunk's flattening
+        if (prev_slot >= 0) CHK(consume(prev_slot));
+        prev_slot = slot;
+        slot ^= 1;
+        state = next_state;
+    }
+    if (prev_slot >= 0) CHK(consume(prev_slot));
+    if (!count) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        *n_out = out_total;
+    }
     return KPAL_OK;
 }
 
@@ -648,10 +823,43 @@ KPAL_API int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_
     if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_fasta before kpal_count_begin");
     if (nbytes == 0) return KPAL_OK;
     if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
-    uint64_t n_flat = 0;
-    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
-    if (n_flat == 0) return KPAL_OK;
-    return count_device_range(ctx, (const uint8_t *)ctx->fa_flat.p, (size_t)n_flat, 0);
+    FaSource src;
+    src.mem = host_buf;
+    src.end = nbytes;
+    return fasta_pipeline(ctx, src, true, nullptr, nullptr);
+}
+
+KPAL_API int kpal_count_feed_fasta_file(kpal_ctx *ctx, const char *path, uint64_t begin, uint64_t end, const uint8_t *prefix, size_t prefix_len)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_fasta_file before kpal_count_begin");
+    if (!path) return set_err(KPAL_E_INVALID, "path is NULL");
+    if (prefix_len && !prefix) return set_err(KPAL_E_INVALID, "prefix is NULL");
+    if (prefix_len > ((size_t)1 << 20)) return set_err(KPAL_E_INVALID, "prefix longer than 1 MiB");
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return set_err(KPAL_E_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return set_err(KPAL_E_IO, "%s is not a regular file", path);
+    }
+    const uint64_t size = (uint64_t)st.st_size;
+    if (end == 0) end = size;
+    if (begin > end || end > size) {
+        close(fd);
+        return set_err(KPAL_E_INVALID, "byte range %llu..%llu outside %s (%llu bytes)", (unsigned long long)begin, (unsigned long long)end, path,
+                       (unsigned long long)size);
+    }
+    (void)posix_fadvise(fd, (off_t)begin, (off_t)(end - begin), POSIX_FADV_SEQUENTIAL);
+    FaSource src;
+    src.fd = fd;
+    src.pos = begin;
+    src.end = end;
+    src.prefix = prefix;
+    src.prefix_left = prefix_len;
+    const int rc = fasta_pipeline(ctx, src, true, nullptr, nullptr);
+    close(fd);
+    return rc;
 }
 
 KPAL_API int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, uint8_t *host_out, uint64_t *n_out)
@@ -660,14 +868,10 @@ KPAL_API int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t n
     if (!n_out || (nbytes && (!host_buf || !host_out))) return set_err(KPAL_E_INVALID, "NULL pointer");
     *n_out = 0;
     if (nbytes == 0) return KPAL_OK;
-    uint64_t n_flat = 0;
-    CHK(fasta_flatten_to_device(ctx, host_buf, nbytes, &n_flat));
-    if (n_flat) {
-        HIPCHK(hipMemcpyAsync(host_out, ctx->fa_flat.p, n_flat, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    *n_out = n_flat;
-    return KPAL_OK;
+    FaSource src;
+    src.mem = host_buf;
+    src.end = nbytes;
+    return fasta_pipeline(ctx, src, false, host_out, n_out);
 }
 
 KPAL_API int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,

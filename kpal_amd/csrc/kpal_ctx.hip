@@ -111,6 +111,10 @@ static int ctx_init(kpal_ctx *ctx, int device)
         }
     }
     if (const char *e = getenv("KPAL_LEVEL2")) ctx->level2_mode = atoi(e);
+    if (const char *e = getenv("KPAL_FASTA_CHUNK")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 16 && v <= kpal_ctx::kStage) ctx->fa_chunk = (size_t)v;
+    }
     if (const char *e = getenv("KPAL_QUAD_STEPS")) ctx->quad_steps_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_STEPS2")) ctx->quad_steps2_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_VERBOSE")) ctx->quad_verbose = atoi(e) != 0;
@@ -163,11 +167,12 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)kpal_comm_destroy(ctx);
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->direct_list, &ctx->direct_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw, &ctx->fa_flat, &ctx->fa_meta, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->direct_list, &ctx->direct_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw[0], &ctx->fa_raw[1], &ctx->fa_flat[0], &ctx->fa_flat[1], &ctx->fa_meta[0], &ctx->fa_meta[1], &ctx->fa_tail, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (ctx->fa_nflat_host) (void)hipHostFree(ctx->fa_nflat_host);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
         if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);

@@ -113,7 +113,11 @@ struct kpal_ctx {
     uint32_t chunk_meta_y = 0;               // coarse-bucket count the meta layout was cleared for
     uint32_t *chunk_error_word = nullptr;
     DevBuf residuals, cnt1, offs1, start1;  // two-level path (k = 13..16)
-    DevBuf fa_raw, fa_flat, fa_meta;          // FASTA ingest
+    // FASTA ingest (kpal_count.hip): raw text and flattened stream of two chunks in flight, scan metadata, the flattened tail of
+    // the previous chunk (the k-1 bytes the next one's first windows begin in), the chunks' flattened sizes in pinned host memory
+    DevBuf fa_raw[2], fa_flat[2], fa_meta[2], fa_tail;
+    uint64_t *fa_nflat_host = nullptr;
+    size_t fa_chunk = kStage;                // text bytes per chunk (KPAL_FASTA_CHUNK: tests put the seams everywhere)
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
     static constexpr size_t kStagePad = 64;

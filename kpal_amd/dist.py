@@ -9,7 +9,19 @@ reads into a private device table and the only collective is ONE
 ``torch.distributed.reduce(SUM, int64)`` of 4^k elements to rank 0 (backend ``nccl`` == RCCL;
 integer addition makes the result bit-exact for any ring/tree order).  The reference itself has
 no parallelism of any kind.
+
+FASTA input (BASELINE north_star: "input FASTA shards partitioned embarrassingly across the 8 GPUs of one node
+with a single RCCL reduce"): ``fasta_shards`` cuts one or several FASTA files into ``world`` byte ranges of about equal size --
+at record boundaries where there is one near the ideal cut, else INSIDE a record at a line start (or, in a line longer than
+64 KiB, anywhere), in which case the right-hand range carries the k - 1 bases before the cut as a read-only halo: every k-mer
+window is counted by exactly one rank.  ``count_fasta_sharded`` counts a rank's ranges (``kpal_count_feed_fasta_file``: the
+library reads the file itself), the tables are merged by the one reduce.  ``python -m kpal_amd.dist count ...`` (under
+``torch.distributed.run``, or alone) is the runnable entry: one profile over all input files, written by rank 0.
 """
+import collections
+import mmap
+import os
+
 import numpy as np
 
 
@@ -29,7 +41,7 @@ def reduce_counts(table, dst=0, group=None):
     ``table``: torch int64 tensor (a CUDA tensor under ``nccl``/RCCL; a CPU tensor under ``gloo``
     in the CPU tests).  Reduced in place; only ``dst`` holds the full sum afterwards."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(table, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return table
 
@@ -192,3 +204,200 @@ class TableReducer(object):
 
     def result_ptr(self):
         return self._result.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# FASTA shards
+# ----------------------------------------------------------------------------------------------------------------------
+FastaSegment = collections.namedtuple('FastaSegment', 'path begin end prefix')
+FastaSegment.__doc__ = """Bytes ``[begin, end)`` of the FASTA file ``path``; ``prefix``: text that logically precedes them (``b''``, or
+``b'>\\n'`` + the k - 1 sequence bytes before a cut inside a record)."""
+
+_LONG_LINE = 64 << 10     # a cut inside a longer line does not move back to the line's start
+_BLANKS = frozenset(b' \t\x0b\x0c\x1c\x1d\x1e\x1f\x85\xa0')   # what the flattening drops at the end of a line (fasta_kernels.hpp)
+
+
+def _line_start(mm, o):
+    """Start of the line that contains byte ``o`` (lines end at ``\\n`` or ``\\r``)."""
+    a = mm.rfind(b'\n', 0, o)
+    b = mm.rfind(b'\r', max(a, 0), o)      # only a later one matters
+    return max(a, b) + 1
+
+
+def _last_header(mm, before):
+    """Start of the last header line (``>`` at a line start) that begins before ``before``, or -1."""
+    a = mm.rfind(b'\n>', 0, before)
+    b = mm.rfind(b'\r>', max(a, 0), before)
+    at = max(a, b)
+    if at >= 0:
+        return at + 1
+    return 0 if before > 0 and mm[0:1] == b'>' else -1
+
+
+def _flatten_fragment(raw):
+    """Sequence bytes of a fragment of ONE record's sequence lines (no header inside), as the device flattening and
+    ``klib._fasta_records`` produce them: every line right-stripped, spaces and line ends removed."""
+    text = raw.decode('latin-1')
+    return ''.join(line.rstrip() for line in text.replace('\r', '\n').split('\n')).replace(' ', '').encode('latin-1')
+
+
+def _cut(mm, o, k):
+    """A cut of the text near byte ``o`` (0 < o < len(mm)): -> (offset, prefix) with offset <= o.  The offset is the start of a
+    header line (prefix empty: a record boundary), or lies inside a record -- at a line start, or for lines longer than 64 KiB
+    wherever ``o`` fell (moved left past blanks) -- and then ``prefix`` is ``b'>\\n'`` + the last k - 1 sequence bytes of that
+    record before the offset: the right-hand range counts the windows that reach across the cut, the left-hand one only those
+    that end before it."""
+    ls = _line_start(mm, o)
+    if mm[ls:ls + 1] == b'>':
+        return ls, b''
+    at = ls
+    if o - ls > _LONG_LINE:
+        at = o
+        while at > ls and mm[at - 1] in _BLANKS:
+            at -= 1
+    hdr = _last_header(mm, at)
+    if hdr < 0:
+        return at, b''                       # text before the first header: ignored by whoever reads it
+    # the record's sequence starts after its header line
+    e = hdr
+    n = len(mm)
+    while e < n and mm[e] not in (10, 13):
+        e += 1
+    seq_start = min(e + 1, n)
+    if at <= seq_start or k <= 1:
+        return at, b'>\n'
+    want = k - 1
+    window = 4096
+    while True:
+        lo = max(seq_start, at - window)     # (a fragment may begin inside a line: only line ENDS are stripped)
+        flat = _flatten_fragment(mm[lo:at])
+        if len(flat) >= want or lo <= seq_start:
+            return at, b'>\n' + flat[-want:]
+        window *= 4
+
+
+def fasta_shards(paths, world, k):
+    """Cut the FASTA files ``paths`` (their concatenation, in order) into ``world`` shards of about equal size:
+    -> ``world`` lists of :class:`FastaSegment`.  Counting every segment of every shard and adding the tables gives the
+    profile of all records of all files (kpal/klib.py:97-112 on each file, merged with ``sum``: doc/tutorial.rst:94-95)."""
+    if isinstance(paths, (str, bytes, os.PathLike)):
+        paths = [paths]
+    paths = [os.fspath(p) for p in paths]
+    if world < 1:
+        raise ValueError('bad world size %r' % (world,))
+    k = int(k)
+    sizes = [os.path.getsize(p) for p in paths]
+    total = sum(sizes)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    # the cut points: (file index, offset, prefix), the first at the very beginning, the last at the very end
+    cuts = [(0, 0, b'')]
+    for r in range(1, world):
+        c = r * total // world
+        f = int(np.searchsorted(starts, c, side='right')) - 1
+        f = min(max(f, 0), len(paths) - 1)
+        o = c - int(starts[f])
+        if o <= 0 or sizes[f] == 0:
+            cuts.append((f, 0, b''))
+            continue
+        with open(paths[f], 'rb') as fh:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                off, prefix = _cut(mm, min(o, sizes[f] - 1), k)
+            finally:
+                mm.close()
+        cuts.append((f, off, prefix))
+    cuts.append((len(paths) - 1, sizes[-1] if sizes else 0, b''))
+    for i in range(1, len(cuts)):            # moving a cut back to a line start must not pass the cut before it
+        if (cuts[i][0], cuts[i][1]) < (cuts[i - 1][0], cuts[i - 1][1]):
+            cuts[i] = cuts[i - 1]
+    shards = []
+    for r in range(world):
+        (f0, o0, prefix), (f1, o1, _) = cuts[r], cuts[r + 1]
+        segs = []
+        for f in range(f0, f1 + 1):
+            begin = o0 if f == f0 else 0
+            end = o1 if f == f1 else sizes[f]
+            if end > begin:
+                segs.append(FastaSegment(paths[f], begin, end, prefix if f == f0 else b''))
+        shards.append(segs)
+    return shards
+
+
+def count_fasta_sharded(ctx, k, segments, strategy='auto'):
+    """Count one rank's shard (``fasta_shards(...)[rank]``) into the context's device table: ``kpal_count_begin`` + one
+    ``kpal_count_feed_fasta_file`` per segment.  The caller then merges the tables (``Context.comm_reduce_table``, or
+    ``reduce_counts(table_as_tensor(ctx))``)."""
+    ctx.count_begin(k, strategy)
+    for seg in segments:
+        ctx.count_feed_fasta_file(seg.path, seg.begin, seg.end, seg.prefix)
+
+
+def segment_text(seg):
+    """The FASTA text a segment stands for (its prefix + its bytes of the file): what a rank counts (tests, small inputs)."""
+    with open(seg.path, 'rb') as fh:
+        fh.seek(seg.begin)
+        return seg.prefix + fh.read(seg.end - seg.begin)
+
+
+def profile_from_fasta_sharded(paths, k, name=None, root=0):
+    """One :class:`kpal_amd.klib.Profile` over all records of the FASTA files ``paths``, counted by all ranks of the current
+    ``torch.distributed`` job (one process per GPU; without an initialised process group: this process alone): shards by
+    ``fasta_shards``, one reduce(SUM) of the int64 tables to ``root``.  Returns the profile on ``root``, None elsewhere."""
+    from . import _native, klib
+    try:
+        import torch.distributed as td
+        grouped = td.is_available() and td.is_initialized()
+    except ImportError:
+        grouped = False
+    rank, world = (td.get_rank(), td.get_world_size()) if grouped else (0, 1)
+    ctx = _native.context()
+    count_fasta_sharded(ctx, k, fasta_shards(paths, world, k)[rank])
+    if grouped:
+        ctx.count_finish(to_host=False)
+        table = table_as_tensor(ctx)
+        ctx.sync()
+        reduce_counts(table, dst=root)
+        import torch
+        torch.cuda.current_stream().synchronize()
+    if rank != root:
+        return None
+    return klib.Profile(ctx.count_finish(), name=name)
+
+
+def main(argv=None):
+    """``python -m kpal_amd.dist count [-k K] [--name NAME] IN.fa [IN.fa ...] OUT.k`` -- `kpal count` over all GPUs of the node:
+    start it with ``python -m torch.distributed.run --nproc-per-node N -m kpal_amd.dist count ...`` (one process per GPU), or
+    plainly for one GPU.  ONE profile over all input files is written (kpal count writes one per file; merging them with
+    `kpal merge` gives this profile, doc/tutorial.rst:94-95)."""
+    import argparse
+    ap = argparse.ArgumentParser(prog='python -m kpal_amd.dist', description=main.__doc__)
+    sub = ap.add_subparsers(dest='command', required=True)
+    c = sub.add_parser('count', help='count the k-mers of FASTA files, sharded over the ranks')
+    c.add_argument('-k', dest='size', type=int, default=9, help='k-mer size (default: %(default)s)')      # kmer.py:789
+    c.add_argument('--name', default=None, help='profile name (default: the first file\'s base name)')
+    c.add_argument('inputs', nargs='+', metavar='INPUT', help='FASTA files')
+    c.add_argument('output', metavar='OUTPUT', help='k-mer profile file (HDF5)')
+    args = ap.parse_args(argv)
+    grouped = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ      # started by torch.distributed.run (any world size)
+    if grouped:
+        import torch
+        import torch.distributed as td
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        td.init_process_group('nccl', device_id=torch.device('cuda', local))
+    name = args.name or os.path.splitext(os.path.basename(args.inputs[0]))[0]
+    profile = profile_from_fasta_sharded(args.inputs, args.size, name=name)
+    if profile is not None:
+        from . import files
+        handle = files.ProfileFileType('w')(args.output)
+        profile.save(handle)
+        handle.close()
+    if grouped:
+        td.barrier()
+        td.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

@@ -18,8 +18,12 @@ There is no CPU fallback for those paths: without libkpal_hip.so or without a GP
 Container-only helpers (``merge``, ``shrink``, ``shuffle``, statistics, printers, HDF5 I/O) are
 not part of the hot path and use NumPy like the reference.
 """
+import codecs
+import io
 import itertools
 import math
+import os
+import stat
 
 import numpy as np
 
@@ -52,6 +56,38 @@ def _fasta_records(handle):
             parts.append(line.rstrip())
     if name is not None:
         yield name, ''.join(parts).translate(_DROPPED)
+
+
+def _plain_file(handle):
+    """``(path, byte position)`` when ``handle`` is an ordinary file opened for reading whose raw bytes ARE its text and whose
+    position is known -- an ``open(path)`` / ``open(path, 'rb')`` / ``argparse.FileType('r')`` handle on a regular file, in an
+    ASCII-compatible encoding, not yet read from (text mode) or at any position (binary mode) -- else None (StringIO, pipes,
+    gzip / bz2 wrappers, sockets, handles somebody has read from ...).  The library then reads the file itself
+    (``kpal_count_feed_fasta_file``); ``/proc/self/fd/N`` names the open file whatever its path was."""
+    raw = handle
+    text_mode = isinstance(handle, io.TextIOWrapper)
+    if text_mode:
+        try:
+            if codecs.lookup(handle.encoding or '').name not in ('utf-8', 'ascii', 'iso8859-1'):
+                return None
+        except LookupError:
+            return None
+        raw = handle.buffer
+    if isinstance(raw, io.BufferedReader):
+        raw = raw.raw
+    if type(raw) is not io.FileIO or not raw.readable():
+        return None
+    try:
+        fd = raw.fileno()
+        if not stat.S_ISREG(os.fstat(fd).st_mode):
+            return None
+        position = handle.tell()
+    except (OSError, ValueError):
+        return None
+    if text_mode and position != 0:      # (a text handle's tell() is an opaque cookie anywhere but at the start)
+        return None
+    path = '/proc/self/fd/%d' % fd
+    return (path, position) if os.path.exists(path) else None
 
 
 def _first_boundary(text):
@@ -135,9 +171,23 @@ class Profile(object):
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         ctx = _native.context()
         ctx.count_begin(length)
+        plain = _plain_file(handle)
+        if plain is not None:
+            # an ordinary file: the library reads it itself -- parallel preads into pinned memory, H2D copy, flattening and
+            # counting pipelined chunk by chunk; no byte of the text passes through Python
+            ctx.count_feed_fasta_file(plain[0], plain[1], 0)
+            handle.seek(0, os.SEEK_END)      # the handle has been consumed, as by the reference's SeqIO.parse loop
+            return cls(ctx.count_finish(), name=name)
+        reader = handle
+        if isinstance(handle, io.TextIOWrapper):
+            try:                              # a pipe or a decompressing wrapper in an ASCII-compatible text encoding: its bytes, undecoded
+                if codecs.lookup(handle.encoding or '').name in ('utf-8', 'ascii', 'iso8859-1') and handle.tell() == 0:
+                    reader = handle.buffer
+            except (LookupError, OSError, ValueError):
+                reader = handle
         carry = b''   # the unfinished last record of the previous chunk (small)
         while True:
-            text = handle.read(_FASTA_CHUNK)
+            text = reader.read(_FASTA_CHUNK)
             if not text:
                 break
             if not isinstance(text, bytes):

@@ -122,6 +122,92 @@ def test_shard_range():
         dist.shard_range(10, 2, 2)
 
 
+def fasta_corpus(tmp_path):
+    """FASTA files that stress the shard cutter: -> {name: path}.  Many short records; one giant record in 60-column lines;
+    one giant record on ONE line (cuts fall inside the line); CRLF line ends; text before the first header, blank lines,
+    blanks inside and at the end of lines, an empty record, lower case and N runs; the tutorial files."""
+    import oracle
+    rs = np.random.RandomState(7)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+
+    def seq(n, noisy=False):
+        s = acgt[rs.randint(0, 4, n)].copy()
+        if noisy and n > 50:
+            for _ in range(n // 200 + 1):
+                at = rs.randint(0, n - 8)
+                s[at:at + rs.randint(1, 8)] = ord('N')
+            low = rs.randint(0, n, n // 50)
+            s[low] |= 0x20
+        return s.tobytes().decode()
+
+    def wrap(s, width=60, eol='\n'):
+        return eol.join(s[i:i + width] for i in range(0, len(s), width)) + eol
+
+    files = {}
+    files['many'] = ''.join('>r%d some description\n%s' % (i, wrap(seq(rs.randint(0, 700), True))) for i in range(400))
+    files['giant_wrapped'] = '>chr1\n' + wrap(seq(300000, True))
+    files['giant_one_line'] = '>chrU\n' + seq(250000, True) + '\n>tail\nACGTTGCA\n'
+    files['crlf'] = ''.join('>c%d\r\n%s' % (i, wrap(seq(rs.randint(1, 500)), 70, '\r\n')) for i in range(150))
+    files['messy'] = ('no header yet\nACGTACGTACGT\n\n>m1  x\nAC GT\tAC \nGGTT\t\n\n  \nACGTAC\n>\n>m3\n' + wrap(seq(5000, True), 33) +
+                      '>m4\n' + wrap(seq(20000), 80) + '\n>m5\nAC\n')
+    files['no_record'] = 'just text\nACGTACGT\n'
+    out = {}
+    for name, text in files.items():
+        p = tmp_path / (name + '.fa')
+        p.write_bytes(text.encode('latin-1'))
+        out[name] = str(p)
+    tut = os.path.join(ROOT, 'tests', 'golden', 'tutorial')
+    for f in sorted(os.listdir(tut))[:3]:
+        if f.endswith('.fa'):
+            out['tutorial_' + f] = os.path.join(tut, f)
+    return out
+
+
+def records_of(path):
+    from kpal_amd import klib
+    with open(path, encoding='latin-1', newline='') as fh:
+        return [s for _, s in klib._fasta_records(io.StringIO(fh.read().replace('\r\n', '\n').replace('\r', '\n')))]
+
+
+def test_fasta_shards_tile_the_input_and_count_every_window_once(tmp_path, monkeypatch):
+    """kpal_amd.dist.fasta_shards (north_star: FASTA shards across the GPUs): for world sizes 1..9 and several k
+    the shards' byte ranges tile the files exactly, every range begins at a header line or carries the halo prefix of a cut
+    inside a record, and the SUM of the per-shard counts -- each shard tokenised and counted on its own, the oracle standing
+    in for the GPU -- equals the count of all records of all files (kpal/klib.py:97-112 per file, merged by `sum`:
+    doc/tutorial.rst:94-95)."""
+    import oracle
+    from kpal_amd import dist, klib
+    corpus = fasta_corpus(tmp_path)
+    monkeypatch.setattr(dist, '_LONG_LINE', 1000)      # (64 KiB: a cut moves back to its line's start unless that is further away)
+    cases = [[corpus[n]] for n in sorted(corpus)] + [[corpus['many'], corpus['giant_one_line'], corpus['no_record'], corpus['messy']]]
+    for paths in cases:
+        for k in (1, 2, 5, 12):
+            want = oracle.from_sequences([s for p in paths for s in records_of(p)], k)
+            for world in (1, 2, 3, 4, 7, 9):
+                shards = dist.fasta_shards(paths, world, k)
+                assert len(shards) == world
+                # the ranges tile every file, in order
+                covered = {p: 0 for p in paths}
+                for segs in shards:
+                    for seg in segs:
+                        assert seg.begin == covered[seg.path] and seg.end > seg.begin, (paths, world, seg)
+                        covered[seg.path] = seg.end
+                assert all(covered[p] == os.path.getsize(p) for p in paths)
+                got = np.zeros(4 ** k, dtype=np.int64)
+                for segs in shards:
+                    for seg in segs:
+                        assert len(seg.prefix) <= 2 + max(k - 1, 0)
+                        text = dist.segment_text(seg).decode('latin-1').replace('\r\n', '\n').replace('\r', '\n')
+                        got += oracle.from_sequences([s for _, s in klib._fasta_records(io.StringIO(text))], k)
+                np.testing.assert_array_equal(got, want, err_msg='%r k=%d world=%d' % (paths, k, world))
+    # sizes are balanced where the text allows it: one giant record is cut inside
+    for name in ('giant_wrapped', 'giant_one_line'):
+        shards = dist.fasta_shards(corpus[name], 4, 12)
+        sizes = [sum(s.end - s.begin for s in segs) for segs in shards]
+        assert max(sizes) < 1.3 * min(sizes), (name, sizes)
+        assert any(seg.prefix for segs in shards for seg in segs)
+
+
 _GLOO_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
@@ -178,6 +264,24 @@ for mode in ('int64', 'u32'):
                     assert red.steps_u32 == 0
 if rank == 0:
     print('REDUCER_OK')
+# FASTA shards (kpal_amd.dist.fasta_shards): every rank tokenises and counts ITS byte ranges, one reduce, rank 0 compares
+# with the count of all records of all files
+import io
+from kpal_amd import klib
+paths = %(fasta)r
+def records(text):
+    return [s for _, s in klib._fasta_records(io.StringIO(text.decode('latin-1').replace('\\r\\n', '\\n').replace('\\r', '\\n')))]
+for k in (4, 9):
+    mine = np.zeros(4 ** k, dtype=np.int64)
+    for seg in dist.fasta_shards(paths, world, k)[rank]:
+        mine += oracle.from_sequences(records(dist.segment_text(seg)), k)
+    t = torch.from_numpy(mine)
+    dist.reduce_counts(t, dst=0)
+    if rank == 0:
+        want = oracle.from_sequences([s for p in paths for s in records(open(p, 'rb').read())], k)
+        assert np.array_equal(t.numpy(), want), 'FASTA shards: merged counts differ from the whole-file count (k=%%d)' %% k
+if rank == 0:
+    print('FASTA_SHARDS_OK')
 td.barrier()
 td.destroy_process_group()
 '''
@@ -187,7 +291,9 @@ def test_world_size_2_gloo_reduce(tmp_path):
     """N > 1 path on CPU: shard reads over 2 ranks, reduce the int64 tables with one collective
     (gloo here, RCCL on the GPUs), compare with the single-stream count."""
     script = tmp_path / 'worker.py'
-    script.write_text(_GLOO_WORKER % {'root': ROOT})
+    corpus = fasta_corpus(tmp_path)
+    fasta = [corpus['many'], corpus['giant_wrapped'], corpus['messy'], corpus['giant_one_line']]
+    script.write_text(_GLOO_WORKER % {'root': ROOT, 'fasta': fasta})
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', WORLD_SIZE='2')
     procs = []
     for rank in range(2):
@@ -197,6 +303,7 @@ def test_world_size_2_gloo_reduce(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GLOO_OK %d' % (1001 * 145) in outs[0]
     assert 'REDUCER_OK' in outs[0], outs[0]
+    assert 'FASTA_SHARDS_OK' in outs[0], outs[0]
 
 
 def test_quad2_index_arithmetic(tmp_path):

@@ -180,3 +180,197 @@ def test_from_fasta_by_record_batched(ctx, monkeypatch):
     np.testing.assert_array_equal(t[2], oracle.from_sequences(['TTTT'], 2))
     with pytest.raises(ValueError):
         ctx.count_records(2, flat, [0, 9, 8, 15])
+
+
+def test_chunk_seams_everywhere(tmp_path):
+    """The pipelined ingest (kpal_count_feed_fasta / _file: chunks cut ANYWHERE, flattened with the state the previous chunk
+    left -- line start / inside a header / inside a sequence line --, k-mer windows carried across the seams by the saved tail)
+    with the chunk size forced down to 16 .. 5000 bytes (KPAL_FASTA_CHUNK), so that seams fall inside headers, between '\\r'
+    and '\\n', inside runs of blanks, before the first header, and chunks flatten to fewer than k - 1 bytes: flattened stream
+    and counts against the host tokeniser and the oracle, from memory and from a file (any begin / end / prefix)."""
+    from kpal_amd import _native
+    rnd = random.Random(31)
+    texts = ['no header at all\nACGT\n', '>only header', '>h\nACGT', 'junk\njunk2\n>a desc\nAC\nGT\n>b\n\n>c\nTT',
+             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\nACGTACGTAC\r\n', '>t\nAC \t \nGT\tA  \t\nACGT\n', '>' + 'h' * 300 + '\nACGTACGTACGTACGT\n' * 5]
+    for _ in range(10):
+        texts.append(random_fasta(rnd, rnd.randint(1, 12), 3000, eol=rnd.choice(['\n', '\n', '\r\n'])))
+    texts.append(random_fasta(rnd, 3, 60000))
+    for chunk in (16, 17, 64, 100, 257, 4096, 5000):
+        os.environ['KPAL_FASTA_CHUNK'] = str(chunk)
+        try:
+            c = _native.Context(_native.default_device())
+        finally:
+            del os.environ['KPAL_FASTA_CHUNK']
+        for t, text in enumerate(texts):
+            if chunk < 64 and len(text) > 20000:
+                continue
+            raw = text.encode('latin-1')
+            assert c.fasta_flatten(raw) == expected_flat(text), (chunk, repr(text[:100]))
+            seqs = [s for _, s in seqio_records(text)]
+            path = tmp_path / ('c%d_%d.fa' % (chunk, t))
+            path.write_bytes(raw)
+            for k in (1, 3, 9, 16):
+                want = oracle.from_sequences(seqs, k)
+                c.count_begin(k)
+                c.count_feed_fasta(raw)
+                np.testing.assert_array_equal(c.count_finish(), want, err_msg='memory chunk=%d k=%d %r' % (chunk, k, text[:80]))
+                c.count_begin(k)
+                c.count_feed_fasta_file(str(path))
+                np.testing.assert_array_equal(c.count_finish(), want, err_msg='file chunk=%d k=%d %r' % (chunk, k, text[:80]))
+        c.close()
+
+
+def test_feed_fasta_file_ranges_and_errors(ctx, tmp_path):
+    """kpal_count_feed_fasta_file: byte ranges, a prefix, several feeds into one count (windows never span feeds), errors."""
+    text = b'>a\nACGTACGTAC\nGGTTAACC\n>b\nTTTTACGT\n'
+    path = tmp_path / 'r.fa'
+    path.write_bytes(text)
+    k = 4
+    whole = oracle.from_sequences(['ACGTACGTACGGTTAACC', 'TTTTACGT'], k)
+    ctx.count_begin(k)
+    ctx.count_feed_fasta_file(str(path))
+    np.testing.assert_array_equal(ctx.count_finish(), whole)
+    # the second record alone; the first alone through an explicit end
+    at = text.index(b'>b')
+    ctx.count_begin(k)
+    ctx.count_feed_fasta_file(str(path), at)
+    np.testing.assert_array_equal(ctx.count_finish(), oracle.from_sequences(['TTTTACGT'], k))
+    ctx.count_begin(k)
+    ctx.count_feed_fasta_file(str(path), 0, at)
+    np.testing.assert_array_equal(ctx.count_finish(), oracle.from_sequences(['ACGTACGTACGGTTAACC'], k))
+    # a cut inside record a, after its first line: the right-hand range with the k - 1 bases before the cut as prefix
+    cut = text.index(b'GGTT')
+    ctx.count_begin(k)
+    ctx.count_feed_fasta_file(str(path), 0, cut)
+    ctx.count_feed_fasta_file(str(path), cut, 0, b'>\n' + b'TAC')
+    np.testing.assert_array_equal(ctx.count_finish(), whole)
+    # without the prefix the range starts with text before its first header: ignored up to '>b'
+    ctx.count_begin(k)
+    ctx.count_feed_fasta_file(str(path), cut)
+    np.testing.assert_array_equal(ctx.count_finish(), oracle.from_sequences(['TTTTACGT'], k))
+    with pytest.raises(OSError):
+        ctx.count_feed_fasta_file(str(tmp_path / 'missing.fa'))
+    with pytest.raises(OSError):
+        ctx.count_feed_fasta_file(str(tmp_path))
+    with pytest.raises(ValueError):
+        ctx.count_feed_fasta_file(str(path), 10, 5)
+    with pytest.raises(ValueError):
+        ctx.count_feed_fasta_file(str(path), 0, len(text) + 1)
+    ctx.count_finish()
+
+
+def test_from_fasta_file_handles_take_the_library_reader(ctx, tmp_path, monkeypatch):
+    """Profile.from_fasta on ordinary file handles (text or binary, what `kpal count` opens) goes through
+    kpal_count_feed_fasta_file -- no text passes through Python; handles whose bytes are not their text (StringIO, gzip,
+    a handle somebody has read from in text mode, UTF-16) take the chunked reads.  Same counts either way."""
+    import gzip
+    from kpal_amd import _native, klib
+    rnd = random.Random(77)
+    text = 'junk\n' + random_fasta(rnd, 200, 2000)
+    seqs = [s for _, s in seqio_records(text)]
+    want = oracle.from_sequences(seqs, 10)
+    path = tmp_path / 'h.fa'
+    path.write_bytes(text.encode('latin-1'))
+    calls = []
+    real = _native.Context.count_feed_fasta_file
+    monkeypatch.setattr(_native.Context, 'count_feed_fasta_file', lambda self, *a, **kw: (calls.append(a), real(self, *a, **kw))[1])
+    for opener in (lambda: open(path), lambda: open(path, 'rb'), lambda: open(path, encoding='latin-1'), lambda: open(path, 'rb', buffering=0)):
+        with opener() as fh:
+            p = klib.Profile.from_fasta(fh, 10, name='x')
+            assert fh.read(1) in ('', b'')             # consumed
+        np.testing.assert_array_equal(p.counts, want)
+    assert len(calls) == 4
+    # a binary handle positioned after the junk line: the library starts there
+    with open(path, 'rb') as fh:
+        fh.readline()
+        p = klib.Profile.from_fasta(fh, 10)
+    np.testing.assert_array_equal(p.counts, want)
+    assert len(calls) == 5 and calls[-1][1] == 5
+    # not plain files
+    with gzip.open(str(path) + '.gz', 'wt', encoding='latin-1') as fh:
+        fh.write(text)
+    with open(str(path) + '.u16', 'w', encoding='utf-16') as fh:
+        fh.write(text.encode('latin-1').decode('latin-1'))
+    for opener in (lambda: io.StringIO(text), lambda: gzip.open(str(path) + '.gz', 'rt', encoding='latin-1'),
+                   lambda: gzip.open(str(path) + '.gz', 'rb'), lambda: open(str(path) + '.u16', encoding='utf-16')):
+        with opener() as fh:
+            p = klib.Profile.from_fasta(fh, 10)
+        np.testing.assert_array_equal(p.counts, want)
+    with open(path) as fh:
+        fh.readline()                                   # a text handle that has been read from: its position is opaque
+        p = klib.Profile.from_fasta(fh, 10)
+    np.testing.assert_array_equal(p.counts, want)
+    assert len(calls) == 5
+
+
+def test_multi_chunk_file_and_shards(ctx, tmp_path):
+    """A 200 MB FASTA file (several 64 MiB chunks in flight; one 150 Mbase record in 60-column lines after a few thousand short
+    ones): Profile.from_fasta against the oracle at k = 12; then the same file cut by kpal_amd.dist.fasta_shards for 1, 3 and 8
+    ranks -- every shard counted through kpal_count_feed_fasta_file, the tables added (on one GPU: into one count) -- equals
+    the whole-file profile: record-boundary cuts AND cuts inside the giant record with their halo prefixes."""
+    from kpal_amd import dist, klib
+    buf = oracle.synth_reads(23, 0, 1_000_000, 150, noisy=True)
+    seq = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)
+    short = oracle.synth_reads(24, 0, 5000, 150, noisy=True)
+    path = tmp_path / 'big.fa'
+    with open(path, 'wb') as fh:
+        for r in short.reshape(-1, 151):
+            fh.write(b'>read\n' + bytes(r[:150]) + b'\n')
+        fh.write(b'>chr1 synthetic\n')
+        lines = np.empty((seq.size // 60, 61), dtype=np.uint8)
+        lines[:, :60] = seq.reshape(-1, 60)
+        lines[:, 60] = 10
+        fh.write(lines.tobytes())
+        fh.write(b'>last\nACGTACGTACGTTTGA\n')
+    k = 12
+    want = oracle.count_flat(short, k, threads=8) + oracle.count_flat(seq, k, threads=16) + oracle.from_sequences(['ACGTACGTACGTTTGA'], k)
+    with open(path) as fh:
+        p = klib.Profile.from_fasta(fh, k)
+    np.testing.assert_array_equal(p.counts, want)
+    for world in (1, 3, 8):
+        shards = dist.fasta_shards(str(path), world, k)
+        sizes = [sum(s.end - s.begin for s in segs) for segs in shards]
+        assert sum(sizes) == os.path.getsize(path) and max(sizes) - min(sizes) < 1 << 20
+        if world > 1:
+            assert any(seg.prefix for segs in shards for seg in segs)
+        ctx.count_begin(k)
+        for segs in shards:
+            for seg in segs:
+                ctx.count_feed_fasta_file(seg.path, seg.begin, seg.end, seg.prefix)
+        np.testing.assert_array_equal(ctx.count_finish(), want, err_msg='world %d' % world)
+    # per-shard tables, added on the host (what the reduce does)
+    acc = np.zeros(4 ** k, dtype=np.int64)
+    for segs in dist.fasta_shards(str(path), 4, k):
+        dist.count_fasta_sharded(ctx, k, segs)
+        acc += ctx.count_finish()
+    np.testing.assert_array_equal(acc, want)
+
+
+def test_sharded_fasta_count_through_rccl_world_1(tmp_path, tutorial_dir):
+    """The multi-GPU FASTA entry as a user starts it -- python -m torch.distributed.run --nproc-per-node 1 -m kpal_amd.dist count
+    -k 8 a_1.fa a_2.fa out.k8 (world size 1 here: the process group and the reduce path are RCCL's) -- writes ONE profile over
+    both files: equal to the merge of the two per-file profiles (doc/tutorial.rst:94-95).  (h5py is not in this image: the
+    in-memory HDF5 stand-in of the CLI tests takes the file's place.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys, os, io\n'
+            'sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))\n'
+            'import numpy as np, memh5\n'
+            'from kpal_amd import files, dist, klib\n'
+            'store = memh5.Store(); files.open_profile_file = store.open\n'
+            'rc = dist.main(["count", "-k", "8", %r, %r, "out.k8"])\n'
+            'assert rc == 0\n'
+            'h = store.open("out.k8", "r")\n'
+            'got = klib.Profile.from_file(h)\n'
+            'a = klib.Profile.from_fasta(open(%r), 8); b = klib.Profile.from_fasta(open(%r), 8); a.merge(b)\n'
+            'assert got.name == "a_1" and np.array_equal(got.counts, a.counts) and int(got.total) == int(a.total)\n'
+            'print("DIST_COUNT_OK", int(got.total))\n') % (root, root, os.path.join(tutorial_dir, 'a_1.fa'), os.path.join(tutorial_dir, 'a_2.fa'),
+                                                              os.path.join(tutorial_dir, 'a_1.fa'), os.path.join(tutorial_dir, 'a_2.fa'))
+    script = tmp_path / 'dist_count.py'
+    script.write_text(code)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', '29611', str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and 'DIST_COUNT_OK' in out, out[-3000:]
