@@ -96,7 +96,7 @@ int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);  
  * giant record into ranges and hands every range but the first the k - 1 bases before it as `prefix` (below). */
 int kpal_count_feed_fasta(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);
 /* The same for the bytes [begin, end) of a FILE (end = 0: to its end), read by the library itself: parallel preads straight
- * into the pinned staging buffers (KPAL_READ_THREADS, default 8) -- the path of `kpal count` on a FASTA file (kmer.py:112-146
+ * into the pinned staging buffers (KPAL_READ_THREADS, default 16) -- the path of `kpal count` on a FASTA file (kmer.py:112-146
  * -> klib.py:97-112) and of one rank's shard of the input (byte ranges cut at record boundaries; for one giant
  * record, ranges with a (k-1)-base read-only halo).  `prefix` (may be NULL): text that logically precedes the range -- for a
  * range that begins inside a record: ">\n" + the last k - 1 sequence bytes before `begin`; the range itself must begin at a

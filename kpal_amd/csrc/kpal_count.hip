@@ -501,46 +501,28 @@ KPAL_API int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t n
     return rc;
 }
 
-// Host copy into a pinned staging buffer on several cores: one core's memcpy (~10 GB/s) is what limits
-// a pageable-memory feed otherwise, the PCIe link takes ~5 times that.  KPAL_COPY_THREADS (default 4, 1 =
-// plain memcpy); pieces below 4 MiB are not worth the thread start.
+// Host copy into a pinned staging buffer on several cores (host_pool.hpp): one core's memcpy (~9 GB/s) is what limits a
+// pageable-memory feed otherwise, the PCIe link takes six times that.  Pieces below 4 MiB are not split.
 static void staged_memcpy(void *dst, const void *src, size_t n)
 {
-    static const int configured = [] {
-        const char *e = getenv("KPAL_COPY_THREADS");
-        int t = e ? atoi(e) : 4;
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw && (unsigned)t > hw) t = (int)hw;
-        return t < 1 ? 1 : (t > 32 ? 32 : t);
-    }();
-    const size_t min_part = (size_t)4 << 20;
-    int parts = (int)std::min<size_t>((size_t)configured, n / min_part);
+    HostPool &pool = HostPool::instance();
+    const int parts = (int)std::min<size_t>((size_t)pool.size(), n / ((size_t)4 << 20));
     if (parts <= 1) {
         memcpy(dst, src, n);
         return;
     }
     const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> workers;
-    workers.reserve(parts - 1);
-    for (int i = 1; i < parts; ++i) {
+    pool.run(parts, [=](int i) {
         const size_t off = (size_t)i * part;
-        if (off >= n) break;
-        const size_t len = std::min(part, n - off);
-        try {
-            workers.emplace_back([=] { memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len); });
-        } catch (...) {   // no thread to be had: copy this part here (no exception may cross the C-ABI)
-            memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, len);
-        }
-    }
-    memcpy(dst, src, std::min(part, n));
-    for (auto &w : workers) w.join();
+        if (off < n) memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, std::min(part, n - off));
+    });
 }
 
 static int ensure_pinned(kpal_ctx *ctx)
 {
     for (int i = 0; i < 2; ++i) {
         if (!ctx->pinned[i]) {
-            hipError_t e = hipHostMalloc(&ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStagePad, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc(&ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStageHead + kpal_ctx::kStagePad, hipHostMallocDefault);
             if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
         }
     }
@@ -642,43 +624,29 @@ static bool pread_all(int fd, uint8_t *dst, size_t n, uint64_t off)
     return true;
 }
 
-// The page cache hands a reader ~5-10 GB/s (one copy_to_user per thread); the link takes 55: the staging buffer is filled by
-// several readers at once.  KPAL_READ_THREADS (default 8, at most the hardware threads); pieces below 4 MiB are not split.
-static bool pread_parallel(int fd, uint8_t *dst, size_t n, uint64_t off)
+// n bytes of the source's range from `pos` into dst, by the pool: the page cache hands ONE reader ~9 GB/s (a copy_to_user per
+// page), the link takes 56.  start: the pool's workers copy while the caller does something else; ok[] says afterwards
+// (HostPool::wait) whether every part arrived.  Pieces below 4 MiB are not split.
+static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t n, std::vector<char> &ok)
 {
-    static const int configured = [] {
-        const char *e = getenv("KPAL_READ_THREADS");
-        int t = e ? atoi(e) : 8;
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw && (unsigned)t > hw) t = (int)hw;
-        return t < 1 ? 1 : (t > 64 ? 64 : t);
-    }();
-    const int parts = (int)std::min<size_t>((size_t)configured, n / ((size_t)4 << 20));
-    if (parts <= 1) return pread_all(fd, dst, n, off);
+    HostPool &pool = HostPool::instance();
+    const int parts = std::max(1, (int)std::min<size_t>((size_t)pool.size(), n / ((size_t)4 << 20)));
     const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> workers;
-    std::vector<char> ok((size_t)parts, 1);
-    workers.reserve(parts - 1);
-    for (int i = 1; i < parts; ++i) {
-        const size_t o = (size_t)i * part;
-        if (o >= n) break;
-        const size_t len = std::min(part, n - o);
-        char *flag = &ok[(size_t)i];
-        try {
-            workers.emplace_back([=] { *flag = pread_all(fd, dst + o, len, off + o) ? 1 : 0; });
-        } catch (...) {   // no thread to be had: this part here (no exception may cross the C-ABI)
-            *flag = pread_all(fd, dst + o, len, off + o) ? 1 : 0;
-        }
-    }
-    ok[0] = pread_all(fd, dst, std::min(part, n), off) ? 1 : 0;
-    for (auto &w : workers) w.join();
-    for (char f : ok)
-        if (!f) return false;
-    return true;
+    ok.assign((size_t)parts, 1);
+    char *flags = ok.data();
+    const int fd = s.fd;
+    const uint8_t *mem = s.mem;
+    pool.start(parts, [=](int i) {
+        const size_t off = (size_t)i * part;
+        if (off >= n) return;
+        const size_t len = std::min(part, n - off);
+        if (mem) memcpy(dst + off, mem + pos + off, len);
+        else flags[i] = pread_all(fd, dst + off, len, pos + off) ? 1 : 0;
+    });
 }
 
-// The next bytes of the source (at most `want`) into dst; returns how many (0: the end), -1 on a read error; *from_range = how
-// many of them came from [pos, end) (the others from the prefix).
+// The next bytes of the source (at most `want`) into dst, now; returns how many (0: the end), -1 on a read error;
+// *from_range = how many of them came from [pos, end) (the others from the prefix).
 static long fa_fill(FaSource &s, uint8_t *dst, size_t want, size_t *from_range)
 {
     size_t got = 0;
@@ -691,8 +659,11 @@ static long fa_fill(FaSource &s, uint8_t *dst, size_t want, size_t *from_range)
     }
     const size_t n = (size_t)std::min<uint64_t>(want - got, s.end - s.pos);
     if (n) {
-        if (s.mem) staged_memcpy(dst + got, s.mem + s.pos, n);
-        else if (!pread_parallel(s.fd, dst + got, n, s.pos)) return -1;
+        std::vector<char> ok;
+        fa_copy_start(s, dst + got, s.pos, n, ok);
+        HostPool::instance().wait();
+        for (char f : ok)
+            if (!f) return -1;
         s.pos += n;
         got += n;
     }
@@ -718,6 +689,21 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         CHK(ensure(ctx, ctx->fa_flat[i], stage + pad + 64));
         CHK(ensure(ctx, ctx->fa_meta[i], (size_t)max_blocks * (8 + 8 + 4) + (size_t)(max_blocks + 1) * 8 + 64));
     }
+    // Read-ahead: while the launches of chunk i are issued, the pool already reads chunk i + 1 into the other pinned buffer
+    // (behind kStageHead bytes of headroom: what chunk i gave back -- a run of blanks at its end -- is put in front of it).
+    struct ReadAhead {
+        bool active = false;
+        int slot = 0;
+        uint64_t pos = 0;
+        size_t n = 0;
+        std::vector<char> ok;
+        ~ReadAhead()
+        {
+            if (active) HostPool::instance().wait();   // (an error return must not leave the pool writing into the staging buffer)
+        }
+    } ra;
+    std::vector<uint8_t> carry;  // the bytes the chunk before gave back
+    const size_t head = kpal_ctx::kStageHead;
     int state = 0;               // what the next chunk's first byte continues (fasta_kernels.hpp: 0 line start, 1 header, 2 sequence)
     bool skipping = true;        // only text before the first header so far: dropped (klib.py:111: SeqIO starts at the first '>')
     bool at_line_start = true;
@@ -744,21 +730,53 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
     };
 
     int slot = 0;
-    while (src.more()) {
-        if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // the slot's previous DMA out of the pinned buffer
-        uint8_t *hp = (uint8_t *)ctx->pinned[slot];
-        size_t from_range = 0;
-        const long got = fa_fill(src, hp, stage, &from_range);
-        if (got < 0) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
-        if (got == 0) break;
-        size_t n = (size_t)got;
+    while (src.more() || !carry.empty()) {
+        uint8_t *hp = nullptr;
+        size_t n = 0, from_range = 0;
+        if (ra.active) {
+            HostPool::instance().wait();
+            ra.active = false;
+            for (char f : ra.ok)
+                if (!f) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
+            if (ra.pos == src.pos && ra.slot == slot && carry.size() <= head) {
+                hp = (uint8_t *)ctx->pinned[slot] + head - carry.size();
+                if (!carry.empty()) memcpy(hp, carry.data(), carry.size());
+                n = carry.size() + ra.n;
+                from_range = n;
+                src.pos += ra.n;
+                carry.clear();
+            }   // (else: the chunk before gave back more than the headroom holds and rewound the source: read again, below)
+        }
+        if (!hp) {
+            if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // the slot's previous DMA out of the pinned buffer
+            const size_t c = std::min(carry.size(), std::min(head, stage / 2));              // (carry.size() <= head whenever it is set)
+            hp = (uint8_t *)ctx->pinned[slot] + head - c;
+            if (c) memcpy(hp, carry.data(), c);
+            carry.clear();
+            const long got = fa_fill(src, hp + c, stage - c, &from_range);
+            if (got < 0) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
+            if (got == 0 && c == 0) break;
+            n = c + (size_t)got;
+            if (src.prefix_left == 0 && (size_t)got == from_range) from_range += c;   // (the carried bytes came from the range as well)
+        }
         if (src.more()) {
             // never cut inside a run of blanks: whether a blank trails its line is decided from the bytes that follow it
             size_t t = n;
             while (t > 0 && fa_host_is_blank(hp[t - 1])) --t;
-            if (t > 0 && n - t <= from_range) {
-                src.pos -= n - t;
+            if (t > 0 && t < n && n - t <= from_range) {
+                if (n - t <= head) carry.assign(hp + t, hp + n);   // goes in front of the next chunk
+                else src.pos -= n - t;                             // (absurdly long run of blanks: the next chunk is read again from there)
                 n = t;
+            }
+            // the next chunk: the pool reads it while this one is scanned, copied and its kernels are issued
+            if (src.pos < src.end && src.prefix_left == 0) {
+                const int other = slot ^ 1;
+                if (ctx->stage_used[other]) HIPCHK(hipEventSynchronize(ctx->ev_copied[other]));
+                ra.slot = other;
+                ra.pos = src.pos;
+                ra.n = (size_t)std::min<uint64_t>(stage - std::min(stage / 2, carry.size()), src.end - src.pos);
+                fa_copy_start(src, (uint8_t *)ctx->pinned[other] + head, ra.pos, ra.n, ra.ok);
+                ra.active = true;
             }
         }
         size_t first = 0;
@@ -766,7 +784,8 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
             first = fasta_first_header(hp, n, at_line_start);
             if (first >= n) {
                 at_line_start = fa_host_is_eol(hp[n - 1]);
-                continue;               // (the pinned slot is reused: nothing was queued on it)
+                if (ra.active) slot ^= 1;   // (the read-ahead fills the other buffer)
+                continue;
             }
             skipping = false;
             state = 0;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kpal_device.hpp"
+#include "host_pool.hpp"
 
 #define KPAL_API extern "C" __attribute__((visibility("default")))
 
@@ -121,6 +122,7 @@ struct kpal_ctx {
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
     static constexpr size_t kStagePad = 64;
+    static constexpr size_t kStageHead = (size_t)64 << 10;   // FASTA ingest: headroom in front of a read-ahead chunk (kpal_count.hip)
     void *pinned[2] = {nullptr, nullptr};
     DevBuf dstage[2];
     hipEvent_t ev_copied[2] = {nullptr, nullptr};
@@ -130,6 +132,10 @@ struct kpal_ctx {
     DevBuf scratch[4];
     DevBuf partials, result;
     DevBuf opt_l, opt_r, opt_levels, opt_profiles;   // ProfileDistance option pipeline
+    // the canonical tile pairs of the LDS-tiled balance kernels for the k they were last built for (kpal_vec.hip: canon_tiles)
+    DevBuf canon;
+    std::vector<uint32_t> canon_host;
+    int canon_k = 0;
     // multi-GPU (kpal_multi.hip): RCCL communicator, the stream the pipelined reduce runs on, two side buffers for it
     void *comm = nullptr;                    // ncclComm_t
     int comm_rank = 0, comm_world = 1;

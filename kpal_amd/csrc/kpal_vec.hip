@@ -15,12 +15,56 @@ KPAL_API uint64_t kpal_reverse_complement(uint64_t number, int k)
 }
 
 // out[i] = in[i] + in[rc(i)]; in == out allowed.  LDS-tiled for k >= 6, pairwise kernels below that.
+// The canonical tile pairs of the LDS-tiled balance family (balance_tiled_kernel, pair_distance_balanced_kernel; k >= 6): the
+// tiles M of k - 6 digits with M <= rc(M), as a device list in the order the persistent workgroups take them, and a grid that
+// gives every workgroup the same number of pairs.
+//   ORDER (k >= 13).  A tile's 64 runs lie 4^(k-3) entries apart -- 64 pages whatever M is -- and the partner's page numbers are
+// the reverse complement of M's LOW digits: with M counting up, every workgroup in flight had 64 partner pages of its own and the
+// balance ran at 2.9 TB/s (k = 15) -- address translation, as in quad2_finalize_kernel.  So the sequence runs through M with the
+// bits that are page bits on NEITHER side (M bits 2 md - 12 .. 11: index bits below 18 here and in the partner) fastest: tiles
+// worked on at the same time share their pages on both sides.
+static int canon_tiles(kpal_ctx *ctx, int k, const uint32_t **list, uint32_t *count, unsigned *grid)
+{
+    const int md = k - 6;
+    if (ctx->canon_k != k) {
+        const uint64_t nM = 1ULL << (2 * md);
+        const int lo = 2 * md - 12 > 0 ? 2 * md - 12 : 0, hi = 2 * md - 1 < 11 ? 2 * md - 1 : 11;
+        const int nn = hi - lo + 1;
+        auto tile_of = [&](uint64_t m) -> uint64_t {
+            if (lo == 0 || nn <= 0) return m;
+            return ((m & ((1ULL << nn) - 1ULL)) << lo) | ((m >> nn) & ((1ULL << lo) - 1ULL)) | ((m >> (nn + lo)) << (nn + lo));
+        };
+        std::vector<uint32_t> host;
+        host.reserve((size_t)(nM / 2 + 1024));
+        for (uint64_t m = 0; m < nM; ++m) {
+            const uint64_t M = tile_of(m);
+            if (md == 0 || M <= kpal_reverse_complement(M, md)) host.push_back((uint32_t)M);
+        }
+        CHK(ensure(ctx, ctx->canon, host.size() * sizeof(uint32_t)));
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // (a previous list may still be read; and `canon_host` is the copy's source)
+        ctx->canon_host.swap(host);
+        HIPCHK(hipMemcpyAsync(ctx->canon.p, ctx->canon_host.data(), ctx->canon_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));   // (once per k; the list is then read by launches on either of the context's streams)
+        ctx->canon_k = k;
+    }
+    const uint32_t n = (uint32_t)ctx->canon_host.size();
+    const uint32_t slots = (uint32_t)ctx->num_cu * 2;                  // two 66 KiB workgroups per CU
+    const uint32_t rounds = (n + slots - 1) / slots;
+    *list = (const uint32_t *)ctx->canon.p;
+    *count = n;
+    *grid = (n + rounds - 1) / rounds;                                  // every workgroup `rounds` pairs (the last ones one fewer)
+    return KPAL_OK;
+}
+
 int launch_balance(kpal_ctx *ctx, int k, const int64_t *in, int64_t *out)
 {
     const uint64_t n = 1ULL << (2 * k);
     if (k >= 6) {
-        const unsigned tiles = 1u << (2 * (k - 6));
-        LAUNCH(ctx, "balance_tiled", balance_tiled_kernel, dim3(std::min<unsigned>(tiles, (unsigned)ctx->num_cu * 2)), dim3(1024), in, out, k);
+        const uint32_t *canon = nullptr;
+        uint32_t ncanon = 0;
+        unsigned grid = 1;
+        CHK(canon_tiles(ctx, k, &canon, &ncanon, &grid));
+        LAUNCH(ctx, "balance_tiled", balance_tiled_kernel, dim3(grid), dim3(1024), in, out, k, canon, ncanon);
     } else if (in == out) {
         LAUNCH(ctx, "balance_inplace", balance_inplace_kernel, dim3(stream_grid(ctx, n)), dim3(256), out, k, n);
     } else {
@@ -171,12 +215,21 @@ KPAL_API int kpal_pair_distance_device(kpal_ctx *ctx, size_t n, const int64_t *d
     if (do_balance) {
         if (k < 1 || k > KPAL_MAX_K || n != (1ULL << (2 * k))) return set_err(KPAL_E_INVALID, "do_balance needs n == 4^k");
         if (k >= 6) {   // fused balance + distance: balanced values are formed in LDS tiles, never written
-            const unsigned grid = std::min<unsigned>(1u << (2 * (k - 6)), (unsigned)ctx->num_cu * 2);   // persistent
+            const uint32_t *canon = nullptr;
+            uint32_t ncanon = 0;
+            unsigned grid = 1;
+            CHK(canon_tiles(ctx, k, &canon, &ncanon, &grid));
+            // persistent workgroups with prefetch, ONE per CU (120 registers), the pairs dealt round robin: every workgroup the same
+            // number of pairs (k = 12: 0.099 -> 0.059 ms with the balanced deal)
+            {
+                const uint32_t slots = (uint32_t)ctx->num_cu, rounds = (ncanon + slots - 1) / slots;
+                grid = (ncanon + rounds - 1) / rounds;
+            }
             CHK(ensure(ctx, ctx->partials, (size_t)grid * sizeof(Partial)));
             Partial *pp = (Partial *)ctx->partials.p;
-            if (metric == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<0>), dim3(grid), dim3(1024), l, r, k, pp);
-            else if (metric == KPAL_PAIRWISE_SUM) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<1>), dim3(grid), dim3(1024), l, r, k, pp);
-            else LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<2>), dim3(grid), dim3(1024), l, r, k, pp);
+            if (metric == KPAL_PAIRWISE_PROD) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<0>), dim3(grid), dim3(1024), l, r, k, canon, ncanon, pp);
+            else if (metric == KPAL_PAIRWISE_SUM) LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<1>), dim3(grid), dim3(1024), l, r, k, canon, ncanon, pp);
+            else LAUNCH(ctx, "pair_distance_balanced", (pair_distance_balanced_kernel<2>), dim3(grid), dim3(1024), l, r, k, canon, ncanon, pp);
             std::vector<Partial> res;
             CHK(finish_partials(ctx, 1, grid, res));
             *out = finish_value(metric, res[0], aux_out);

@@ -95,7 +95,12 @@ __global__ __launch_bounds__(256) void balance_inplace_kernel(int64_t *__restric
 // runs of 512 B, keeps them in LDS (rows padded to 65 to spread banks on the transposed read),
 // and writes out[i] = in[i] + in[rc(i)] for both tiles -- 16 B of HBM traffic per bin instead of
 // scattered 8-byte partner accesses.  in == out is allowed (all reads precede the barrier).
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void balance_tiled_kernel(const int64_t *in, int64_t *out, int k)
+// The tile pairs come from a LIST (canon[c] = M of the c-th canonical pair, built by the host: kpal_vec.hip, canon_tiles) and the
+// persistent workgroups take them round robin -- every workgroup gets the same number of pairs to within one.  (Striding through
+// M itself and skipping the non-canonical ones left the work badly spread: a workgroup's M share their low digits, and those
+// decide whether M <= rc(M) for nearly all of them -- a quarter of the workgroups had eight pairs, a quarter none.)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void balance_tiled_kernel(const int64_t *in, int64_t *out, int k,
+                                                                                                     const uint32_t *__restrict__ canon, uint32_t ncanon)
 {
     constexpr int T = 3, S = 64;
     __shared__ unsigned long long A[S][S + 1];
@@ -108,22 +113,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const unsigned long long *uin = reinterpret_cast<const unsigned long long *>(in);
     unsigned long long *uout = reinterpret_cast<unsigned long long *>(out);
     // persistent workgroups over the canonical tile pairs (M <= rc(M)); the next pair's eight values
-    // per thread are loaded before the current pair is exchanged through LDS and written back
-    // ORDER of the tile pairs (k >= 13).  A tile's 64 runs lie 4^(k-3) entries apart -- 64 pages whatever M is -- and the partner's
-    // page numbers are the reverse complement of M's LOW digits: with M counting up, every workgroup in flight had 64 partner pages
-    // of its own and the kernel ran at 2.9 TB/s (k = 15) -- address translation, as in quad2_finalize_kernel.  So the sequence
-    // number m is mapped to M with the bits that are page bits on NEITHER side (M bits 2 md - 12 .. 11: index bits below 18 here and
-    // in the partner) running fastest: tiles worked on at the same time share their pages on both sides.
-    const int lo = 2 * md - 12 > 0 ? 2 * md - 12 : 0, hi = 2 * md - 1 < 11 ? 2 * md - 1 : 11;
-    const int nn = hi - lo + 1;
-    auto tile_of = [&](uint64_t m) -> uint64_t {
-        if (lo == 0 || nn <= 0) return m;
-        return ((m & ((1ULL << nn) - 1ULL)) << lo) | ((m >> nn) & ((1ULL << lo) - 1ULL)) | ((m >> (nn + lo)) << (nn + lo));
-    };
-    auto canonical_from = [&](uint64_t m) {     // m: sequence number; the tile is tile_of(m)
-        while (m < nM && md > 0 && tile_of(m) > revcomp(tile_of(m), md)) m += gridDim.x;
-        return m;
-    };
+    // per thread are loaded before the current pair is exchanged through LDS and written back.
+    // The ORDER of the list (k >= 13) is page-aware: see canon_tiles.
+    (void)nM;
     auto fetch = [&](uint64_t M, unsigned long long (&a)[4], unsigned long long (&b)[4]) {
         const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
 #pragma unroll
@@ -134,12 +126,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
         }
     };
     unsigned long long a[4], b[4], na[4], nb[4];
-    uint64_t seq = canonical_from(blockIdx.x);
-    if (seq < nM) fetch(tile_of(seq), a, b);
-    while (seq < nM) {
-        const uint64_t M = tile_of(seq);
-        const uint64_t seqn = canonical_from(seq + gridDim.x);
-        if (seqn < nM) fetch(tile_of(seqn), na, nb);
+    uint32_t seq = blockIdx.x;
+    if (seq < ncanon) fetch(canon[seq], a, b);
+    while (seq < ncanon) {
+        const uint64_t M = canon[seq];
+        const uint32_t seqn = seq + gridDim.x;
+        if (seqn < ncanon) fetch(canon[seqn], na, nb);
         const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
         const bool self = M == Mr;
 #pragma unroll
@@ -293,37 +285,40 @@ __global__ __launch_bounds__(256) void pair_distance_kernel(const T *__restrict_
 // copies.  The two LDS tiles (66 KiB: two workgroups per CU) are used twice: first for the left
 // profile, whose balanced values stay in registers (8 per thread), then for the right profile,
 // whose global loads are already in flight while the left one is transposed.
-template <int METRIC>
-__global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int64_t *__restrict__ l,
-                                                                      const int64_t *__restrict__ r, int k,
-                                                                      Partial *__restrict__ partials)
+// PREFETCH: persistent workgroups, the next pair's values requested before the current pair is worked on -- ~120 registers, so
+// ONE 1024-thread workgroup per CU (the launcher sizes the grid for that).  Without (KPAL_PDB_PREFETCH=0, A/B only): one pair at
+// a time; forced into 64 registers for two workgroups per CU it spills and ran at half the rate (k = 12: 0.126 vs 0.059 ms).
+template <int METRIC, bool PREFETCH>
+__device__ __forceinline__ void pair_distance_balanced_body(const int64_t *__restrict__ l, const int64_t *__restrict__ r, int k,
+                                                            const uint32_t *__restrict__ canon, uint32_t ncanon,
+                                                            Partial *__restrict__ partials, unsigned long long (*A)[65], unsigned long long (*B)[65])
 {
     constexpr int T = 3, S = 64;
-    __shared__ unsigned long long A[S][S + 1], B[S][S + 1];
     const int md = k - 2 * T;
     const uint64_t nM = 1ULL << (2 * md);
     const uint64_t rowstride = 1ULL << (2 * (k - T));
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: row addresses are scalar)
     const int rl = (int)revcomp((uint64_t)lane, T);
     const unsigned long long *ul = reinterpret_cast<const unsigned long long *>(l);
     const unsigned long long *ur = reinterpret_cast<const unsigned long long *>(r);
     Partial p = {0.0, 0ULL};
-    // persistent workgroups over the canonical tile pairs (M <= rc(M)); the next pair's 16 values
-    // per thread are loaded before the current pair is transposed and reduced
-    auto canonical_from = [&](uint64_t m) {
-        while (m < nM && md > 0 && m > revcomp(m, md)) m += gridDim.x;
-        return m;
-    };
+    // persistent workgroups over the list of canonical tile pairs (M <= rc(M): balance_tiled_kernel), round robin; the next
+    // pair's 16 values per thread are loaded before the current pair is transposed and reduced
+    (void)nM;
     auto fetch = [&](uint64_t M, unsigned long long (&la)[4], unsigned long long (&lb)[4], unsigned long long (&ra)[4],
                      unsigned long long (&rb)[4]) {
-        const uint64_t Mr = md > 0 ? revcomp(M, md) : 0;
+        // (everything but the lane is wave-uniform: said explicitly, the loads take a scalar base + the lane's offset)
+        const uint64_t Mu = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)M);
+        const uint64_t Mr = md > 0 ? (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)revcomp(Mu, md)) : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint64_t row = (uint64_t)(w + 16 * q) * rowstride;
-            la[q] = ul[row + M * S + lane];
-            lb[q] = ul[row + Mr * S + lane];
-            ra[q] = ur[row + M * S + lane];
-            rb[q] = ur[row + Mr * S + lane];
+            const unsigned long long *pla = ul + (row + Mu * S), *plb = ul + (row + Mr * S);
+            const unsigned long long *pra = ur + (row + Mu * S), *prb = ur + (row + Mr * S);
+            la[q] = pla[lane];
+            lb[q] = plb[lane];
+            ra[q] = pra[lane];
+            rb[q] = prb[lane];
         }
     };
     auto term = [&](unsigned long long xu, unsigned long long yu) {
@@ -339,11 +334,16 @@ __global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int6
         }
     };
     unsigned long long la[4], lb[4], ra[4], rb[4], nla[4], nlb[4], nra[4], nrb[4];
-    uint64_t M = canonical_from(blockIdx.x);
-    if (M < nM) fetch(M, la, lb, ra, rb);
-    while (M < nM) {
-        const uint64_t Mn = canonical_from(M + gridDim.x);
-        if (Mn < nM) fetch(Mn, nla, nlb, nra, nrb);
+    uint32_t seq = blockIdx.x;
+    if (PREFETCH && seq < ncanon) fetch(canon[seq], la, lb, ra, rb);
+    while (seq < ncanon) {
+        const uint64_t M = canon[seq];
+        const uint32_t seqn = seq + gridDim.x;
+        if constexpr (PREFETCH) {
+            if (seqn < ncanon) fetch(canon[seqn], nla, nlb, nra, nrb);
+        } else {
+            fetch(M, la, lb, ra, rb);
+        }
         const bool self = md == 0 || M == revcomp(M, md);
         auto exchange = [&](unsigned long long (&a)[4], unsigned long long (&b)[4]) {
             // a/b: this thread's bins of tile M / rc(M); on return each holds bin + bin[rc]
@@ -366,19 +366,32 @@ __global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int6
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             term(la[q], ra[q]);
+            if constexpr (!PREFETCH) __builtin_amdgcn_sched_barrier(0);   // (64 registers: one division's temporaries at a time)
             if (!self) term(lb[q], rb[q]);
+            if constexpr (!PREFETCH) __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            la[q] = nla[q];
-            lb[q] = nlb[q];
-            ra[q] = nra[q];
-            rb[q] = nrb[q];
+            for (int q = 0; q < 4; ++q) {
+                la[q] = nla[q];
+                lb[q] = nlb[q];
+                ra[q] = nra[q];
+                rb[q] = nrb[q];
+            }
         }
-        M = Mn;
+        seq = seqn;
     }
     p = block_reduce(p);
     if (threadIdx.x == 0) partials[blockIdx.x] = p;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(1024) void pair_distance_balanced_kernel(const int64_t *__restrict__ l, const int64_t *__restrict__ r, int k,
+                                                                      const uint32_t *__restrict__ canon, uint32_t ncanon,
+                                                                      Partial *__restrict__ partials)
+{
+    __shared__ unsigned long long A[64][65], B[64][65];
+    pair_distance_balanced_body<METRIC, true>(l, r, k, canon, ncanon, partials, A, B);
 }
 
 // kmer.get_balance score (kpal/kmer.py:243-245) with the split halves never materialised: every

@@ -47,6 +47,9 @@ class File(object):
     def flush(self):
         self.flushes += 1
 
+    def close(self):
+        self.flushes += 1
+
 
 class Store(object):
     """``open(path, mode)`` in place of ``h5py.File``: files written live in memory, an empty placeholder is

@@ -209,7 +209,7 @@ def test_chunk_seams_everywhere(tmp_path):
             seqs = [s for _, s in seqio_records(text)]
             path = tmp_path / ('c%d_%d.fa' % (chunk, t))
             path.write_bytes(raw)
-            for k in (1, 3, 9, 16):
+            for k in (1, 3, 9) + ((12,) if t < 8 and chunk in (17, 257) else ()):
                 want = oracle.from_sequences(seqs, k)
                 c.count_begin(k)
                 c.count_feed_fasta(raw)

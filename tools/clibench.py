@@ -96,7 +96,7 @@ def main():
     import memh5
     ctx = _native.context()
     path = os.path.join(args.dir, 'kpal_clibench_%d.fa' % os.getpid())
-    out = {'k': args.k, 'dir': args.dir, 'host_cores': os.cpu_count(), 'read_threads': int(os.environ.get('KPAL_READ_THREADS', '8'))}
+    out = {'k': args.k, 'dir': args.dir, 'host_cores': os.cpu_count(), 'read_threads': int(os.environ.get('KPAL_READ_THREADS', '16')), 'read_pin': os.environ.get('KPAL_READ_PIN', '0')}
     try:
         t0 = time.perf_counter()
         nbytes, bases, records = write_fasta(ctx, path, args.gb)
