@@ -84,6 +84,12 @@ int kpal_memcpy_d2d(kpal_ctx *ctx, void *dev_dst, const void *dev_src, size_t nb
 int kpal_count_begin(kpal_ctx *ctx, int k);            /* klib.py:149-151: zeroed 4^k table */
 int kpal_count_set_strategy(kpal_ctx *ctx, int strategy);
 int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);        /* klib.py:154-168 */
+/* Page-locked host memory for the caller's own staging (the host side of Profile.from_sequences gathers a list of reads into
+ * it): kpal_count_feed_pinned lets the DMA engine read it in place -- no staging copy inside the library -- and returns when the
+ * buffer may be refilled (the counting kernels may still run). */
+int kpal_host_alloc(kpal_ctx *ctx, size_t nbytes, void **host_out);
+int kpal_host_free(kpal_ctx *ctx, void *host);
+int kpal_count_feed_pinned(kpal_ctx *ctx, const uint8_t *pinned_buf, size_t nbytes);   /* klib.py:154-168, as kpal_count_feed */
 int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous and stream-ordered: work queued on
                                                                                      * the context afterwards (kpal_memcpy_*, kpal_synth_reads_device, the next feed) may
                                                                                      * reuse dev_buf; anything outside the context's stream waits for kpal_sync first */

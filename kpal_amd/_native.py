@@ -65,6 +65,9 @@ SIGNATURES = {
     'kpal_count_set_strategy': (ctypes.c_int, [_vp, ctypes.c_int]),
     'kpal_count_feed': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_device': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_count_feed_pinned': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    'kpal_host_alloc': (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    'kpal_host_free': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_feed_fasta': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     'kpal_count_feed_fasta_file': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_size_t]),
     'kpal_fasta_flatten': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint64)]),
@@ -299,6 +302,21 @@ class Context(object):
         a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf, dtype=np.uint8)
         if a.size:
             _check(self._L.kpal_count_feed(self._h, a.ctypes.data, a.size))
+
+    def host_alloc(self, nbytes):
+        """Page-locked host buffer -> (address, uint8 NumPy view); free with ``host_free(address)`` (the view dangles afterwards)."""
+        p = _vp()
+        _check(self._L.kpal_host_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        view = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
+        return p.value, view
+
+    def host_free(self, address):
+        _check(self._L.kpal_host_free(self._h, _vp(address)))
+
+    def count_feed_pinned(self, address, nbytes):
+        """``nbytes`` at ``address`` inside a ``host_alloc`` buffer: copied by DMA in place; returns when the buffer may be refilled."""
+        if nbytes:
+            _check(self._L.kpal_count_feed_pinned(self._h, _vp(address), int(nbytes)))
 
     def count_feed_fasta(self, buf):
         """buf: FASTA text (bytes-like) made of whole records; flattened and counted on the GPU."""

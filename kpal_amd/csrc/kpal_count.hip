@@ -529,12 +529,10 @@ static int ensure_pinned(kpal_ctx *ctx)
     return KPAL_OK;
 }
 
-KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+// pinned_source: host_buf came from kpal_host_alloc -- the DMA engine reads it in place, no staging copy; the call returns
+// when the last copy has left it (the kernels may still run).
+static int count_feed_host(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, bool pinned_source)
 {
-    CTX_ENTER(ctx);
-    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed before kpal_count_begin");
-    if (nbytes == 0) return KPAL_OK;
-    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
     const size_t km1 = (size_t)ctx->k - 1;
     const size_t stage = kpal_ctx::kStage;
     const size_t pad = kpal_ctx::kStagePad;  // room for the halo, keeps the payload 16-byte aligned
@@ -549,8 +547,12 @@ KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbyt
             HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[slot], 0));
         }
-        uint8_t *hp = (uint8_t *)ctx->pinned[slot] + (pad - h);
-        staged_memcpy(hp, host_buf + off - h, len + h);
+        const uint8_t *hp = host_buf + off - h;
+        if (!pinned_source) {
+            uint8_t *staged = (uint8_t *)ctx->pinned[slot] + (pad - h);
+            staged_memcpy(staged, host_buf + off - h, len + h);
+            hp = staged;
+        }
         uint8_t *dp = (uint8_t *)ctx->dstage[slot].p + (pad - h);
         HIPCHK(hipMemcpyAsync(dp, hp, len + h, hipMemcpyHostToDevice, ctx->copy_stream));
         HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
@@ -559,6 +561,49 @@ KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbyt
         HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
         ctx->stage_used[slot] = true;
     }
+    if (pinned_source) HIPCHK(hipStreamSynchronize(ctx->copy_stream));   // the caller may refill its buffer
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!host_buf) return set_err(KPAL_E_INVALID, "host_buf is NULL");
+    return count_feed_host(ctx, host_buf, nbytes, false);
+}
+
+KPAL_API int kpal_count_feed_pinned(kpal_ctx *ctx, const uint8_t *pinned_buf, size_t nbytes)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_count_feed_pinned before kpal_count_begin");
+    if (nbytes == 0) return KPAL_OK;
+    if (!pinned_buf) return set_err(KPAL_E_INVALID, "pinned_buf is NULL");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, pinned_buf) != hipSuccess || attr.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return set_err(KPAL_E_INVALID, "kpal_count_feed_pinned needs memory from kpal_host_alloc");
+    }
+    return count_feed_host(ctx, pinned_buf, nbytes, true);
+}
+
+KPAL_API int kpal_host_alloc(kpal_ctx *ctx, size_t nbytes, void **host_out)
+{
+    CTX_ENTER(ctx);
+    if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
+    *host_out = nullptr;
+    hipError_t e = hipHostMalloc(host_out, nbytes ? nbytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_host_free(kpal_ctx *ctx, void *host)
+{
+    CTX_ENTER(ctx);
+    if (!host) return KPAL_OK;
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    HIPCHK(hipHostFree(host));
     return KPAL_OK;
 }
 

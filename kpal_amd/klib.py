@@ -29,7 +29,14 @@ import numpy as np
 
 from . import _native, metrics
 
+try:                      # the C gatherer of from_sequences (csrc/kpal_join.c; built by __graft_entry__.build()); without it the
+    from . import _kpal_join   # sequences are joined by the interpreter -- same stream, ~3 x slower for lists of short reads
+except ImportError:       # pragma: no cover
+    _kpal_join = None
+
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
+_GATHER_BYTES = 64 << 20  # page-locked gather buffer of from_sequences
+_GATHER_THREADS = 8
 _JOIN_BLOCK = 4096       # sequences joined per C-level call
 _RECORD_BATCH_BYTES = 1 << 30   # tables downloaded per from_fasta_by_record batch
 _FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
@@ -119,6 +126,49 @@ def _join_block(block):
         return b'\n'.join(block)
     except TypeError:
         return b'\n'.join(_encode(s) for s in block)
+
+
+_gather_buffers = {}      # Context -> (address, uint8 view): one page-locked buffer per context, kept for the process
+
+
+def _gather_feed(ctx, sequences):
+    """Feed ``sequences`` to the running count through the C gatherer: the items of a list are copied (each followed by the
+    separator ``\\n``) into a page-locked buffer by several threads and handed to ``kpal_count_feed_pinned`` buffer by
+    buffer.  A sequence is never split over two feeds (windows do not span feeds); one that does not fit the buffer goes
+    through ``kpal_count_feed`` on its own; items the gatherer does not know (``str`` with characters beyond latin-1,
+    ``memoryview`` ...) are encoded here, one at a time."""
+    if ctx not in _gather_buffers:
+        _gather_buffers[ctx] = ctx.host_alloc(_GATHER_BYTES)
+    address, view = _gather_buffers[ctx]
+    cap = view.size
+    fill = 0
+    it = None if isinstance(sequences, (list, tuple)) else iter(sequences)
+    while True:
+        block = sequences if it is None else list(itertools.islice(it, 1 << 16))
+        pos = 0
+        while pos < len(block):
+            pos, nbytes, status = _kpal_join.gather(block, pos, address + fill, cap - fill, _GATHER_THREADS)
+            fill += nbytes
+            if status == 0:
+                break
+            data = None
+            if status == 2:                      # an item the gatherer does not read: encoded here
+                data = _encode(block[pos]) + b'\n'
+                if len(data) <= cap - fill:
+                    view[fill:fill + len(data)] = np.frombuffer(data, dtype=np.uint8)
+                    fill += len(data)
+                    pos += 1
+                    continue
+            if fill:                             # the buffer is full: hand it over, go on with an empty one
+                ctx.count_feed_pinned(address, fill)
+                fill = 0
+            elif data is not None or len(block[pos]) + 1 > cap:
+                ctx.count_feed(data if data is not None else _encode(block[pos]))   # larger than the buffer: on its own
+                pos += 1
+        if it is None or not block:
+            break
+    if fill:
+        ctx.count_feed_pinned(address, fill)
 
 
 def _encode(sequence):
@@ -264,6 +314,9 @@ class Profile(object):
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         ctx = _native.context()
         ctx.count_begin(length)
+        if _kpal_join is not None:
+            _gather_feed(ctx, sequences)
+            return cls(ctx.count_finish(), name=name)
         it = iter(sequences)
         pending = []
         size = 0

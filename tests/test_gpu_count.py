@@ -868,3 +868,51 @@ def test_k16_two_level_on_device(ctx):
     finally:
         ctx.free(d)
         other.close()
+
+
+def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
+    """Profile.from_sequences on lists / tuples / generators of bytes, str, bytearray, memoryview and str with characters
+    beyond latin-1 (separators, like every non-nucleotide: klib.py:152) goes through the C gatherer (kpal_amd/csrc/kpal_join.c)
+    and kpal_count_feed_pinned: with the usual 64 MiB buffer and with a 4 KiB one (buffer full in the middle of the list, a
+    sequence longer than the buffer, foreign items at a buffer's end), against the oracle and against the interpreter's join."""
+    from kpal_amd import klib
+    assert klib._kpal_join is not None, 'the gatherer extension was not built'
+    rs = np.random.RandomState(8)
+    reads = oracle.synth_reads(61, 0, 3000, 150, noisy=True).reshape(-1, 151)[:, :150]
+    items = []
+    for i, r in enumerate(reads):
+        b = bytes(r[:rs.randint(0, 151)])
+        items.append([b, b.decode(), bytearray(b), memoryview(b), b.decode() + 'ሴ' + 'ACGTACGTACGTA'][i % 5])
+    items[100] = bytes(np.frombuffer(b'ACGT', dtype=np.uint8)[rs.randint(0, 4, 20000)])       # longer than the small buffer
+    items[2000] = ('ACGTTGCA' * 1000) + '中' + 'TTGACCA' * 50                            # foreign AND longer than the small buffer
+    as_text = [bytes(x).decode('latin-1') if not isinstance(x, str) else x.encode('latin-1', 'replace').decode('latin-1') for x in items]
+    for k in (3, 9, 12):
+        want = oracle.from_sequences(as_text, k)
+        for shape in (list, tuple, iter):
+            p = klib.Profile.from_sequences(shape(items), k)
+            np.testing.assert_array_equal(p.counts, want, err_msg='k=%d %s' % (k, shape.__name__))
+    small = ctx.host_alloc(4096)
+    from kpal_amd import _native
+    default = _native.context()
+    saved = klib._gather_buffers.get(default)
+    try:
+        klib._gather_buffers[default] = small
+        for k in (4, 11):
+            want = oracle.from_sequences(as_text, k)
+            np.testing.assert_array_equal(klib.Profile.from_sequences(items, k).counts, want)
+            np.testing.assert_array_equal(klib.Profile.from_sequences(iter(items), k).counts, want)
+    finally:
+        if saved is None:
+            klib._gather_buffers.pop(default, None)
+        else:
+            klib._gather_buffers[default] = saved
+        ctx.host_free(small[0])
+    # the interpreter's join (no extension) gives the same stream
+    monkeypatch.setattr(klib, '_kpal_join', None)
+    np.testing.assert_array_equal(klib.Profile.from_sequences(items, 9).counts, oracle.from_sequences(as_text, 9))
+    # empty inputs
+    assert klib.Profile.from_sequences([], 5).total == 0 and klib.Profile.from_sequences([b'', ''], 5).total == 0
+    with pytest.raises(ValueError):
+        ctx.count_begin(5)
+        ctx.count_feed_pinned(np.zeros(64, dtype=np.uint8).ctypes.data, 64)      # not page-locked memory
+    ctx.count_finish()
