@@ -890,7 +890,12 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     };
     // the values of the next stage are requested before this stage's arithmetic and staged after it.  (Requesting TWO stages
     // ahead -- a stage's arithmetic takes ~0.3 us, a load 1-2 us -- needs 16 more registers than four waves per SIMD leave:
-    // the compiler parked the prefetched values in scratch memory and the kernel was slower.)
+    // the compiler parked the prefetched values in scratch memory and the kernel was slower.  Round 4 tried the register-free
+    // way to that depth: the raw counts by LDS-DMA (global_load_lds_dwordx4, inline assembly so that hipcc does not drain it
+    // before every LDS read) into a three-slot ring, converted to reciprocals in place one iteration later, one raw s_barrier
+    // per stage, 52 KiB of LDS = three workgroups per CU -- correct, and 8.4 ms against this kernel's 6.0: the DMA pieces cost
+    // 100-185 cycles of issue each (MI355X_MICROARCH.md) -- four per wave and stage, as much as the stage's 136 fp64
+    // instructions -- and the in-place pass adds a third to the LDS traffic, which already runs level with the fp64 pipe.)
     longlong2 next[4];
     uint64_t c = group;
     uint64_t stages = 0;
