@@ -36,7 +36,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 FP64_VALU_PEAK_T = 39.3    # fp64 vector lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (78.6 TFLOP/s with FMA = half the guide's 157.3 TF fp32 vector rate)
 FP64_MFMA_PEAK_T = 78.6    # fp64 matrix TFLOP/s (v_mfma_f64_16x16x4_f64: 2048 flop per 64 SIMD-cycles x 1024 SIMDs x 2.4 GHz)
-PROFILE_DIR = os.path.join(ROOT, 'profiles', 'r3')
+PROFILE_ROUND = 'r4'
+PROFILE_DIR = os.path.join(ROOT, 'profiles', PROFILE_ROUND)
 
 
 def source_sha():
@@ -80,12 +81,12 @@ def pmc_traffic(kernels, dom, k, input_bytes_per_step):
     fname = 'pmc_hbm_traffic%s.json' % ('' if k == 12 else '_k%d' % k)
     prof = _load_profile(fname)
     if prof is None:
-        info['traffic_source'] = 'no committed counter profile profiles/r3/%s' % fname
+        info['traffic_source'] = 'no committed counter profile profiles/r4/%s' % fname
         return info
     info['traffic_profile_src_sha'] = prof.get('src_sha')
     here = source_sha()
     if prof.get('src_sha') != here:
-        info['traffic_source'] = 'profiles/r3/%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (fname, prof.get('src_sha'), here)
+        info['traffic_source'] = 'profiles/r4/%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (fname, prof.get('src_sha'), here)
         return info
     scale = input_bytes_per_step / prof['input_bytes_per_launch_avg']
     per_kernel, total = {}, 0.0
@@ -111,7 +112,7 @@ def pmc_traffic(kernels, dom, k, input_bytes_per_step):
         info['traffic'] = per_kernel[dom] / max(launches_per_step, 1)
     info['traffic_step'] = total
     info['traffic_by_kernel_per_step'] = per_kernel
-    info['traffic_source'] = ('profiles/r3/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, '
+    info['traffic_source'] = ('profiles/r4/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, '
                               'scaled by input bytes)' % fname)
     return info
 
@@ -129,7 +130,7 @@ def pmc_limiter(dom, k):
     # over the 256 CUs (tools/profile_numbers.py uses the same normalisation); wave-level shares are taken against SQ_WAVE_CYCLES
     cyc = row['SQ_BUSY_CYCLES'] / 32.0
     waves = row.get('SQ_WAVE_CYCLES') or 0.0
-    out = {'source': 'profiles/r3/pmc_lds_quad%s.json' % ('' if k == 12 else '_k%d' % k)}
+    out = {'source': 'profiles/r4/pmc_lds_quad%s.json' % ('' if k == 12 else '_k%d' % k)}
     if waves:
         out['valu_issue_share_of_wave_cycles'] = row.get('SQ_ACTIVE_INST_VALU', 0.0) / waves
         out['waiting_share_of_wave_cycles'] = row.get('SQ_WAIT_ANY', 0.0) / waves
@@ -254,10 +255,11 @@ def matrix_measure(ctx, k, P, dprof, host, metric_name, balance, steps, warmup, 
                     'memory_frac': mem_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': mem_bytes,
                     'avg_launch_ms': dom_ms}
     else:
-        # the NECESSARY fp64 work of a multiset term (metrics.py:118-123): |l - r|, the product (l + 1)(r + 1) and the division = 3
-        # lane operations for prod (sum: add instead of the product); the kernel's own instruction count is higher (conversions, term
-        # counts) and is not what the fraction is priced on
-        slots = 3.0
+        # fp64 lane operations a multiset term NEEDS.  matrix_rdiff (prod as |1/(y+1) - 1/(x+1)| on staged reciprocals): its own
+        # algebra, a subtraction and an add of the absolute value = 2.  The pair-of-counts kernels (matrix_rsum / matrix_super /
+        # matrix_tile; metrics.py:118-123): |l - r|, the denominator and the division = 3.  The kernels' instruction counts are
+        # higher (loader, conversions, term counts) and are not what the fraction is priced on
+        slots = 2.0 if dom == 'matrix_rdiff' else 3.0
         roofline = {'bound': 'fp64-valu', 'kernel': dom, 'achieved': terms * slots / (dom_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_T,
                     'unit': 'Tinstr/s (fp64 lane operations; %.0f necessary per term)' % slots,
                     'frac': terms * slots / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_T, 'traffic': None,
@@ -422,6 +424,7 @@ def end_to_end(ctx, k, dev_buf, nbytes, n_reads, read_len, kernel_s):
 
 def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
     """BASELINE configs 4 and 5 and the end-to-end figure, after the headline measurement (same process, same resident buffer)."""
+    import numpy as np
     extra = {}
     L = args.read_len
 
@@ -453,6 +456,45 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
             ctx.free(dprof)
         return {'config': 'BASELINE config 5: %d profiles k=12 (%d reads each, seed 100+p) resident in HBM; see matrix_prod / matrix_euclidean' % (args.profiles, args.profile_reads)}
     guarded('matrix', matrices)
+
+    def fasta_end_to_end():
+        """Profile.from_fasta on a FILE (what `kpal count` does, kmer.py:112-146 -> klib.py:97-112): a 2 GB FASTA in 60-column
+        lines (records of ~100 Mbases, bases from the 8d generator) in tmpfs, read by the library itself -- page cache ->
+        pinned staging -> HBM -> flattened -> counted, pipelined; + the download of the table.  tools/clibench.py is the
+        full version (8 GB, the CLI entry, shards)."""
+        import tempfile
+        from kpal_amd import klib
+        width, lines = 60, 32_000_000
+        d = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+        path = os.path.join(d, 'kpal_bench_%d.fa' % os.getpid())
+        host = np.empty(lines * (width + 1), dtype=np.uint8)
+        ctx.synth_reads_device(77, 0, lines, width, dev_buf)
+        ctx.d2h(host, dev_buf)
+        try:
+            with open(path, 'wb') as fh:
+                per = 1_600_000
+                for r, at in enumerate(range(0, lines, per)):
+                    fh.write(b'>chr%d synthetic\n' % (r + 1))
+                    fh.write(host[at * (width + 1):min(at + per, lines) * (width + 1)].data)
+            del host
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                with open(path) as fh:
+                    p = klib.Profile.from_fasta(fh, args.k)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            per_record = per * width - args.k + 1
+            records = (lines + per - 1) // per
+            want = (records - 1) * per_record + ((lines - (records - 1) * per) * width - args.k + 1)
+            return {'seconds': best, 'Gbases_per_s': lines * width / best / 1e9, 'file_GBs': os.path.getsize(path) / best / 1e9,
+                    'file_bytes': os.path.getsize(path), 'checksum_ok': int(p.total) == want, 'dir': d,
+                    'note': 'Profile.from_fasta(open(path), k) incl. the D2H of the table; input in the page cache, never the bench value'}
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+    if nbytes >= 32_000_000 * 61:
+        guarded('fasta_end_to_end', fasta_end_to_end)
     return extra
 
 

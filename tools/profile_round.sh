@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash tools/profile_round.sh r3'): the round's measurement artefacts into
+# Run on the GPU box (gpurun -- 'bash tools/profile_round.sh r4'): the round's measurement artefacts into
 # gpurun_out/<round>/ -- copy what should be judged into profiles/<round>/.
 #   pmc_hbm_traffic.json / _k15        FETCH_SIZE / WRITE_SIZE passes (separate), per kernel; taken FIRST and copied to
 #                                      profiles/<round>/ so that the bench lines of the same call report roofline.traffic
@@ -10,7 +10,7 @@
 #   bench_k15_*                        BASELINE config 4 as its own command, + kernel stats
 #   matrix_k12_P64_*                   BASELINE config 5 (multiset prod, euclidean) as its own command, + kernel stats
 set -u
-ROUND=${1:-r3}
+ROUND=${1:-r4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT" "$ROOT/profiles/$ROUND"
@@ -80,8 +80,23 @@ for d, _, files in os.walk(sys.argv[1]):
                 per[name][row['Counter_Name']] += float(row['Counter_Value']); disp[name].add(row['Dispatch_Id'])
 json.dump({n: dict({k: v / len(disp[n]) for k, v in c.items()}, dispatches=len(disp[n])) for n, c in per.items() if 'matrix' in n}, sys.stdout, indent=1)
 PY
-# ---- skewed inputs
+# ---- vector kernels (north_star: "fused balance+multiset-distance reduction over paired profiles"): pair distance, the fused
+#      balance + distance, balance, strand balance / split, summaries -- HIP-event times, rocprofv3 kernel stats, HBM counters
 cd "$ROOT"
+for k in 12 15; do python3 tools/vbench.py --k $k > "$OUT/vbench_k$k.log" 2>&1; done
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats_vec" -o v -- python3 "$ROOT/tools/vbench.py" --k 12 > /dev/null 2> "$OUT/stats_vec.err"
+find "$OUT/stats_vec" -name '*kernel_stats.csv' -exec cp {} "$OUT/vbench_k12_kernel_stats.csv" \;
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_vec" -o p -- python3 "$ROOT/tools/vbench.py" --k 12 > /dev/null 2> "$OUT/pmc_fetch_vec.err"
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_vec" -o p -- python3 "$ROOT/tools/vbench.py" --k 12 > /dev/null 2> "$OUT/pmc_write_vec.err"
+python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_vec" "$OUT/pmc_write_vec" 0 \
+  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around python3 tools/vbench.py --k 12 (two Poisson(16.6) profiles of 4^12 bins resident in HBM); gfx950 correction: FETCH_SIZE x2" pair_distance_balanced > "$OUT/pmc_hbm_traffic_vec_k12.json"
+# ---- the drop-in entry points on host-resident input (never the bench value): a multi-GB FASTA file through Profile.from_fasta /
+#      the CLI / the shard cutter; lists of reads through Profile.from_sequences
+cd "$ROOT"
+python3 tools/clibench.py --gb 8 > "$OUT/clibench.json" 2> "$OUT/clibench.err"
+python3 tools/hostbench.py --reads 20000000 2>&1 | head -8 > "$OUT/hostbench.log"
+# ---- skewed inputs
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -delete
