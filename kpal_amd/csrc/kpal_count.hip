@@ -511,7 +511,7 @@ static void staged_memcpy(void *dst, const void *src, size_t n)
         memcpy(dst, src, n);
         return;
     }
-    const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
+    const size_t part = (((n + (size_t)parts - 1) / (size_t)parts) + 4095) & ~(size_t)4095;
     pool.run(parts, [=](int i) {
         const size_t off = (size_t)i * part;
         if (off < n) memcpy((uint8_t *)dst + off, (const uint8_t *)src + off, std::min(part, n - off));
@@ -676,7 +676,7 @@ static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t 
 {
     HostPool &pool = HostPool::instance();
     const int parts = std::max(1, (int)std::min<size_t>((size_t)pool.size(), n / ((size_t)4 << 20)));
-    const size_t part = ((n / parts) + 4095) & ~(size_t)4095;
+    const size_t part = (((n + (size_t)parts - 1) / (size_t)parts) + 4095) & ~(size_t)4095;
     ok.assign((size_t)parts, 1);
     char *flags = ok.data();
     const int fd = s.fd;

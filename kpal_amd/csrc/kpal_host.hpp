@@ -232,6 +232,13 @@ struct ProfScope {
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k); \
     }
 
+#define DISPATCH_K_12_16(k, ...)                                                                   \
+    switch (k) {                                                                                   \
+        CASE_K(12, __VA_ARGS__) CASE_K(13, __VA_ARGS__) CASE_K(14, __VA_ARGS__) CASE_K(15, __VA_ARGS__) CASE_K(16, __VA_ARGS__) \
+    default:                                                                                       \
+        return set_err(KPAL_E_INVALID, "staged quad histograms need 12 <= k <= 16 (k=%d)", k);     \
+    }
+
 #define DISPATCH_K_8_16(k, ...)                                                                   \
     switch (k) {                                                                                   \
         CASE_K(8, __VA_ARGS__) CASE_K(9, __VA_ARGS__) CASE_K(10, __VA_ARGS__) CASE_K(11, __VA_ARGS__) CASE_K(12, __VA_ARGS__)         \

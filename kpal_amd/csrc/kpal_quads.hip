@@ -179,6 +179,19 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     CHK(ensure(ctx, ctx->keys, pool_bytes));
     uint32_t *pool = (uint32_t *)ctx->keys.p;
     const TableOnly table = {(unsigned long long *)ctx->table.p};   // counts that bypass the records: atomics into the (zeroed) table
+    // k = 12: every table entry receives FOUR adds from the histogram stage (one per form, from four different workgroups): 67 M
+    // global atomics per piece, 0.25 ms of the 3.7 ms histogram (A/B `hist_nomerge`) -- and Profile.balance then reads and writes the
+    // table once more.  As on the two-level path the forms are STAGED instead (8-bit counts, 64 MiB; quad2_index.hpp with the
+    // 11-bit bucket read as coarse : fine) and quad2_finalize_kernel gathers the four of every entry -- and balances in the same
+    // pass when kpal_count_balance asks (the pending finalisation: kpal_quads2.hip).  A form count >= 256 goes to the table
+    // directly; the mean per form is bytes / (4 x 4^12), so pieces whose mean could pass 240 (16 GB of unbroken sequence) keep the
+    // atomic merge.  KPAL_K12_STAGED=0: the atomic merge everywhere (A/B, tests).
+    static const bool allow_staged = [] { const char *e = getenv("KPAL_K12_STAGED"); return !e || atoi(e) != 0; }();
+    uint32_t *stage = nullptr;
+    if (ctx->k == 12 && allow_staged && (double)feed_bytes <= 240.0 * 4.0 * (double)ctx->bins) {
+        CHK(ensure(ctx, ctx->residuals, (size_t)ctx->bins * 4 * sizeof(quad2_stage_t)));
+        stage = (uint32_t *)ctx->residuals.p;
+    }
     // (input chunks are requested S steps ahead; at k <= 11 with eight steps that ring costs the registers the kernel does not have --
     // 12 spilled, and a kernel that uses scratch memory at all ran ~10 % slower in same-box comparisons -- so four steps ahead there;
     // k = 12 fits its 128 registers either way and a four-step ring changed nothing: 7.44 vs 7.40 ms)
@@ -196,9 +209,15 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         default: KPAL_QUAD_LAUNCH(6); break;
         }
         LAUNCH(ctx, "quad_hist", (quad_hist_kernel<K>), dim3(QuadCfg<K>::kHistBuckets), dim3(1024), (const uint32_t *)pool,
-               (const uint32_t *)nrounds, G, (uint32_t)tpb, table, (uint32_t *)nullptr);
+               (const uint32_t *)nrounds, G, (uint32_t)tpb, table, stage);
     });
 #undef KPAL_QUAD_LAUNCH
+    if (stage) {   // added to the table (and balanced) by quad2_finalize_kernel<12, ...> when something needs the table
+        ctx->finalize_pending = true;
+        ctx->finalize_stage = stage;
+        ctx->finalize_fresh = false;
+        ctx->fresh_resolved = false;
+    }
     if (ctx->quad_verbose) {   // diagnostics: tile size chosen, tiles abandoned to the direct path
         uint32_t st[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(st, error, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));

@@ -216,6 +216,11 @@ int quad2_finalize(kpal_ctx *ctx, bool balance)
     ctx->finalize_fresh = false;
     const quad2_stage_t *stage = (const quad2_stage_t *)ctx->finalize_stage;
     unsigned long long *table = (unsigned long long *)ctx->table.p;
+    if (ctx->k == 12) {   // the one-level pipeline's staged forms (kpal_quads.hip): never FRESH (its table is zeroed by kpal_count_begin)
+        if (balance) LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<12, true, false>), dim3(Quad2Index<12>::kSets), dim3(1024), stage, table);
+        else LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<12, false, false>), dim3(Quad2Index<12>::kSets), dim3(1024), stage, table);
+        return KPAL_OK;
+    }
     DISPATCH_K_13_16(ctx->k, {
         if (balance && fresh)
             LAUNCH(ctx, "quad2_finalize_balanced", (quad2_finalize_kernel<K, true, true>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);

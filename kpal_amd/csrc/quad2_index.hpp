@@ -1,4 +1,5 @@
-// quad2_index.hpp -- index arithmetic of the finalisation stage of the two-level quad pipeline (k = 13..16):
+// quad2_index.hpp -- index arithmetic of the finalisation stage of the quad pipelines (two-level: k = 13..16; and the one-level
+// pipeline at k = 12, whose 2048 histogram buckets are this file's (coarse: 2 bits | fine: 9 bits) read as one number):
 // where the histogram workgroups stage their four forms, and which table entries one finalisation workgroup owns.
 // Plain integer functions, shared by quad_kernels.hpp (device) and tests/quad2_index_check.cpp (host: the same
 // functions drive a CPU emulation of the staging + finalisation that is compared with a direct count + balance).
@@ -38,15 +39,19 @@ constexpr uint32_t kQuad2StageLimit = 256u;         // counts >= this go to the 
 
 template <int K>
 struct Quad2Index {
-    static_assert(K >= 13 && K <= 16, "two-level quad pipeline: k = 13..16");
-    static constexpr int CB = 2 * K - 22;                       // coarse bucket bits: 4, 6, 8, 10
+    static_assert(K >= 12 && K <= 16, "staged quad histograms: k = 12..16");
+    static constexpr int CB = 2 * K - 22;                       // coarse bucket bits: 4, 6, 8, 10 (k = 12: 2, the top bits of its 11-bit bucket)
     static constexpr uint32_t kCoarseMask = (1u << CB) - 1u;
     static constexpr int kSetBits = 2 * K - 14;                 // sets: 2^12 .. 2^18
     static constexpr uint32_t kSets = 1u << kSetBits;
     static constexpr int kRowStride = 129;                      // LDS: 128 rows (hi7) x 129 (128 lo7 + 1 pad) u64
 
-    static constexpr KPAL_HD uint32_t smask(uint32_t t) { return ((t << 5) | t) & 511u; }                                    // = QuadCfg<K>::smask
-    static constexpr KPAL_HD uint32_t smask1(uint32_t t) { return (CB > 4 ? ((t << (CB - 4)) ^ t) : t) & kCoarseMask; }      // = QuadCfg<K>::smask1
+    // k = 12 scrambles its 11-bit bucket with (t << 7 | t) (QuadCfg<12>::smask): the low nine bits and the top two of that
+    static constexpr KPAL_HD uint32_t smask(uint32_t t) { return K == 12 ? ((((t & 3u) << 7) | t) & 511u) : (((t << 5) | t) & 511u); }   // = QuadCfg<K>::smask
+    static constexpr KPAL_HD uint32_t smask1(uint32_t t)                                                                     // = QuadCfg<K>::smask1
+    {
+        return K == 12 ? ((t >> 2) & 3u) : ((CB > 4 ? ((t << (CB - 4)) ^ t) : t) & kCoarseMask);
+    }
 
     // ---- staging
     // position (in counts) of form i of table entry idx

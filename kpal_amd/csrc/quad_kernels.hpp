@@ -51,6 +51,9 @@ struct QuadCfg {
     // 2K-22 shared bits, scrambled) x a replica, 256 rows of 128 slots (1024 of 32 at k = 16); the 4-byte item keeps
     // the 9-bit fine bucket of level 2 as well:  hi6 << 26 | fine9 << 17 | low13 << 4 | mask4.
     static constexpr bool kTwoLevel = K >= 13;
+    // the histogram stage can STAGE its forms for quad2_finalize_kernel instead of adding them to the table with atomics
+    // (quad2_index.hpp): the two-level path always does, the one-level path at k = 12 when the host says so
+    static constexpr bool kStaged = K >= 12;
     static constexpr int kCoarseBits = kTwoLevel ? 2 * K - 22 : 0;           // 4, 6, 8, 10
     static constexpr int kCoarse = 1 << kCoarseBits;
     static constexpr int kRep = kTwoLevel ? (kCoarse >= 256 ? 1 : 256 / kCoarse) : 1;   // 16, 4, 1, 1
@@ -97,7 +100,9 @@ struct QuadCfg {
 static_assert(Quad2Index<13>::smask(11) == QuadCfg<13>::smask(11) && Quad2Index<16>::smask(5) == QuadCfg<16>::smask(5) &&
                   Quad2Index<13>::smask1(9) == QuadCfg<13>::smask1(9) && Quad2Index<14>::smask1(13) == QuadCfg<14>::smask1(13) &&
                   Quad2Index<15>::smask1(7) == QuadCfg<15>::smask1(7) && Quad2Index<16>::smask1(15) == QuadCfg<16>::smask1(15) &&
-                  Quad2Index<15>::CB == QuadCfg<15>::kCoarseBits,
+                  Quad2Index<15>::CB == QuadCfg<15>::kCoarseBits &&
+                  ((Quad2Index<12>::smask1(13) << 9) | Quad2Index<12>::smask(13)) == QuadCfg<12>::smask(13) &&
+                  ((Quad2Index<12>::smask1(6) << 9) | Quad2Index<12>::smask(6)) == QuadCfg<12>::smask(6),
               "quad2_index.hpp restates the scramble masks of QuadCfg");
 
 // item = hi6 << (L+4) | low << 4 | mask4 (mask bit 3 = oldest k-mer).  0 = null item.
@@ -1057,7 +1062,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #if defined(KPAL_AB_NO_STAGE_SWIZZLE)   // A/B timing
         return local;
 #endif
-        if constexpr (C::kTwoLevel) {
+        if constexpr (C::kStaged) {
             if (i == 0) return local ^ (((local >> 8) & 7u) << 3);                                   // hipart[3:1] -> bits 5:3 (t's low bits); a
                                                                                                       // staging lane reads hipart 2j and 2j+1
             if (i == 1) return local ^ (((local >> 9) & 1u) << 5) ^ (((local >> 10) & 3u) << 3);   // hipart[0] -> bit 5, hipart[2:1] -> bits 4:3
@@ -1193,7 +1198,8 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         // t-major -- the bins of one t (the top four bits of the low part, which select the scramble mask) are the bins of one
         // true bucket, so the finalisation reads them as one piece of 512 B.  A count that does not fit (a k-mer seen 256 times
         // in one batch within ONE of its four positions) goes to the table / the FRESH list directly and is staged as zero.
-        if constexpr (C::kTwoLevel) {
+        if constexpr (C::kStaged) {
+            // (k = 12, one level: `row` is the scrambled 11-bit bucket = scrambled coarse * 512 + scrambled fine of quad2_index.hpp, `coarse` 0)
             using Q = Quad2Index<K>;
             quad2_stage_t *dst = reinterpret_cast<quad2_stage_t *>(stage);
             for (int j = threadIdx.x; j < 4 * BINS / 16; j += blockDim.x) {
@@ -1240,7 +1246,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
-                const uint32_t c = hist[i * BINS + local];
+                const uint32_t c = hist[i * BINS + stage_swizzle(i, (uint32_t)local)];   // (k = 12 keeps forms 0 and 1 swizzled for the staging read)
                 if (c) atomicAdd(&table.table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
             }
         }

@@ -252,8 +252,9 @@ static int emulate_sets()
 int main(int argc, char **argv)
 {
     const bool full14 = argc > 1 && !strcmp(argv[1], "--k14");
-    if (check_properties<13>(6) || check_properties<14>(6) || check_properties<15>(4) || check_properties<16>(3)) return 1;
-    if (emulate_sets<13>() || emulate_sets<14>() || emulate_sets<15>() || emulate_sets<16>()) return 1;
+    if (check_properties<12>(6) || check_properties<13>(6) || check_properties<14>(6) || check_properties<15>(4) || check_properties<16>(3)) return 1;
+    if (emulate_sets<12>() || emulate_sets<13>() || emulate_sets<14>() || emulate_sets<15>() || emulate_sets<16>()) return 1;
+    if (emulate<12>()) return 1;             // the one-level pipeline at k = 12 stages its forms the same way (even k: self-paired sets)
     if (emulate<13>()) return 1;
     if (full14 && emulate<14>()) return 1;   // 12 GB of host memory: on request (self-paired sets exist only for even k)
     puts("QUAD2_INDEX_OK");

@@ -916,3 +916,63 @@ def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
         ctx.count_begin(5)
         ctx.count_feed_pinned(np.zeros(64, dtype=np.uint8).ctypes.data, 64)      # not page-locked memory
     ctx.count_finish()
+
+
+def test_k12_staged_forms_and_fused_balance():
+    """The one-level quad pipeline at k = 12 stages the four forms of its histogram stage as 8-bit counts and lets
+    quad2_finalize_kernel<12> add them to the table -- balanced in the same pass when kpal_count_balance asks (what bench.py times
+    at k = 12) -- instead of 67 M global atomics + a stand-alone balance.  Against the oracle: uniform noisy reads (40 MiB: AUTO
+    takes the quad pipeline), plain and balanced; TWO feeds into one count (the first feed's pending forms are flushed before
+    the second is staged), balanced; repeats whose counts do not fit a staged form (a 300-base sequence 1500 times: ~375 per
+    position; a 40-base one 300 000 times); a device feed; and the atomic merge (KPAL_K12_STAGED=0) as the cross-check, which
+    must give the same tables (its histogram bins are kept in the staging order too)."""
+    from kpal_amd import _native
+    rs = np.random.RandomState(12)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    k = 12
+    uniform = oracle.synth_reads(71, 0, 280000, 150, noisy=True)                 # 42 MB
+    blocks = [acgt[rs.randint(0, 4, size=300)].tobytes() for _ in range(2)]
+    short = acgt[rs.randint(0, 4, size=40)].tobytes()
+    reads = [blocks[0]] * 1500 + [blocks[1]] * 400 + [short] * 300000 + [acgt[rs.randint(0, 4, size=150)].tobytes() for _ in range(150000)]
+    order = rs.permutation(len(reads))
+    repeats = np.frombuffer(b'\n'.join(reads[i] for i in order), dtype=np.uint8)
+    assert repeats.size > (32 << 20)
+    os.environ['KPAL_K12_STAGED'] = '0'
+    try:
+        atomic = _native.Context(_native.default_device())
+    finally:
+        del os.environ['KPAL_K12_STAGED']
+    staged = _native.Context(_native.default_device())
+    try:
+        for data in (uniform, repeats):
+            want = oracle.count_flat(data, k, threads=8)
+            wantb = oracle.balance(want, k)
+            for c in (staged, atomic):
+                c.count_begin(k)
+                c.count_feed(data)
+                assert c.count_last_plan()[0] == 'partition_quads'
+                np.testing.assert_array_equal(c.count_finish(), want)
+                c.count_begin(k)
+                c.count_feed(data)
+                c.count_balance()
+                np.testing.assert_array_equal(c.count_finish(), wantb)
+                c.count_begin(k)                      # two feeds, then balance: 2 x the counts
+                c.count_feed(data)
+                c.count_feed(data)
+                c.count_balance()
+                np.testing.assert_array_equal(c.count_finish(), 2 * wantb)
+        assert oracle.count_flat(repeats, k).max() >= 300000
+        d = staged.alloc(uniform.size + 64)
+        staged.h2d(d + 3, uniform)
+        staged.count_begin(k, 'partition_quads')
+        staged.count_feed_device(d + 3, uniform.size)
+        staged.count_balance()
+        ptr, bins = staged.count_table()
+        got = np.empty(bins, dtype=np.int64)
+        staged.d2h(got, ptr)
+        np.testing.assert_array_equal(got, oracle.balance(oracle.count_flat(uniform, k, threads=8), k))
+        staged.count_finish(to_host=False)
+        staged.free(d)
+    finally:
+        staged.close()
+        atomic.close()
