@@ -964,14 +964,17 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return launch_ranks(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and not args.worker and os.environ.get('KPAL_BENCH_NO_SUPERVISOR', '') != '1':
+    # KPAL_BENCH_FORCE_MULTI=1 (tests on a one-GPU box): a world of ONE rank takes the multi-GPU code path -- supervisor, worker,
+    # communicators of size one, every reduce mode, the per-bin comparison with the single-stream count
+    multi = world > 1 or (os.environ.get('KPAL_BENCH_FORCE_MULTI', '') == '1' and 'RANK' in os.environ)
+    if multi and not args.worker and os.environ.get('KPAL_BENCH_NO_SUPERVISOR', '') != '1':
         sys.exit(supervise_rank(args))
     if args.stub:
         return stub_rank(args)
     if args.workload == 'matrix':
         return matrix_workload(args)
     args.gpus = world
-    if world > 1:
+    if multi:
         return multi_gpu_worker(args)
 
     import numpy as np   # noqa: F401

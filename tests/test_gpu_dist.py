@@ -55,3 +55,28 @@ def test_library_rccl_world_1():
     out = p.stdout.decode()
     assert p.returncode == 0, out[-3000:]
     assert 'RCCL_LIBRARY_OK' in out
+
+
+def test_bench_multi_gpu_code_path_on_one_gpu():
+    """The N > 1 code of bench.py -- rank supervisor, worker process, the library's RCCL communicator and torch.distributed's,
+    the three reduce modes (pipelined / serial in-library reduce, torch reduce) each timed with its own warm-up and steps, the
+    per-bin comparison of the merged + balanced table with the single-stream count, the line's fields -- started exactly as
+    the driver starts the scaling runs (python -m torch.distributed.run ... bench.py --gpus N ...), with a world of ONE rank
+    (KPAL_BENCH_FORCE_MULTI=1: this box has one GPU; the 8-GPU run is the driver's)."""
+    import json
+    env = dict(os.environ, KPAL_BENCH_FORCE_MULTI='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', '29633', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--reads', '3000000'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1 and line['attempt'] == 1
+    assert line['reduce_mode'] == 'library_pipelined' and line['pipelined_reduce'] is True and line['reduce_via'] == 'library'
+    assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
+    assert line['config']['merged_equals_single_stream'] is True and line['config']['reduce_mode'] == 'library_pipelined'
+    for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce'):
+        assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['ms_per_step'] > 0, mode
+        assert line['config'][mode + '_ms_per_step'] > 0
+    assert line['value'] > 0 and line['roofline']['frac'] > 0 and 'rccl_reduce' in line['roofline']['kernels_ms_per_step']
