@@ -79,4 +79,5 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce'):
         assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['ms_per_step'] > 0, mode
         assert line['config'][mode + '_ms_per_step'] > 0
-    assert line['value'] > 0 and line['roofline']['frac'] > 0 and 'rccl_reduce' in line['roofline']['kernels_ms_per_step']
+    # (at 3 M reads the fixed-cost histogram stage may be the longest kernel: an intermediate kernel has no algorithmic bytes of its own)
+    assert line['value'] > 0 and line['roofline']['pipeline_frac'] > 0 and 'rccl_reduce' in line['roofline']['kernels_ms_per_step']
