@@ -459,13 +459,13 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
     guarded('matrix', matrices)
 
     def fasta_end_to_end():
-        """Profile.from_fasta on a FILE (what `kpal count` does, kmer.py:112-146 -> klib.py:97-112): a 2 GB FASTA in 60-column
+        """Profile.from_fasta on a FILE (what `kpal count` does, kmer.py:112-146 -> klib.py:97-112): a 3.9 GB FASTA in 60-column
         lines (records of ~100 Mbases, bases from the 8d generator) in tmpfs, read by the library itself -- page cache ->
         pinned staging -> HBM -> flattened -> counted, pipelined; + the download of the table.  tools/clibench.py is the
         full version (8 GB, the CLI entry, shards)."""
         import tempfile
         from kpal_amd import klib
-        width, lines = 60, 32_000_000
+        width, lines = 60, 64_000_000
         d = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
         path = os.path.join(d, 'kpal_bench_%d.fa' % os.getpid())
         host = np.empty(lines * (width + 1), dtype=np.uint8)
@@ -479,7 +479,7 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
                     fh.write(host[at * (width + 1):min(at + per, lines) * (width + 1)].data)
             del host
             best = None
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.perf_counter()
                 with open(path) as fh:
                     p = klib.Profile.from_fasta(fh, args.k)
@@ -494,7 +494,7 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
         finally:
             if os.path.exists(path):
                 os.unlink(path)
-    if nbytes >= 32_000_000 * 61:
+    if nbytes >= 64_000_000 * 61:
         guarded('fasta_end_to_end', fasta_end_to_end)
     return extra
 

@@ -98,8 +98,11 @@ struct Chunk {
     uint32_t bad;    // 16 flags, base 0 in bit 15
 };
 
-// ~54 VALU: 8 per dword to classify, 2 per dword + three v_perm_b32 for the codes, 5 per PAIR of dwords (the flags of
-// dwords 0 / 2 ride at bit 4 of every byte, those of 1 / 3 at bit 0) + one v_perm_b32 for the flags.
+// ~45 VALU: 8 per dword to classify; the four 2-bit codes of a dword are gathered into one byte by ONE v_dot4_u32_u8 (the
+// byte-wise dot product with the weights 64, 16, 4, 1: the oldest base is the most significant digit) and the four bytes joined
+// by three v_lshl_or_b32; the flags (0x80 per bad byte) of a PAIR of dwords by two chained dot products (weights 128 .. 16 and
+// 8 .. 1: 0x80 x the pair's eight flags) and the two pairs by a shift and a v_lshl_or_b32.  (Round 3's shift-or gathers and
+// byte permutes took 54; KPAL_ENCODE_SHIFTS builds them for A/B.)
 __device__ __forceinline__ Chunk encode16(uint4 v)
 {
     uint32_t t0, t1, t2, t3, z0, z1, z2, z3;
@@ -107,14 +110,25 @@ __device__ __forceinline__ Chunk encode16(uint4 v)
     classify4(v.y, t1, z1);
     classify4(v.z, t2, z2);
     classify4(v.w, t3, z3);
+    Chunk r;
+#if defined(KPAL_ENCODE_SHIFTS)
     const uint32_t c0 = codes_to_top_byte(t0), c1 = codes_to_top_byte(t1), c2 = codes_to_top_byte(t2), c3 = codes_to_top_byte(t3);
     const uint32_t c01 = __builtin_amdgcn_perm(c0, c1, 0x07030000u);      // bytes 3, 2 = top bytes of c0, c1
     const uint32_t c23 = __builtin_amdgcn_perm(c2, c3, 0x07030000u);
     const uint32_t f01 = flags_to_top_byte((z0 >> 3) | (z1 >> 7));   // top byte = flags of dword 0 | dword 1
     const uint32_t f23 = flags_to_top_byte((z2 >> 3) | (z3 >> 7));
-    Chunk r;
     r.codes = __builtin_amdgcn_perm(c01, c23, 0x07060302u);
     r.bad = __builtin_amdgcn_perm(f01, f23, 0x0c0c0703u);
+#else
+    constexpr uint32_t kDigits = 0x01041040u;                            // byte 0 (oldest base) x 64, byte 1 x 16, byte 2 x 4, byte 3 x 1
+    const uint32_t d0 = __builtin_amdgcn_udot4(t0, kDigits, 0u, false), d1 = __builtin_amdgcn_udot4(t1, kDigits, 0u, false);
+    const uint32_t d2 = __builtin_amdgcn_udot4(t2, kDigits, 0u, false), d3 = __builtin_amdgcn_udot4(t3, kDigits, 0u, false);
+    r.codes = shl_or<24>(d0, shl_or<16>(d1, shl_or<8>(d2, d3)));
+    constexpr uint32_t kHigh = 0x10204080u, kLow = 0x01020408u;          // byte 0 (oldest) the highest flag of its nibble
+    const uint32_t f01 = __builtin_amdgcn_udot4(z1, kLow, __builtin_amdgcn_udot4(z0, kHigh, 0u, false), false);   // 0x80 x the eight flags
+    const uint32_t f23 = __builtin_amdgcn_udot4(z3, kLow, __builtin_amdgcn_udot4(z2, kHigh, 0u, false), false);
+    r.bad = shl_or<1>(f01, f23 >> 7);
+#endif
     return r;
 }
 
