@@ -17,7 +17,10 @@
  *    stream and must not be used from two threads at once.
  *  - count vectors are int64, length 4^k, index = big-endian 2-bit packing of the k-mer
  *    with A/a=0 C/c=1 G/g=2 T/t=3 (klib.py:43-48, doc/method.rst:23-45).
- *  - 1 <= k <= KPAL_MAX_K.
+ *  - 1 <= k <= KPAL_MAX_K = 16.  The reference takes any length and is bounded by memory alone (klib.py:149-151: a Python list
+ *    of 4^k integers, then an int64 array); here the bound is the encoder's window -- a lane sees its own 16 bases and the 16
+ *    before them -- and 4^16 int64 counts are 32 GiB of the 288 GB of one MI355X; k = 17 (128 GiB per profile, two of them
+ *    for any distance) is refused with KPAL_E_INVALID -- ValueError in the Python face -- not miscounted.
  */
 #ifndef KPAL_HIP_H
 #define KPAL_HIP_H

@@ -16,7 +16,7 @@ int set_err(int code, const char *fmt, ...)
 }
 
 KPAL_API const char *kpal_last_error(void) { return g_err; }
-KPAL_API const char *kpal_version(void) { return "kpal_amd 0.3 (gfx950)"; }
+KPAL_API const char *kpal_version(void) { return "kpal_amd 0.4 (gfx950)"; }
 
 int ensure(kpal_ctx *ctx, DevBuf &b, size_t bytes)
 {

@@ -123,11 +123,13 @@ __device__ __forceinline__ Chunk encode16(uint4 v)
     constexpr uint32_t kDigits = 0x01041040u;                            // byte 0 (oldest base) x 64, byte 1 x 16, byte 2 x 4, byte 3 x 1
     const uint32_t d0 = __builtin_amdgcn_udot4(t0, kDigits, 0u, false), d1 = __builtin_amdgcn_udot4(t1, kDigits, 0u, false);
     const uint32_t d2 = __builtin_amdgcn_udot4(t2, kDigits, 0u, false), d3 = __builtin_amdgcn_udot4(t3, kDigits, 0u, false);
-    r.codes = shl_or<24>(d0, shl_or<16>(d1, shl_or<8>(d2, d3)));
+    // (plain C, not the inline-assembly shl_or: a dot product's result needs wait states before a VALU instruction may read it,
+    // and hipcc's hazard recogniser does not look into inline assembly -- the first build of this read stale registers)
+    r.codes = (d0 << 24) | ((d1 << 16) | ((d2 << 8) | d3));
     constexpr uint32_t kHigh = 0x10204080u, kLow = 0x01020408u;          // byte 0 (oldest) the highest flag of its nibble
     const uint32_t f01 = __builtin_amdgcn_udot4(z1, kLow, __builtin_amdgcn_udot4(z0, kHigh, 0u, false), false);   // 0x80 x the eight flags
     const uint32_t f23 = __builtin_amdgcn_udot4(z3, kLow, __builtin_amdgcn_udot4(z2, kHigh, 0u, false), false);
-    r.bad = shl_or<1>(f01, f23 >> 7);
+    r.bad = (f01 << 1) | (f23 >> 7);
 #endif
     return r;
 }

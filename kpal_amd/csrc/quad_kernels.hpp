@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
     }
 }
 
-// Q4 (k = 13..16): the finalisation.  table[idx] += the four staged form counts of entry idx -- and, BALANCE, Profile.balance
+// Q4 (k = 13..16, and the one-level pipeline at k = 12): the finalisation.  table[idx] += the four staged form counts of entry idx -- and, BALANCE, Profile.balance
 // (klib.py:285-298) in the same pass: table[idx] = v[idx] + v[rc(idx)], v = table + forms.  Balancing afterwards costs a
 // second read and write of the whole table (k = 15: 8 GiB each way, 5.8 of 31 ms); here the table is read once and written
 // once either way.
