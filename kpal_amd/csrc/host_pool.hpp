@@ -1,8 +1,10 @@
 // host_pool.hpp -- a small pool of host threads for the copies that feed the GPU: page cache -> pinned staging (pread) and
-// pageable memory -> pinned staging (memcpy).  One thread moves 7-9 GB/s, the link takes 56.  Measured on the MI355X host (two
-// sockets, 256 hardware threads; tools/clibench.py, 8 GB FASTA in tmpfs): 16 threads left to the scheduler 42 GB/s end to end, 8
-// threads 29-34; spreading the workers over the L3 domains of BOTH sockets (KPAL_READ_PIN=1) 28 GB/s -- half of them then sit
-// on the socket the pinned buffer and the GPU are not attached to.  So: 16 workers (KPAL_READ_THREADS), not pinned.
+// pageable memory -> pinned staging (memcpy).  One thread moves 7-9 GB/s, the link takes 56.  The MI355X host has two sockets
+// (256 hardware threads, two NUMA nodes) and a GPU hangs on ONE of them: the pool's threads are bound to the CPUs of the GPU's
+// node (set_preferred_node: the first context says which; /sys/devices/system/node/nodeN/cpulist) and the pinned staging
+// buffers are allocated there (kpal_count.hip: ensure_pinned) -- left to the scheduler the same 16 threads gave 25 to 42 GB/s
+// end to end from one run to the next, depending on where they and the buffers happened to land; spread over the L3 domains of
+// BOTH sockets 28.  KPAL_READ_THREADS (default 16) sizes the pool, KPAL_READ_PIN=0 leaves its threads unbound.
 // The pool lives for the process (its threads sleep on a condition variable between jobs).
 #pragma once
 #include <condition_variable>
@@ -10,7 +12,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -23,6 +24,8 @@ namespace kpal {
 
 class HostPool {
 public:
+    // the NUMA node the pool's threads should run on (-1: unknown / no binding); takes effect if called before the first use
+    static void set_preferred_node(int node) { preferred_node() = node; }
     static HostPool &instance()
     {
         static HostPool *pool = new HostPool();   // never destroyed: its threads may outlive static destructors
@@ -63,6 +66,11 @@ public:
     }
 
 private:
+    static int &preferred_node()
+    {
+        static int node = -1;
+        return node;
+    }
     HostPool()
     {
         const char *e = getenv("KPAL_READ_THREADS");
@@ -71,48 +79,48 @@ private:
         if (hw && (unsigned)n > hw) n = (int)hw;
         n = n < 1 ? 1 : (n > 64 ? 64 : n);
         const char *p = getenv("KPAL_READ_PIN");
-        const bool pin = p && atoi(p) != 0;
-        std::vector<std::vector<int>> domains;
-        if (pin) domains = l3_domains();
+        const bool pin = !p || atoi(p) != 0;
+        cpu_set_t node_cpus;
+        const bool have = pin && node_cpu_set(preferred_node(), &node_cpus);
         for (int w = 0; w + 1 < n; ++w) {
             try {
                 workers_.emplace_back([this] { loop(); });
             } catch (...) {
                 break;
             }
-            if (domains.size() > 1) {
-                const std::vector<int> &d = domains[(size_t)(w + 1) % domains.size()];
-                cpu_set_t set;
-                CPU_ZERO(&set);
-                for (int c : d)
-                    if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
-                (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(set), &set);   // (a refusal changes nothing)
-            }
+            if (have) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(node_cpus), &node_cpus);   // (a refusal changes nothing)
         }
         for (auto &t : workers_) t.detach();
     }
 
-    // the CPUs this process may run on, grouped by the L3 cache they share
-    static std::vector<std::vector<int>> l3_domains()
+    // the CPUs of NUMA node `node` this process may run on (/sys/devices/system/node/nodeN/cpulist: "0-63,128-191")
+    static bool node_cpu_set(int node, cpu_set_t *out)
     {
-        std::vector<std::vector<int>> out;
+        if (node < 0) return false;
+        char path[96], line[4096];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        const bool ok = fgets(line, sizeof(line), f) != nullptr;
+        fclose(f);
+        if (!ok) return false;
         cpu_set_t allowed;
         CPU_ZERO(&allowed);
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
-        std::map<std::string, std::vector<int>> by_l3;
-        for (int c = 0; c < CPU_SETSIZE; ++c) {
-            if (!CPU_ISSET(c, &allowed)) continue;
-            char path[128], line[256];
-            snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
-            FILE *f = fopen(path, "r");
-            if (!f) return std::vector<std::vector<int>>();
-            const bool ok = fgets(line, sizeof(line), f) != nullptr;
-            fclose(f);
-            if (!ok) return std::vector<std::vector<int>>();
-            by_l3[line].push_back(c);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+        CPU_ZERO(out);
+        int count = 0;
+        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int lo = 0, hi = 0;
+            const int got = sscanf(tok, "%d-%d", &lo, &hi);
+            if (got < 1) continue;
+            if (got == 1) hi = lo;
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+                if (c >= 0 && CPU_ISSET(c, &allowed)) {
+                    CPU_SET(c, out);
+                    ++count;
+                }
         }
-        for (auto &kv : by_l3) out.push_back(kv.second);
-        return out;
+        return count > 0;
     }
 
     // Tasks are claimed and retired under the lock, tagged with the job they belong to: a worker that wakes late can never take

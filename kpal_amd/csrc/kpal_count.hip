@@ -11,6 +11,7 @@
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 static_assert(sizeof(ChunkPool) <= sizeof(kpal_ctx::chunk_pool_sent), "kpal_ctx::chunk_pool_sent holds a ChunkPool");
@@ -518,14 +519,35 @@ static void staged_memcpy(void *dst, const void *src, size_t n)
     });
 }
 
-static int ensure_pinned(kpal_ctx *ctx)
+// Page-locked host memory on the NUMA node the GPU is attached to: the calling thread's memory policy is set to "prefer that node"
+// around the allocation (raw set_mempolicy: libnuma is not a dependency) and hipHostMallocNumaUser lets the runtime honour it.  A
+// staging buffer on the other socket puts the inter-socket link into every DMA.  Any failure falls back to a plain allocation.
+int host_alloc_near_gpu(kpal_ctx *ctx, void **out, size_t nbytes)
 {
-    for (int i = 0; i < 2; ++i) {
-        if (!ctx->pinned[i]) {
-            hipError_t e = hipHostMalloc(&ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStageHead + kpal_ctx::kStagePad, hipHostMallocDefault);
-            if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+    *out = nullptr;
+    const int node = ctx->numa_node;
+    hipError_t e = hipErrorUnknown;
+    if (node >= 0 && node < 64) {
+        unsigned long mask = 1ul << node;
+        const long kPreferred = 1, kDefault = 0;   // MPOL_PREFERRED, MPOL_DEFAULT
+        if (syscall(SYS_set_mempolicy, kPreferred, &mask, 65ul) == 0) {
+            e = hipHostMalloc(out, nbytes, hipHostMallocNumaUser);
+            (void)syscall(SYS_set_mempolicy, kDefault, nullptr, 0ul);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                *out = nullptr;
+            }
         }
     }
+    if (!*out) e = hipHostMalloc(out, nbytes, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
+    return KPAL_OK;
+}
+
+static int ensure_pinned(kpal_ctx *ctx)
+{
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->pinned[i]) CHK(host_alloc_near_gpu(ctx, &ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStageHead + kpal_ctx::kStagePad));
     return KPAL_OK;
 }
 
@@ -592,10 +614,7 @@ KPAL_API int kpal_host_alloc(kpal_ctx *ctx, size_t nbytes, void **host_out)
 {
     CTX_ENTER(ctx);
     if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
-    *host_out = nullptr;
-    hipError_t e = hipHostMalloc(host_out, nbytes ? nbytes : 16, hipHostMallocDefault);
-    if (e != hipSuccess) return set_err(KPAL_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", nbytes, hipGetErrorString(e));
-    return KPAL_OK;
+    return host_alloc_near_gpu(ctx, host_out, nbytes ? nbytes : 16);
 }
 
 KPAL_API int kpal_host_free(kpal_ctx *ctx, void *host)

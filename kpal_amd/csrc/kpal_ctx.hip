@@ -97,6 +97,20 @@ static int ctx_init(kpal_ctx *ctx, int device)
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // the host NUMA node the GPU hangs on: /sys/bus/pci/devices/<domain:bus:device.function>/numa_node
+        char bus[32] = "", path[128];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) == hipSuccess && bus[0]) {
+            for (char *q = bus; *q; ++q) *q = (char)tolower((unsigned char)*q);
+            snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+            if (FILE *f = fopen(path, "r")) {
+                int node = -1;
+                if (fscanf(f, "%d", &node) == 1 && node >= 0) ctx->numa_node = node;
+                fclose(f);
+            }
+        }
+        (void)hipGetLastError();
+        HostPool::set_preferred_node(ctx->numa_node);   // (the first context of the process decides where the copy threads run)
+    }
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {

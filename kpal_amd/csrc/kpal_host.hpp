@@ -64,6 +64,7 @@ struct kpal_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;
     int num_cu = 256;
+    int numa_node = -1;                      // NUMA node of the host the GPU is attached to (-1: unknown): staging buffers and copy threads go there
     // counting state
     int k = 0;
     int strategy = KPAL_STRATEGY_AUTO;
