@@ -534,7 +534,7 @@ def test_bench_traffic_comes_from_the_committed_profiles():
     import bench
     nbytes = 100_000_000 * 151
     here = bench.source_sha()
-    for k, names in ((12, ('quad_sample', 'quad_scatter', 'quad_hist', 'balance_tiled')),
+    for k, names in ((12, ('quad_sample', 'quad_scatter', 'quad_hist', 'quad2_finalize_balanced')),
                      (15, ('quad_sample', 'quad_scatter', 'quad2_scatter', 'quad_hist', 'quad2_finalize_balanced', 'quad2_apply_list'))):
         kernels = {n: (1.0, 1) for n in names}
         info = bench.pmc_traffic(kernels, 'quad_scatter', k, nbytes)
@@ -547,5 +547,8 @@ def test_bench_traffic_comes_from_the_committed_profiles():
         table = 8 * 4 ** k
         if k == 15:
             assert 1.4 * table < per['quad2_finalize_balanced'] < 1.6 * table    # forms read (4 B per entry), table written: not scaled
+        else:
+            assert 2.3 * table < per['quad2_finalize_balanced'] < 2.7 * table    # k = 12 (not FRESH): table read + forms read + table written
+            assert per['quad_hist'] < 1.1 * nbytes                               # the records read once, 64 MiB of staged forms written
         assert info['traffic_step'] == pytest.approx(sum(per.values()))
         assert 2.5 * nbytes < info['traffic_step'] < 7 * nbytes
