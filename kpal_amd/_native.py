@@ -260,7 +260,7 @@ class Context(object):
 
     def close(self):
         if getattr(self, '_h', None):
-            self._L.kpal_ctx_destroy(self._h)
+            self._L.kpal_ctx_destroy(self._h)      # (also releases what host_alloc handed out: views of it dangle from here on)
             self._h = None
 
     def __del__(self):

@@ -614,15 +614,20 @@ KPAL_API int kpal_host_alloc(kpal_ctx *ctx, size_t nbytes, void **host_out)
 {
     CTX_ENTER(ctx);
     if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
-    return host_alloc_near_gpu(ctx, host_out, nbytes ? nbytes : 16);
+    CHK(host_alloc_near_gpu(ctx, host_out, nbytes ? nbytes : 16));
+    ctx->host_allocs.push_back(*host_out);
+    return KPAL_OK;
 }
 
 KPAL_API int kpal_host_free(kpal_ctx *ctx, void *host)
 {
     CTX_ENTER(ctx);
     if (!host) return KPAL_OK;
+    auto it = std::find(ctx->host_allocs.begin(), ctx->host_allocs.end(), host);
+    if (it == ctx->host_allocs.end()) return set_err(KPAL_E_INVALID, "not a buffer of kpal_host_alloc of this context");
     HIPCHK(hipStreamSynchronize(ctx->copy_stream));
     HIPCHK(hipHostFree(host));
+    ctx->host_allocs.erase(it);
     return KPAL_OK;
 }
 
@@ -813,11 +818,11 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         }
         if (!hp) {
             if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // the slot's previous DMA out of the pinned buffer
-            const size_t c = std::min(carry.size(), std::min(head, stage / 2));              // (carry.size() <= head whenever it is set)
+            const size_t c = carry.size();                                                   // (<= head whenever it is set: all of it goes in front)
             hp = (uint8_t *)ctx->pinned[slot] + head - c;
             if (c) memcpy(hp, carry.data(), c);
             carry.clear();
-            const long got = fa_fill(src, hp + c, stage - c, &from_range);
+            const long got = fa_fill(src, hp + c, stage - std::min(c, stage / 2), &from_range);
             if (got < 0) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
             if (got == 0 && c == 0) break;
             n = c + (size_t)got;

@@ -187,6 +187,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->fa_nflat_host) (void)hipHostFree(ctx->fa_nflat_host);
+    for (void *p : ctx->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
         if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);

@@ -119,6 +119,7 @@ struct kpal_ctx {
     // the previous chunk (the k-1 bytes the next one's first windows begin in), the chunks' flattened sizes in pinned host memory
     DevBuf fa_raw[2], fa_flat[2], fa_meta[2], fa_tail;
     uint64_t *fa_nflat_host = nullptr;
+    std::vector<void *> host_allocs;         // kpal_host_alloc buffers still owned by callers (released with the context at the latest)
     size_t fa_chunk = kStage;                // text bytes per chunk (KPAL_FASTA_CHUNK: tests put the seams everywhere)
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;

@@ -374,3 +374,33 @@ def test_sharded_fasta_count_through_rccl_world_1(tmp_path, tutorial_dir):
                         '--master-port', '29611', str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'DIST_COUNT_OK' in out, out[-3000:]
+
+
+@pytest.mark.parametrize('env', [{'KPAL_READ_THREADS': '1'}, {'KPAL_READ_PIN': '0', 'KPAL_READ_THREADS': '3'}])
+def test_ingest_with_other_pool_settings(tmp_path, env):
+    """The host copy pool (csrc/host_pool.hpp) is sized and bound when it is first used, once per process: a child process per
+    setting -- a pool of one (every copy on the calling thread), three unbound threads -- counts a multi-chunk FASTA file and a
+    large host feed and must reproduce the default's tables."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    buf = oracle.synth_reads(29, 0, 600000, 150, noisy=True)                     # 90 MB: two staging pieces, several preads each
+    path = tmp_path / 'p.fa'
+    with open(path, 'wb') as fh:
+        fh.write(b'>r\n')
+        fh.write(buf.tobytes())
+    want = oracle.count_flat(buf, 11, threads=8)
+    np.save(tmp_path / 'want.npy', want)
+    code = ('import sys, numpy as np\n'
+            'sys.path.insert(0, %r)\n'
+            'from kpal_amd import klib, _native\n'
+            'want = np.load(%r)\n'
+            'with open(%r) as fh:\n'
+            '    p = klib.Profile.from_fasta(fh, 11)\n'
+            'assert np.array_equal(p.counts, want), "file"\n'
+            'ctx = _native.context()\n'
+            'raw = np.fromfile(%r, dtype=np.uint8)[3:]\n'
+            'assert np.array_equal(ctx.count_bytes(11, raw), want), "host feed"\n'
+            'print("POOL_OK")\n') % (root, str(tmp_path / 'want.npy'), str(path), str(path))
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and b'POOL_OK' in p.stdout, p.stdout.decode()[-2000:]
