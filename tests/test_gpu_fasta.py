@@ -389,18 +389,19 @@ def test_ingest_with_other_pool_settings(tmp_path, env):
     with open(path, 'wb') as fh:
         fh.write(b'>r\n')
         fh.write(buf.tobytes())
-    want = oracle.count_flat(buf, 11, threads=8)
+    want = oracle.count_flat(buf, 11, threads=8)                                 # as a host feed: every line a sequence of its own
+    joined = np.ascontiguousarray(buf.reshape(-1, 151)[:, :150]).reshape(-1)     # as ONE FASTA record: the lines are joined
     np.save(tmp_path / 'want.npy', want)
+    np.save(tmp_path / 'want_record.npy', oracle.count_flat(joined, 11, threads=8))
     code = ('import sys, numpy as np\n'
             'sys.path.insert(0, %r)\n'
             'from kpal_amd import klib, _native\n'
-            'want = np.load(%r)\n'
             'with open(%r) as fh:\n'
             '    p = klib.Profile.from_fasta(fh, 11)\n'
-            'assert np.array_equal(p.counts, want), "file"\n'
+            'assert np.array_equal(p.counts, np.load(%r)), "file"\n'
             'ctx = _native.context()\n'
             'raw = np.fromfile(%r, dtype=np.uint8)[3:]\n'
-            'assert np.array_equal(ctx.count_bytes(11, raw), want), "host feed"\n'
-            'print("POOL_OK")\n') % (root, str(tmp_path / 'want.npy'), str(path), str(path))
+            'assert np.array_equal(ctx.count_bytes(11, raw), np.load(%r)), "host feed"\n'
+            'print("POOL_OK")\n') % (root, str(path), str(tmp_path / 'want_record.npy'), str(path), str(tmp_path / 'want.npy'))
     p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0 and b'POOL_OK' in p.stdout, p.stdout.decode()[-2000:]
