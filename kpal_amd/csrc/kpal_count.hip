@@ -680,29 +680,32 @@ struct FaSource {
     bool more() const { return prefix_left > 0 || pos < end; }
 };
 
-static bool pread_all(int fd, uint8_t *dst, size_t n, uint64_t off)
+// (returns 0, or the errno of the failed read; EIO when the file turned out shorter than its size said)
+static int pread_all(int fd, uint8_t *dst, size_t n, uint64_t off)
 {
     while (n) {
         const ssize_t r = pread(fd, dst, n, (off_t)off);
         if (r < 0 && errno == EINTR) continue;
-        if (r <= 0) return false;   // error, or the file is shorter than its size said
+        if (r < 0) return errno ? errno : EIO;
+        if (r == 0) return EIO;
         dst += r;
         off += (uint64_t)r;
         n -= (size_t)r;
     }
-    return true;
+    return 0;
 }
 
 // n bytes of the source's range from `pos` into dst, by the pool: the page cache hands ONE reader ~9 GB/s (a copy_to_user per
 // page), the link takes 56.  start: the pool's workers copy while the caller does something else; ok[] says afterwards
-// (HostPool::wait) whether every part arrived.  Pieces below 4 MiB are not split.
-static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t n, std::vector<char> &ok)
+// (HostPool::wait) whether every part arrived (0, or the errno of its reader: errno itself is per thread).  Pieces below 4 MiB
+// are not split.
+static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t n, std::vector<int> &ok)
 {
     HostPool &pool = HostPool::instance();
     const int parts = std::max(1, (int)std::min<size_t>((size_t)pool.size(), n / ((size_t)4 << 20)));
     const size_t part = (((n + (size_t)parts - 1) / (size_t)parts) + 4095) & ~(size_t)4095;
-    ok.assign((size_t)parts, 1);
-    char *flags = ok.data();
+    ok.assign((size_t)parts, 0);
+    int *flags = ok.data();
     const int fd = s.fd;
     const uint8_t *mem = s.mem;
     pool.start(parts, [=](int i) {
@@ -710,7 +713,7 @@ static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t 
         if (off >= n) return;
         const size_t len = std::min(part, n - off);
         if (mem) memcpy(dst + off, mem + pos + off, len);
-        else flags[i] = pread_all(fd, dst + off, len, pos + off) ? 1 : 0;
+        else flags[i] = pread_all(fd, dst + off, len, pos + off);
     });
 }
 
@@ -728,11 +731,14 @@ static long fa_fill(FaSource &s, uint8_t *dst, size_t want, size_t *from_range)
     }
     const size_t n = (size_t)std::min<uint64_t>(want - got, s.end - s.pos);
     if (n) {
-        std::vector<char> ok;
+        std::vector<int> ok;
         fa_copy_start(s, dst + got, s.pos, n, ok);
         HostPool::instance().wait();
-        for (char f : ok)
-            if (!f) return -1;
+        for (int e : ok)
+            if (e) {
+                errno = e;
+                return -1;
+            }
         s.pos += n;
         got += n;
     }
@@ -765,7 +771,7 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         int slot = 0;
         uint64_t pos = 0;
         size_t n = 0;
-        std::vector<char> ok;
+        std::vector<int> ok;
         ~ReadAhead()
         {
             if (active) HostPool::instance().wait();   // (an error return must not leave the pool writing into the staging buffer)
@@ -805,8 +811,8 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         if (ra.active) {
             HostPool::instance().wait();
             ra.active = false;
-            for (char f : ra.ok)
-                if (!f) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
+            for (int e : ra.ok)
+                if (e) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(e));
             if (ra.pos == src.pos && ra.slot == slot && carry.size() <= head) {
                 hp = (uint8_t *)ctx->pinned[slot] + head - carry.size();
                 if (!carry.empty()) memcpy(hp, carry.data(), carry.size());
@@ -874,8 +880,8 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         uint8_t *raw = (uint8_t *)ctx->fa_raw[slot].p;
         uint8_t *flat = (uint8_t *)ctx->fa_flat[slot].p + pad;
         long long *last_eol = (long long *)ctx->fa_meta[slot].p;
-        long long *carry = last_eol + nblocks;
-        uint64_t *offs = (uint64_t *)(carry + nblocks);
+        long long *eol_before = last_eol + nblocks;
+        uint64_t *offs = (uint64_t *)(eol_before + nblocks);
         uint32_t *kept = (uint32_t *)(offs + nblocks + 1);
         // the device copy of the raw text is free once the flattening that read it is done (two chunks ago)
         if (ctx->stage_used[slot]) HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[slot], 0));
@@ -883,11 +889,11 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
         LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, last_eol);
-        LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, carry);
-        LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)carry, state, kept);
+        LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, eol_before);
+        LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)eol_before, state, kept);
         LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
         LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m,
-               (const long long *)carry, state, (const uint64_t *)offs, flat);
+               (const long long *)eol_before, state, (const uint64_t *)offs, flat);
         HIPCHK(hipMemcpyAsync(&ctx->fa_nflat_host[slot], offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
         ctx->stage_used[slot] = true;
