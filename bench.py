@@ -684,7 +684,8 @@ def stub_rank(args):
     arithmetic, one reduce(SUM) of int64 tables to rank 0 per step, max-over-ranks timing, the per-bin comparison of the merged
     table with the single-stream one, rank 0's JSON line.  Exists so that the launcher / supervisor path of `python bench.py
     --gpus N` can be tested where there is no GPU; `value` is null.  --stub-hang-attempt A: every worker of attempt A stops
-    responding after it has started; --stub-fail-rank R: rank R's worker of attempt 1 dies before the rendezvous."""
+    responding after it has started; --stub-fail-rank R: rank R's worker of attempt 1 dies before the rendezvous;
+    --stub-hang-after-headline: rank 0 publishes its line (as after the headline reduce mode), then every worker hangs."""
     import torch
     import torch.distributed as td
     from kpal_amd import dist as kdist
@@ -718,6 +719,11 @@ def stub_rank(args):
                 'checksum_ok': same, 'merged_equals_single_stream': same, 'attempt': args.attempt, 'scaling': 'weak', 'data': 'synthetic'}
         if args.fallback_reason:
             line['fallback_reason'] = args.fallback_reason
+        if args.worker and args.stub_hang_after_headline:
+            set_flag(args.attempt, 'line', text=json.dumps(line))     # the headline mode is measured and verified ...
+    if args.stub_hang_after_headline:
+        time.sleep(3600)                                              # ... and a later mode never returns
+    if rank == 0:
         print(json.dumps(line), flush=True)
         if args.worker:
             set_flag(args.attempt, 'done')
@@ -951,6 +957,7 @@ def main():
     ap.add_argument('--stub', action='store_true', help='plumbing self-test on CPU/gloo, no counting (tests of the launcher and the supervisors)')
     ap.add_argument('--stub-hang-attempt', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--stub-fail-rank', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--stub-hang-after-headline', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)           # set by supervise_rank
     ap.add_argument('--attempt', type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument('--fallback-reason', default=None, help=argparse.SUPPRESS)

@@ -343,6 +343,23 @@ def test_bench_launcher_spawns_the_ranks():
     assert p.returncode != 0
 
 
+def test_bench_supervisor_keeps_a_measured_headline():
+    """A hang AFTER the headline reduce mode has been measured and verified (rank 0 publishes its line at that point) must not cost
+    the measurement: the supervisors end the attempt, rank 0's prints the published line with `later_modes_failed`, nobody starts
+    a second attempt, the job exits 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(KPAL_BENCH_RUN_TIMEOUT='4', KPAL_BENCH_STARTUP_TIMEOUT='120')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0', '--stub', '--stub-hang-after-headline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['attempt'] == 1 and line['merged_equals_single_stream'] is True and 'did not finish within' in line['later_modes_failed']
+    assert 'attempt 2' not in p.stderr.decode()
+
+
 @pytest.mark.parametrize('fault', ['hang', 'rank_dies'])
 def test_bench_supervisor_falls_back_to_a_fresh_worker(fault):
     """A first multi-GPU attempt that never returns must still end in a line: every rank under torch.distributed.run is a
