@@ -1010,7 +1010,16 @@ def main():
     if not args.no_cpu:
         line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
     if not args.no_extra and k == 12 and args.strategy == 'auto':
-        line['extra'] = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
+        line['extra'] = ex = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
+        # the other BASELINE configs and the host-resident figures as SCALARS of `config` (the driver's record keeps scalars only)
+        for key, src, field in (('config4_k15_ms_per_step', 'k15', 'ms_per_step'), ('config4_k15_Gbases_per_s', 'k15', 'value'),
+                                ('config5_matrix_prod_ms', 'matrix_prod', 'ms_per_step'), ('config5_matrix_euclidean_ms', 'matrix_euclidean', 'ms_per_step'),
+                                ('host_reads_overlapped_Gbases_per_s', 'end_to_end', 'overlapped_Gbases_per_s'),
+                                ('fasta_file_Gbases_per_s', 'fasta_end_to_end', 'Gbases_per_s')):
+            if isinstance(ex.get(src), dict) and field in ex[src]:
+                line['config'][key] = ex[src][field]
+        line['config']['extras_ok'] = all(v.get('checksum_ok', True) is True and 'error' not in v for v in ex.values() if isinstance(v, dict))
+    line['config']['checksum_ok'] = r['checksum_ok']
     print(json.dumps(line), flush=True)
     ctx.free(dev_buf)
     ctx.close()
