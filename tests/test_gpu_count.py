@@ -907,6 +907,20 @@ def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
         else:
             klib._gather_buffers[default] = saved
         ctx.host_free(small[0])
+    # a page-locked buffer larger than one 64 MiB staging piece fed in place: the seams carry their k - 1 bytes of halo
+    big = oracle.synth_reads(62, 0, 900000, 150, noisy=True)                     # 136 MB
+    seq = np.ascontiguousarray(big.reshape(-1, 151)[:, :150]).reshape(-1)        # one unbroken sequence: every seam matters
+    address, view = ctx.host_alloc(seq.size)
+    try:
+        view[:] = seq
+        for k in (5, 12):
+            ctx.count_begin(k)
+            ctx.count_feed_pinned(address, seq.size)
+            np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(seq, k, threads=8))
+    finally:
+        ctx.host_free(address)
+    with pytest.raises(ValueError):
+        ctx.host_free(address)                                                   # not (any more) a buffer of this context
     # the interpreter's join (no extension) gives the same stream
     monkeypatch.setattr(klib, '_kpal_join', None)
     np.testing.assert_array_equal(klib.Profile.from_sequences(items, 9).counts, oracle.from_sequences(as_text, 9))

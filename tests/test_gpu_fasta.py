@@ -191,7 +191,8 @@ def test_chunk_seams_everywhere(tmp_path):
     from kpal_amd import _native
     rnd = random.Random(31)
     texts = ['no header at all\nACGT\n', '>only header', '>h\nACGT', 'junk\njunk2\n>a desc\nAC\nGT\n>b\n\n>c\nTT',
-             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\nACGTACGTAC\r\n', '>t\nAC \t \nGT\tA  \t\nACGT\n', '>' + 'h' * 300 + '\nACGTACGTACGTACGT\n' * 5]
+             '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\nACGTACGTAC\r\n', '>t\nAC \t \nGT\tA  \t\nACGT\n', '>' + 'h' * 300 + '\nACGTACGTACGTACGT\n' * 5,
+             'junk\r>a x\rACGTAC\rGTTGCA\r>b\r\rTTGACC\r', '>only\n' + 'ACGT' * 50 + ' \t' * 40 + '\n' + 'TTGCA' * 30 + '\t' * 9 + 'ACG\n']
     for _ in range(10):
         texts.append(random_fasta(rnd, rnd.randint(1, 12), 3000, eol=rnd.choice(['\n', '\n', '\r\n'])))
     texts.append(random_fasta(rnd, 3, 60000))
