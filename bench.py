@@ -355,6 +355,11 @@ def count_roofline(kern, k, n_bytes_step, bins, steps, ms_per_step, fused_balanc
     if r.get('traffic_step'):
         r['traffic_step_over_algorithmic'] = r['traffic_step'] / alg_step
         r['traffic_step_rate_GBs'] = r['traffic_step'] / (ms_per_step * 1e-3) / 1e9
+    if r.get('traffic'):
+        # what the dominant kernel MOVES (PMC bytes per launch over its live duration) next to what it is priced on: the scatter
+        # reads its input and writes as many bytes of records, so its memory pipes carry twice `achieved`
+        r['traffic_rate_GBs'] = r['traffic'] / (avg_ms * 1e-3) / 1e9
+        r['traffic_frac_of_peak'] = r['traffic_rate_GBs'] / HBM_PEAK_GBS
     r['limiter'] = pmc_limiter(dom, k)
     return r
 
