@@ -463,6 +463,28 @@ __device__ __forceinline__ void quad_take_carried(const QuadSpill *spill, uint32
     }
 }
 
+// Wave priority inside a tile of the scatter kernels.  The sixteen waves of a workgroup -- four per SIMD -- have the same STEPS
+// wave-steps to do between two barriers, but a SIMD's arbiter prefers its oldest wave: the four finished one after the other, and
+// per-phase cycle counters (round 4) showed a wave waiting at the barrier behind the placement for 27 % of the kernel while the
+// last wave of its SIMD ran alone, every LDS round trip exposed.  So a wave's priority FALLS as it advances through the tile
+// (s_setprio 3, 2, 1, 0 over the four quarters): whoever is behind is served first and the four arrive together.  k = 12, 100 M
+// reads: 6.87 -> 6.03 ms; level 1 of k = 15: 6.24 -> 5.61 ms (same-box A/B against -DKPAL_QUAD_NO_PRIO).
+template <int STEPS>
+__device__ __forceinline__ void quad_tile_priority(int st)
+{
+#if !defined(KPAL_QUAD_NO_PRIO)   // A/B builds
+    const int level = st * 4 / STEPS;             // (the unrolled step loop folds this: s_setprio takes an immediate)
+    if (st == 0 || level != (st - 1) * 4 / STEPS) {
+        switch (level) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    }
+#endif
+}
+
 // Q0: row loads of a sample of the input.  Workgroup g encodes `steps` wave-steps starting at its share of the
 // stream and adds every item to load[row] (global atomics: a few hundred thousand).  The host picks the tile size
 // from these loads: rows that would be over-full every round (compositional skew, e.g. an AT-rich genome) call
@@ -649,6 +671,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         for (int st = 0; st < STEPS; ++st) {
             uint64_t window;
             uint32_t mask;
+            quad_tile_priority<STEPS>(st);
             encode_step<K>(s, first + st, raw[st % DEPTH], carry, window, mask, edge);
             // the previous round's records leave AFTER this step's chunk has been consumed: the compiler guards the first use of
             // raw[] in a tile with s_waitcnt vmcnt(0) (the loads were issued a tile ago, under conditions it cannot count) --
@@ -678,6 +701,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 #endif
         }
         have_rec = false;
+        quad_tile_priority<1>(0);                // (the flush and the carried items: everybody is needed at the next barrier)
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
         const uint32_t spilled = min(*spill_n, CAP);         // (beyond CAP: counted directly by quad_place); reset only during the flush of the NEXT tile
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
@@ -907,6 +931,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         if (more) seek(j + 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
+            quad_tile_priority<STEPS>(st);
             const uint4 v = raw[st];
             const uint32_t it[4] = {v.x, v.y, v.z, v.w};
             uint32_t row[4], item[4];
@@ -926,6 +951,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
             quad_place<K, false, 2, 4, TableSinkRef>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
         }
         have_rec = false;
+        quad_tile_priority<1>(0);
         lds_barrier();
         const uint32_t spilled = min(*spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;
@@ -1146,6 +1172,20 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         const uint4 *src = C::kPairRows
                                ? reinterpret_cast<const uint4 *>(pool + ((uint64_t)((row_linear >> 1) * G + g) * rounds_cap) * (2 * S) + (row_linear & 1u) * S)
                                : reinterpret_cast<const uint4 *>(pool + ((uint64_t)(row_linear * G + g) * rounds_cap) * S);
+#if !defined(KPAL_QUAD_NO_PRIO)   // A/B builds
+        // The wave that is behind in its runs goes first (quad_tile_priority: the arbiter's oldest-first order let the waves of a SIMD
+        // finish one after the other, and the LDS idled under the last ones): k = 12 3.79 -> 3.58 ms, k = 11 3.35 -> 3.19, k = 13
+        // 3.85 -> 3.63.  Not when waves SHARE a run (G < 16; k = 15, 16): g then says nothing about progress, and the same switch
+        // cost that histogram 8 %.
+        if (parts == 1u) {
+            switch (g * 4u / G) {
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
+        }
+#endif
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
         if (nvec == 0u) continue;                  // wave-uniform: this scatter workgroup wrote nothing
         // four 16-byte loads per lane in flight; the next four are requested before these are counted.  The loads are
@@ -1189,6 +1229,9 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             q3 = n3;
         }
     }
+#if !defined(KPAL_QUAD_NO_PRIO)
+    __builtin_amdgcn_s_setprio(3);               // (staging / merging: every wave is needed)
+#endif
     __syncthreads();
     if (stage) {
         // two-level path: every table entry would receive four atomic adds (one per form, from four different

@@ -777,6 +777,21 @@ __global__ __launch_bounds__(256) void matrix_super_kernel(const int64_t *__rest
         }
 }
 
+// Wave priority by progress (quad_kernels.hpp: quad_tile_priority): the workgroups of the staged matrix kernels run a few thousand
+// stages each, four to a CU, and the arbiter's oldest-first order let them finish one after the other -- the last one of a CU
+// alone.  A workgroup's priority falls with the share of its stages it has done.
+__device__ __forceinline__ void matrix_stage_priority(uint64_t done, uint64_t total)
+{
+#if !defined(KPAL_MATRIX_NO_PRIO)   // A/B builds
+    switch ((uint32_t)(done * 4u / total)) {     // (block-uniform scalars)
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+#endif
+}
+
 // Multiset with the 'prod' pairwise function (the default of kpal distance / matrix; metrics.py:101-123, 159-162) as a
 // difference of reciprocals:
 //        |x - y| / ((x + 1)(y + 1))  =  |(x + 1) - (y + 1)| / ((x + 1)(y + 1))  =  | 1/(y + 1) - 1/(x + 1) |.
@@ -906,8 +921,10 @@ __global__ __launch_bounds__(256) void matrix_rdiff_kernel(const int64_t *__rest
     }
     __syncthreads();
     int cur = 0;
+    const uint64_t my_stages = group < chunks ? (chunks - group + ngroups - 1) / ngroups : 1;
     for (; c < chunks; c += ngroups, ++stages) {
         const bool more = c + ngroups < chunks;        // block-uniform
+        if ((stages & 15u) == 0) matrix_stage_priority(stages, my_stages);
         request(next, c + ngroups);
         compute(cur);
         if (more) {
@@ -1047,8 +1064,10 @@ __global__ __launch_bounds__(256) void matrix_rsum_kernel(const int64_t *__restr
     }
     __syncthreads();
     int cur = 0;
+    const uint64_t my_stages = group < chunks ? (chunks - group + ngroups - 1) / ngroups : 1;
     for (; c < chunks; c += ngroups, ++stages) {
         const bool more = c + ngroups < chunks;
+        if ((stages & 15u) == 0) matrix_stage_priority(stages, my_stages);
         request(next, c + ngroups);
         compute(cur);
         if (more) {
