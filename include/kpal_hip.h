@@ -60,7 +60,7 @@ extern "C" {
 #define KPAL_STRATEGY_PARTITION 3     /* exact-offset radix partition (count, scan, scatter, histogram); 8 <= k <= 12 */
 #define KPAL_STRATEGY_PARTITION_CHUNKED 5 /* one-pass partition into chunked bucket lists (no counting pass); 8 <= k <= 12; AUTO */
 #define KPAL_STRATEGY_PARTITION2 4    /* two-level radix partition; 13 <= k <= 16 */
-#define KPAL_STRATEGY_PARTITION2_QUADS 7 /* two-level partition of 4-k-mer items (quad_kernels.hpp); 13 <= k <= 16; AUTO for feeds >= 64 MiB */
+#define KPAL_STRATEGY_PARTITION2_QUADS 7 /* two-level partition of 4-k-mer items (quad_kernels.hpp); 13 <= k <= 16; AUTO for feeds >= 64 MiB that hold 1/8 byte per table entry (first piece of a count, a whole device buffer) or 3 bytes (any other) */
 #define KPAL_STRATEGY_PARTITION_QUADS 6 /* partition of 4-k-mer items into aligned records (quad_kernels.hpp); 8 <= k <= 12; AUTO for feeds >= 32 MiB */
 
 typedef struct kpal_ctx kpal_ctx;

@@ -386,12 +386,21 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
     else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
-    // the two-level quad pipeline stages and combines 16 bytes per TABLE ENTRY whatever the feed holds (k = 15: 17 GB written,
-    // 34 GB combined): it wins once the feed is about half as large as the table (k = 15: 44 vs 59 ms on 15 GB, but 11.8 vs
-    // 8.7 ms on 1 GiB); below that the round-1 two-level pipeline stays
-    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS &&
-             n < std::max<size_t>((size_t)64 << 20, (size_t)(ctx->bins * 4)))
-        strat = KPAL_STRATEGY_PARTITION2;
+    // The two-level quad pipeline pays per FEED for the whole table -- its forms are staged (4 bytes per entry) and the finalisation
+    // reads them and the table and writes the table -- where the round-1 two-level pipeline adds into the table with atomics and
+    // pays for the table once per count (memset, Profile.balance).  Measured at the end of round 4 (same box, count + balance,
+    // 68 MB .. 15 GB of reads): a feed that is the FIRST piece of a count and a whole device buffer (FRESH: no memset, the table
+    // not read, the balance fused) is faster through the quads at every size from 64 MiB up -- k = 15: 4.7 vs 9.5 ms on 68 MB, 8.6
+    // vs 23.7 on 4.2 GB; k = 16: 19.3 vs 30.5 and 24.2 vs 54.6, and 34.9 vs 92.8 ms on the 15.1 GB of BASELINE's reads, which the
+    // earlier rule (feed >= 4 bytes per table entry, from round-2 timings of both pipelines) still sent to the old pipeline --
+    // except that a count that is never balanced loses ~7 % below an eighth of a byte per entry (k = 16).  Any other feed (a later
+    // piece, a piece of a host feed, a FASTA chunk) takes the quads once it holds about three bytes per table entry (the per-feed
+    // crossover computed from the same timings: 2.8 B per entry at k = 15, 1.5 at k = 16).
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION2_QUADS) {
+        const bool fresh_piece = ctx->table_zero_pending && ctx->fresh_feed && halo == 0;
+        const size_t need = fresh_piece ? (size_t)(ctx->bins / 8) : (size_t)(ctx->bins * 3);
+        if (n < std::max<size_t>((size_t)64 << 20, need)) strat = KPAL_STRATEGY_PARTITION2;
+    }
     const size_t km1 = (size_t)ctx->k - 1;
     size_t piece = n;
     if (strat == KPAL_STRATEGY_PARTITION) piece = ctx->batch_bytes;

@@ -992,3 +992,40 @@ def test_k12_staged_forms_and_fused_balance():
     finally:
         staged.close()
         atomic.close()
+
+
+@pytest.mark.gpu
+def test_auto_two_level_choice_fresh_and_later_pieces(ctx):
+    """AUTO at k >= 13 (kpal_count.hip: count_device_range): the FIRST piece of a count that is a whole device buffer of at least
+    64 MiB and an eighth of a byte per table entry goes through the two-level quad pipeline (FRESH table, fused balance); a later
+    piece only once it holds three bytes per entry -- below that the round-1 two-level pipeline adds into the finished table.
+    Both orders, with and without the balance, against the oracle run on the whole input."""
+    k, n_reads = 13, 560_000                              # 84.6 MB per piece; 4^13 / 8 = 8.4 MB, 3 * 4^13 = 201 MB
+    nbytes = n_reads * 151
+    host = oracle.synth_reads(77, 0, 2 * n_reads, 150, noisy=True)
+    want = oracle.count_flat(host, k, threads=8)
+    d = ctx.alloc(2 * nbytes)
+    try:
+        ctx.h2d(d, host)
+        for balance in (False, True):
+            ctx.count_begin(k)
+            ctx.count_feed_device(d, nbytes)
+            assert ctx.count_last_plan()[0] == 'partition2_quads'
+            ctx.count_feed_device(d + nbytes, nbytes)
+            assert ctx.count_last_plan()[0] == 'partition2'
+            if balance:
+                ctx.count_balance()
+            got = ctx.count_finish()
+            np.testing.assert_array_equal(got, oracle.balance(want, k) if balance else want)
+        # one piece of both halves: still the first piece of its count
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, 2 * nbytes)
+        assert ctx.count_last_plan()[0] == 'partition2_quads'
+        np.testing.assert_array_equal(ctx.count_finish(), want)
+        # a first piece below 64 MiB stays with the round-1 pipeline
+        ctx.count_begin(k)
+        ctx.count_feed_device(d, 40 << 20)
+        assert ctx.count_last_plan()[0] == 'partition2'
+        np.testing.assert_array_equal(ctx.count_finish(), oracle.count_flat(host[:40 << 20], k, threads=8))
+    finally:
+        ctx.free(d)
