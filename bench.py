@@ -149,7 +149,7 @@ def pmc_limiter(dom, k):
 def cpu_baseline(k, read_len, budget_reads):
     """CPU figures next to the GPU number (reported baselines, never the target):
     the oracle's C port (kpal/klib.py:149-170 restated) on a bounded sample of the same workload with 1
-    thread and with all host cores (one shared table, relaxed atomic adds), and the pure-Python
+    thread and with all host cores (a private table per thread or one shared table, whichever is faster), and the pure-Python
     restatement of the reference's loop on BASELINE config 1 (the reference's own speed class)."""
     import oracle
     from oracle import pyref
@@ -159,17 +159,31 @@ def cpu_baseline(k, read_len, budget_reads):
     t0 = time.perf_counter()
     c1 = oracle.count_flat(buf, k, threads=1)
     t1 = time.perf_counter() - t0
-    # all cores: one shared table, relaxed atomic adds; on a many-socket host fewer threads can be faster (cache-line
-    # ping-pong), so a few thread counts are timed and the best is reported with its own core count
-    tn, best_threads, tried = None, cores, {}
-    for threads in sorted(set([cores, min(cores, 64), min(cores, 16)]), reverse=True):
+    # all cores: every thread its own 4^k table (calloc and the merge inside the timed region), as many threads as the host has
+    # hardware threads and memory for (a quarter of MemAvailable at most); and ONE shared table with relaxed atomic adds, which
+    # stops scaling early (cache-line ping-pong) -- a few thread counts of each are timed and the best is reported with its own
+    # thread count
+    avail = 64 << 30
+    try:
+        with open('/proc/meminfo') as fh:
+            for ln in fh:
+                if ln.startswith('MemAvailable:'):
+                    avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    table_bytes = 8 * 4 ** k
+    most_private = max(1, min(cores, 256, (avail // 4) // table_bytes))
+    tn, best_threads, best_mode, tried = None, cores, 'shared', {}
+    plans = [('private', t) for t in sorted(set([most_private, max(1, most_private // 2), min(most_private, 64)]), reverse=True)]
+    plans += [('shared', t) for t in sorted(set([min(cores, 64), min(cores, 16)]), reverse=True)]
+    for mode, threads in plans:
         t0 = time.perf_counter()
-        cn = oracle.count_flat(buf, k, threads=threads)
+        cn = oracle.count_flat(buf, k, threads=threads, mode=mode)
         t = time.perf_counter() - t0
-        tried[str(threads)] = t
+        tried['%s_%d' % (mode, threads)] = t
         assert int(cn.sum()) == budget_reads * (read_len - k + 1)
         if tn is None or t < tn:
-            tn, best_threads = t, threads
+            tn, best_threads, best_mode = t, threads, mode
     assert int(c1.sum()) == budget_reads * (read_len - k + 1)
     bases = budget_reads * read_len
     # BASELINE config 1: 10 k reads, k = 9 through the interpreter loop
@@ -182,12 +196,14 @@ def cpu_baseline(k, read_len, budget_reads):
         'value': bases / t1 / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
         'sample': '%d synthetic %d bp reads, k=%d, oracle/kpal_oracle.c (1 thread: %.2f s)' % (budget_reads, read_len, k, t1),
         # the same figures as scalars (the driver's record keeps scalars only): all host cores, and the reference's own speed class
-        'all_cores_value': bases / tn / 1e9, 'all_cores_threads': best_threads, 'host_cores': cores,
+        'all_cores_value': bases / tn / 1e9, 'all_cores_threads': best_threads, 'all_cores_tables': best_mode, 'host_cores': cores,
         'python_loop_value': 1.5e6 / tp / 1e9, 'python_loop_sample': 'BASELINE config 1 (10000 reads, k=9), pure-Python restatement of klib.py:149-170, 1 core',
         'all_cores': {'value': bases / tn / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn,
                       'per_thread_efficiency': (bases / tn) / (bases / t1) / best_threads,
                       'seconds_by_threads': tried,
-                      'note': 'one shared 4^k table, relaxed atomic adds (oracle/kpal_oracle.c); best of the thread counts tried'},
+                      'tables': best_mode,
+                      'note': 'oracle/kpal_oracle.c on T threads: a private 4^k table per thread (calloc + merge timed) or one shared table with '
+                              'relaxed atomic adds; best of the (tables, threads) plans tried'},
         'python_reference_loop': {'value': 1.5e6 / tp / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'seconds': tp,
                                   'sample': 'BASELINE config 1 (10000 reads, k=9) through oracle/pyref.py, the statement-by-statement restatement of kpal/klib.py:149-170'},
     }
@@ -613,7 +629,7 @@ def supervise_rank(args):
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     run_dir = bench_run_dir()
     startup_limit = float(os.environ.get('KPAL_BENCH_STARTUP_TIMEOUT', '420'))   # a cold `import torch` takes 1-2 min on a fresh box
-    run_limit = float(os.environ.get('KPAL_BENCH_RUN_TIMEOUT', '300'))           # generate + warm-up + every mode + verification: well under a minute
+    run_limit = float(os.environ.get('KPAL_BENCH_RUN_TIMEOUT', '420'))           # generate + warm-up + every mode + verification: under a minute; rank 0's CPU baseline sample: ~1 min
     reason = None
     for attempt in (1, 2):
         argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ['--worker', '--attempt', str(attempt)]
@@ -902,6 +918,8 @@ def multi_gpu_worker(args):
                           'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(o['prof'].items())}}
             line['config'][key + '_ms_per_step'] = extra[key]['ms_per_step']       # (scalars: the driver's record keeps them)
         line['extra'] = extra
+        if cpu[0] is not None:
+            line['cpu_baseline'] = cpu[0]
         if library_error:
             line['library_rccl_error'] = library_error
         if args.fallback_reason:
@@ -910,9 +928,17 @@ def multi_gpu_worker(args):
         return line
 
     results, headline = {}, None
+    cpu = [None]
     for mode in modes:
         r = measure(mode)
         if rank == 0:
+            if cpu[0] is None and not args.no_cpu:
+                # the same bounded CPU sample as at N = 1, on rank 0's host cores, outside every timed region (the other ranks wait in
+                # the next mode's first collective, or in the final fence)
+                try:
+                    cpu[0] = cpu_baseline(k, L, args.cpu_reads)
+                except Exception as e:       # never lose the line over the reported baseline
+                    cpu[0] = {'error': '%s: %s' % (type(e).__name__, e)}
             w = single_stream()
             r['same'] = bool(np.array_equal(r.pop('merged'), w))
             r['sum_ok'] = int(w.sum()) == 2 * total_reads * (L - k + 1)

@@ -16,8 +16,8 @@
 //   * the text of one feed is handed to these kernels in chunks cut ANYWHERE (64 MiB pieces of a file); `start_state` says
 //     what the chunk's first byte continues: 0 = it is the first byte of a line (header iff '>'), 1 = the middle of a header
 //     line, 2 = the middle of a sequence line.  The first chunk of a feed starts at a header (the host skips anything before
-//     the first header, like Biopython does); a chunk never ends inside a run of blanks unless the text ends there (the host
-//     moves the cut), so "only whitespace follows on this line" can be decided inside the chunk.
+//     the first header, like Biopython does); when a chunk ends inside a run of blanks, `tail_trailing` says what the host found
+//     behind it (the run trails its line, or a base follows), so "only whitespace follows on this line" is decided with it.
 // Whether byte i is inside a header depends only on the first byte of its line, i.e. on the last
 // end-of-line before i: a prefix-max over the buffer.  Five small passes: per-block last EOL,
 // carry scan, per-block kept-byte count, offset scan, scatter (staged through LDS so the output
@@ -35,15 +35,16 @@ constexpr int kFaBlockBytes = kFaThreads * kFaPerThread;  // 4 KiB per workgroup
 __device__ __forceinline__ bool fa_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
 // whitespace that str.rstrip() removes at the end of a line but that stays inside it
 __device__ __forceinline__ bool fa_is_soft_space(uint8_t c) { return c == 9 || c == 11 || c == 12 || (c >= 28 && c <= 31) || c == 0x85 || c == 0xA0; }   // str.isspace() of a latin-1 text handle
-// true iff only whitespace follows byte i on its line (rare bytes: a forward walk per occurrence)
-__device__ __forceinline__ bool fa_trailing(const uint8_t *__restrict__ in, uint64_t n, uint64_t i)
+// true iff only whitespace follows byte i on its line (rare bytes: a forward walk per occurrence); a walk that reaches the end of
+// the chunk returns `tail_trailing` -- what the host found behind the chunk (fasta_host.hpp; true at the end of the text)
+__device__ __forceinline__ bool fa_trailing(const uint8_t *__restrict__ in, uint64_t n, uint64_t i, bool tail_trailing)
 {
     for (uint64_t j = i + 1; j < n; ++j) {
         const uint8_t d = in[j];
         if (fa_is_eol(d)) return true;
         if (d != ' ' && !fa_is_soft_space(d)) return false;
     }
-    return true;
+    return tail_trailing;
 }
 
 // inclusive prefix-max of one int64 per thread over a 256-thread workgroup; returns the exclusive
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void fa_carry_kernel(const long long *__restri
 
 // Classify the thread's 16 bytes: bit j of `keep` set iff byte j is emitted; out[j] its value.
 __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint64_t n, uint64_t i0, long long prev_eol, int start_state,
-                                            uint32_t &keep, uint8_t (&out)[kFaPerThread])
+                                            bool tail_trailing, uint32_t &keep, uint8_t (&out)[kFaPerThread])
 {
     keep = 0;
     long long last = prev_eol;   // last EOL strictly before the current byte
@@ -128,7 +129,7 @@ __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint
                 keep |= 1u << j;
                 out[j] = '\n';
             }
-        } else if (c != ' ' && !fa_is_eol(c) && !(fa_is_soft_space(c) && fa_trailing(in, n, i))) {
+        } else if (c != ' ' && !fa_is_eol(c) && !(fa_is_soft_space(c) && fa_trailing(in, n, i, tail_trailing))) {
             keep |= 1u << j;
             out[j] = c;
         }
@@ -141,7 +142,7 @@ __device__ __forceinline__ void fa_classify(const uint8_t *__restrict__ in, uint
 
 // K3: kept bytes per block.
 __global__ __launch_bounds__(kFaThreads) void fa_count_kernel(const uint8_t *__restrict__ in, uint64_t n,
-                                                              const long long *__restrict__ carry, int start_state,
+                                                              const long long *__restrict__ carry, int start_state, int tail_trailing,
                                                               uint32_t *__restrict__ kept)
 {
     __shared__ long long sh[4];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kFaThreads) void fa_count_kernel(const uint8_t *__r
     const long long prev = fa_block_exclusive_max(mine, carry[blockIdx.x], sh);
     uint32_t keep;
     uint8_t out[kFaPerThread];
-    fa_classify(in, n, i0, prev, start_state, keep, out);
+    fa_classify(in, n, i0, prev, start_state, tail_trailing != 0, keep, out);
     uint32_t c = __popc(keep);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void fa_offset_kernel(const uint32_t *__restri
 
 // K5: write the kept bytes of each block contiguously at offs[block].
 __global__ __launch_bounds__(kFaThreads) void fa_scatter_kernel(const uint8_t *__restrict__ in, uint64_t n,
-                                                                const long long *__restrict__ carry, int start_state,
+                                                                const long long *__restrict__ carry, int start_state, int tail_trailing,
                                                                 const uint64_t *__restrict__ offs,
                                                                 uint8_t *__restrict__ flat)
 {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kFaThreads) void fa_scatter_kernel(const uint8_t *_
     const long long prev = fa_block_exclusive_max(mine, carry[blockIdx.x], sh);
     uint32_t keep;
     uint8_t out[kFaPerThread];
-    fa_classify(in, n, i0, prev, start_state, keep, out);
+    fa_classify(in, n, i0, prev, start_state, tail_trailing != 0, keep, out);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = __popc(keep);
     uint32_t incl = c;

@@ -7,6 +7,7 @@
 #include "partition_kernels.hpp"
 #include "chunk_kernels.hpp"
 #include "fasta_kernels.hpp"
+#include "fasta_host.hpp"
 
 #include <cerrno>
 #include <fcntl.h>
@@ -530,7 +531,8 @@ static void staged_memcpy(void *dst, const void *src, size_t n)
 
 // Page-locked host memory on the NUMA node the GPU is attached to: the calling thread's memory policy is set to "prefer that node"
 // around the allocation (raw set_mempolicy: libnuma is not a dependency) and hipHostMallocNumaUser lets the runtime honour it.  A
-// staging buffer on the other socket puts the inter-socket link into every DMA.  Any failure falls back to a plain allocation.
+// staging buffer on the other socket puts the inter-socket link into every DMA.  The policy the thread had is saved and put back
+// (a policy that cannot be read is left alone: plain allocation).  Any failure falls back to a plain allocation.
 int host_alloc_near_gpu(kpal_ctx *ctx, void **out, size_t nbytes)
 {
     *out = nullptr;
@@ -538,10 +540,14 @@ int host_alloc_near_gpu(kpal_ctx *ctx, void **out, size_t nbytes)
     hipError_t e = hipErrorUnknown;
     if (node >= 0 && node < 64) {
         unsigned long mask = 1ul << node;
-        const long kPreferred = 1, kDefault = 0;   // MPOL_PREFERRED, MPOL_DEFAULT
-        if (syscall(SYS_set_mempolicy, kPreferred, &mask, 65ul) == 0) {
+        const long kPreferred = 1;   // MPOL_PREFERRED
+        // the thread's own policy (numactl --membind / --interleave, the application's set_mempolicy) is put back afterwards
+        int old_mode = 0;
+        unsigned long old_mask[16] = {};   // 1024 nodes
+        const bool saved = syscall(SYS_get_mempolicy, &old_mode, old_mask, (unsigned long)(sizeof(old_mask) * 8), nullptr, 0ul) == 0;
+        if (saved && syscall(SYS_set_mempolicy, kPreferred, &mask, 65ul) == 0) {
             e = hipHostMalloc(out, nbytes, hipHostMallocNumaUser);
-            (void)syscall(SYS_set_mempolicy, kDefault, nullptr, 0ul);
+            (void)syscall(SYS_set_mempolicy, (long)old_mode, old_mask, (unsigned long)(sizeof(old_mask) * 8 + 1));
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 *out = nullptr;
@@ -556,7 +562,7 @@ int host_alloc_near_gpu(kpal_ctx *ctx, void **out, size_t nbytes)
 static int ensure_pinned(kpal_ctx *ctx)
 {
     for (int i = 0; i < 2; ++i)
-        if (!ctx->pinned[i]) CHK(host_alloc_near_gpu(ctx, &ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStageHead + kpal_ctx::kStagePad));
+        if (!ctx->pinned[i]) CHK(host_alloc_near_gpu(ctx, &ctx->pinned[i], kpal_ctx::kStage + kpal_ctx::kStagePad));
     return KPAL_OK;
 }
 
@@ -646,115 +652,6 @@ KPAL_API int kpal_host_free(kpal_ctx *ctx, void *host)
 // flattened SIZE of the chunk before (read back asynchronously, needed on the host to launch its count), which is one whole
 // chunk old by then.
 // ----------------------------------------------------------------------------------------------
-static inline bool fa_host_is_eol(uint8_t c) { return c == '\n' || c == '\r'; }
-// blanks the flattening drops at the end of a line only (str.rstrip() of a latin-1 text handle), and the space it drops everywhere
-static inline bool fa_host_is_blank(uint8_t c) { return c == ' ' || c == 9 || c == 11 || c == 12 || (c >= 28 && c <= 31) || c == 0x85 || c == 0xA0; }
-
-// First byte of the first header line ('>' at a line start) of buf[0, n), or n.  at_line_start: buf[0] begins a line.
-static size_t fasta_first_header(const uint8_t *buf, size_t n, bool at_line_start)
-{
-    size_t next_cr = 0;        // position of the next '\r' at or after the scan position (n: none); found lazily, once per '\r'
-    bool cr_known = false;
-    auto next_eol = [&](size_t from) -> size_t {
-        if (!cr_known || next_cr < from) {
-            const void *cr = from < n ? memchr(buf + from, '\r', n - from) : nullptr;
-            next_cr = cr ? (size_t)((const uint8_t *)cr - buf) : n;
-            cr_known = true;
-        }
-        const size_t stop = next_cr;   // a '\n' beyond the next '\r' does not matter
-        const void *nl = from < stop ? memchr(buf + from, '\n', stop - from) : nullptr;
-        return nl ? (size_t)((const uint8_t *)nl - buf) : stop;
-    };
-    size_t i = 0;
-    if (!at_line_start) {
-        i = next_eol(0);
-        if (i >= n) return n;
-        ++i;
-    }
-    while (i < n) {
-        if (buf[i] == '>') return i;
-        i = next_eol(i);
-        if (i >= n) return n;
-        ++i;
-    }
-    return n;
-}
-
-struct FaSource {
-    int fd = -1;                       // a byte range [pos, end) of a file ...
-    const uint8_t *mem = nullptr;      // ... or of host memory (mem[pos .. end))
-    uint64_t pos = 0, end = 0;
-    const uint8_t *prefix = nullptr;   // text that logically precedes the range (a record's header and the bases before a cut)
-    size_t prefix_left = 0;
-    bool more() const { return prefix_left > 0 || pos < end; }
-};
-
-// (returns 0, or the errno of the failed read; EIO when the file turned out shorter than its size said)
-static int pread_all(int fd, uint8_t *dst, size_t n, uint64_t off)
-{
-    while (n) {
-        const ssize_t r = pread(fd, dst, n, (off_t)off);
-        if (r < 0 && errno == EINTR) continue;
-        if (r < 0) return errno ? errno : EIO;
-        if (r == 0) return EIO;
-        dst += r;
-        off += (uint64_t)r;
-        n -= (size_t)r;
-    }
-    return 0;
-}
-
-// n bytes of the source's range from `pos` into dst, by the pool: the page cache hands ONE reader ~9 GB/s (a copy_to_user per
-// page), the link takes 56.  start: the pool's workers copy while the caller does something else; ok[] says afterwards
-// (HostPool::wait) whether every part arrived (0, or the errno of its reader: errno itself is per thread).  Pieces below 4 MiB
-// are not split.
-static void fa_copy_start(const FaSource &s, uint8_t *dst, uint64_t pos, size_t n, std::vector<int> &ok)
-{
-    HostPool &pool = HostPool::instance();
-    const int parts = std::max(1, (int)std::min<size_t>((size_t)pool.size(), n / ((size_t)4 << 20)));
-    const size_t part = (((n + (size_t)parts - 1) / (size_t)parts) + 4095) & ~(size_t)4095;
-    ok.assign((size_t)parts, 0);
-    int *flags = ok.data();
-    const int fd = s.fd;
-    const uint8_t *mem = s.mem;
-    pool.start(parts, [=](int i) {
-        const size_t off = (size_t)i * part;
-        if (off >= n) return;
-        const size_t len = std::min(part, n - off);
-        if (mem) memcpy(dst + off, mem + pos + off, len);
-        else flags[i] = pread_all(fd, dst + off, len, pos + off);
-    });
-}
-
-// The next bytes of the source (at most `want`) into dst, now; returns how many (0: the end), -1 on a read error;
-// *from_range = how many of them came from [pos, end) (the others from the prefix).
-static long fa_fill(FaSource &s, uint8_t *dst, size_t want, size_t *from_range)
-{
-    size_t got = 0;
-    if (s.prefix_left) {
-        const size_t n = std::min(want, s.prefix_left);
-        memcpy(dst, s.prefix, n);
-        s.prefix += n;
-        s.prefix_left -= n;
-        got = n;
-    }
-    const size_t n = (size_t)std::min<uint64_t>(want - got, s.end - s.pos);
-    if (n) {
-        std::vector<int> ok;
-        fa_copy_start(s, dst + got, s.pos, n, ok);
-        HostPool::instance().wait();
-        for (int e : ok)
-            if (e) {
-                errno = e;
-                return -1;
-            }
-        s.pos += n;
-        got += n;
-    }
-    *from_range = n;
-    return (long)got;
-}
-
 // The pipeline.  count: the flattened chunks are counted into the running count (windows span chunk seams through the saved
 // tail of the chunk before, never a record boundary: every header leaves a '\n' in the stream); else they are copied to host_out.
 static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *host_out, uint64_t *n_out)
@@ -773,24 +670,6 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         CHK(ensure(ctx, ctx->fa_flat[i], stage + pad + 64));
         CHK(ensure(ctx, ctx->fa_meta[i], (size_t)max_blocks * (8 + 8 + 4) + (size_t)(max_blocks + 1) * 8 + 64));
     }
-    // Read-ahead: while the launches of chunk i are issued, the pool already reads chunk i + 1 into the other pinned buffer
-    // (behind kStageHead bytes of headroom: what chunk i gave back -- a run of blanks at its end -- is put in front of it).
-    struct ReadAhead {
-        bool active = false;
-        int slot = 0;
-        uint64_t pos = 0;
-        size_t n = 0;
-        std::vector<int> ok;
-        ~ReadAhead()
-        {
-            if (active) HostPool::instance().wait();   // (an error return must not leave the pool writing into the staging buffer)
-        }
-    } ra;
-    std::vector<uint8_t> carry;  // the bytes the chunk before gave back
-    const size_t head = kpal_ctx::kStageHead;
-    int state = 0;               // what the next chunk's first byte continues (fasta_kernels.hpp: 0 line start, 1 header, 2 sequence)
-    bool skipping = true;        // only text before the first header so far: dropped (klib.py:111: SeqIO starts at the first '>')
-    bool at_line_start = true;
     int prev_slot = -1;          // the chunk that has been flattened but not consumed yet
     uint64_t flat_total = 0;     // flattened bytes of the chunks consumed so far (this feed)
     uint64_t out_total = 0;
@@ -813,78 +692,23 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         return KPAL_OK;
     };
 
-    int slot = 0;
-    while (src.more() || !carry.empty()) {
-        uint8_t *hp = nullptr;
-        size_t n = 0, from_range = 0;
-        if (ra.active) {
-            HostPool::instance().wait();
-            ra.active = false;
-            for (int e : ra.ok)
-                if (e) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(e));
-            if (ra.pos == src.pos && ra.slot == slot && carry.size() <= head) {
-                hp = (uint8_t *)ctx->pinned[slot] + head - carry.size();
-                if (!carry.empty()) memcpy(hp, carry.data(), carry.size());
-                n = carry.size() + ra.n;
-                from_range = n;
-                src.pos += ra.n;
-                carry.clear();
-            }   // (else: the chunk before gave back more than the headroom holds and rewound the source: read again, below)
-        }
-        if (!hp) {
-            if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));   // the slot's previous DMA out of the pinned buffer
-            const size_t c = carry.size();                                                   // (<= head whenever it is set: all of it goes in front)
-            hp = (uint8_t *)ctx->pinned[slot] + head - c;
-            if (c) memcpy(hp, carry.data(), c);
-            carry.clear();
-            const long got = fa_fill(src, hp + c, stage - std::min(c, stage / 2), &from_range);
-            if (got < 0) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(errno));
-            if (got == 0 && c == 0) break;
-            n = c + (size_t)got;
-            if (src.prefix_left == 0 && (size_t)got == from_range) from_range += c;   // (the carried bytes came from the range as well)
-        }
-        if (src.more()) {
-            // never cut inside a run of blanks: whether a blank trails its line is decided from the bytes that follow it
-            size_t t = n;
-            while (t > 0 && fa_host_is_blank(hp[t - 1])) --t;
-            if (t > 0 && t < n && n - t <= from_range) {
-                if (n - t <= head) carry.assign(hp + t, hp + n);   // goes in front of the next chunk
-                else src.pos -= n - t;                             // (absurdly long run of blanks: the next chunk is read again from there)
-                n = t;
-            }
-            // the next chunk: the pool reads it while this one is scanned, copied and its kernels are issued
-            if (src.pos < src.end && src.prefix_left == 0) {
-                const int other = slot ^ 1;
-                if (ctx->stage_used[other]) HIPCHK(hipEventSynchronize(ctx->ev_copied[other]));
-                ra.slot = other;
-                ra.pos = src.pos;
-                ra.n = (size_t)std::min<uint64_t>(stage - std::min(stage / 2, carry.size()), src.end - src.pos);
-                fa_copy_start(src, (uint8_t *)ctx->pinned[other] + head, ra.pos, ra.n, ra.ok);
-                ra.active = true;
-            }
-        }
-        size_t first = 0;
-        if (skipping) {
-            first = fasta_first_header(hp, n, at_line_start);
-            if (first >= n) {
-                at_line_start = fa_host_is_eol(hp[n - 1]);
-                if (ra.active) slot ^= 1;   // (the read-ahead fills the other buffer)
-                continue;
-            }
-            skipping = false;
-            state = 0;
-        }
-        const uint8_t *chunk = hp + first;
-        const size_t m = n - first;
-        // what the chunk after this one continues: the chunk's last line
-        int next_state;
-        {
-            size_t e = m;
-            while (e > 0 && !fa_host_is_eol(chunk[e - 1])) --e;      // e = one past the last end of line (0: none)
-            if (e == 0) next_state = state == 0 ? (chunk[0] == '>' ? 1 : 2) : state;
-            else if (e == m) next_state = 0;
-            else next_state = chunk[e] == '>' ? 1 : 2;
-        }
+    // The chunker (fasta_host.hpp) reads chunk i + 1 into the other pinned buffer while the launches of chunk i are issued; a
+    // pinned buffer is written again only after the DMA out of it has finished.
+    FaChunker chunker(src, (uint8_t *)ctx->pinned[0], (uint8_t *)ctx->pinned[1], stage, [ctx](int slot) -> int {
+        if (ctx->stage_used[slot] && hipEventSynchronize(ctx->ev_copied[slot]) != hipSuccess) return KPAL_E_HIP;
+        return 0;
+    });
+    FaChunk ck;
+    for (;;) {
+        const int got = chunker.next(ck);
+        if (got == 0) break;
+        if (got == -1) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(chunker.io_errno()));
+        if (got < 0) return set_err(KPAL_E_HIP, "hipEventSynchronize failed while reading the FASTA input");
+        const int slot = ck.slot;
+        const uint8_t *chunk = ck.data;
+        const size_t m = ck.n;
+        const int state = ck.state;
+        const int tail = ck.tail_trailing ? 1 : 0;
         const uint32_t nblocks = (uint32_t)((m + kFaBlockBytes - 1) / kFaBlockBytes);
         uint8_t *raw = (uint8_t *)ctx->fa_raw[slot].p;
         uint8_t *flat = (uint8_t *)ctx->fa_flat[slot].p + pad;
@@ -899,18 +723,16 @@ static int fasta_pipeline(kpal_ctx *ctx, FaSource &src, bool count, uint8_t *hos
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
         LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, last_eol);
         LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, eol_before);
-        LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)eol_before, state, kept);
+        LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)eol_before, state, tail, kept);
         LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
         LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m,
-               (const long long *)eol_before, state, (const uint64_t *)offs, flat);
+               (const long long *)eol_before, state, tail, (const uint64_t *)offs, flat);
         HIPCHK(hipMemcpyAsync(&ctx->fa_nflat_host[slot], offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ev_done[slot], ctx->stream));
         ctx->stage_used[slot] = true;
         // the chunk before: its flattened size has long arrived; its count is queued behind this chunk's flattening
         if (prev_slot >= 0) CHK(consume(prev_slot));
         prev_slot = slot;
-        slot ^= 1;
-        state = next_state;
     }
     if (prev_slot >= 0) CHK(consume(prev_slot));
     if (!count) {

@@ -124,7 +124,6 @@ struct kpal_ctx {
     // host-feed staging
     static constexpr size_t kStage = (size_t)64 << 20;
     static constexpr size_t kStagePad = 64;
-    static constexpr size_t kStageHead = (size_t)64 << 10;   // FASTA ingest: headroom in front of a read-ahead chunk (kpal_count.hip)
     void *pinned[2] = {nullptr, nullptr};
     DevBuf dstage[2];
     hipEvent_t ev_copied[2] = {nullptr, nullptr};

@@ -15,29 +15,18 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
-#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct {
-    const char **ptr;
-    const uint32_t *len;
-    const uint64_t *off;
-    char *dst;
-    size_t begin, end;
-} copy_job;
+#include "kpal_join_core.h"
 
-static void *copy_worker(void *arg)
-{
-    copy_job *j = (copy_job *)arg;
-    for (size_t i = j->begin; i < j->end; i++) {
-        char *d = j->dst + j->off[i];
-        memcpy(d, j->ptr[i], j->len[i]);
-        d[j->len[i]] = '\n';
-    }
-    return NULL;
-}
+/* (PyUnicode_IS_READY is deprecated since Python 3.12, where every str is in its canonical form) */
+#if PY_VERSION_HEX < 0x030C0000
+#define KPAL_UNICODE_READY(o) PyUnicode_IS_READY(o)
+#else
+#define KPAL_UNICODE_READY(o) 1
+#endif
 
 /* gather(seq, start, address, capacity, threads) -> (next, nbytes, status)
  *   seq: list or tuple; items seq[start:next] were written to `address` (each followed by '\n'), nbytes in total.
@@ -78,7 +67,7 @@ static PyObject *gather(PyObject *self, PyObject *args)
         if (PyBytes_CheckExact(it)) {
             p = PyBytes_AS_STRING(it);
             l = PyBytes_GET_SIZE(it);
-        } else if (PyUnicode_CheckExact(it) && PyUnicode_IS_READY(it) && PyUnicode_KIND(it) == PyUnicode_1BYTE_KIND) {
+        } else if (PyUnicode_CheckExact(it) && KPAL_UNICODE_READY(it) && PyUnicode_KIND(it) == PyUnicode_1BYTE_KIND) {
             p = (const char *)PyUnicode_1BYTE_DATA(it);
             l = PyUnicode_GET_LENGTH(it);
         } else if (PyByteArray_CheckExact(it)) {
@@ -99,30 +88,7 @@ static PyObject *gather(PyObject *self, PyObject *args)
         n++;
     }
     char *dst = (char *)(uintptr_t)address;
-    if (n) {
-        int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
-        if (at < ((uint64_t)4 << 20)) T = 1;
-        pthread_t th[64];
-        copy_job jobs[64];
-        char joinable[64];
-        /* equal BYTE shares: the items of thread t are those whose offset falls into its share */
-        size_t next = 0;
-        for (int t = 0; t < T; t++) {
-            const uint64_t limit = at / (uint64_t)T * (uint64_t)(t + 1);
-            size_t e = next;
-            if (t == T - 1) e = n;
-            else while (e < n && off[e] < limit) e++;
-            jobs[t].ptr = ptr; jobs[t].len = len; jobs[t].off = off; jobs[t].dst = dst;
-            jobs[t].begin = next; jobs[t].end = e;
-            next = e;
-            joinable[t] = 0;
-            if (t > 0 && jobs[t].end > jobs[t].begin) joinable[t] = pthread_create(&th[t], NULL, copy_worker, &jobs[t]) == 0;
-            if (t > 0 && !joinable[t]) copy_worker(&jobs[t]);
-        }
-        copy_worker(&jobs[0]);
-        for (int t = 1; t < T; t++)
-            if (joinable[t]) pthread_join(th[t], NULL);
-    }
+    kpal_join_copy(ptr, len, off, n, at, dst, threads, (uint64_t)4 << 20);
     free(ptr); free(len); free(off);
     return Py_BuildValue("nKi", start + (Py_ssize_t)n, (unsigned long long)at, status);
 }

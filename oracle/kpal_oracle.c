@@ -772,12 +772,15 @@ static void *merge_worker(void *arg)
     return NULL;
 }
 
-ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, int threads, int64_t *counts)
+/* mode 0: the rule above (private histograms for k <= 8, else one shared table); 1: one shared table; 2: a private
+ * histogram per thread whatever its size (the all-cores CPU baseline at k = 12: T x 128 MiB, calloc and the merge inside
+ * the caller's timed region).  The result is the same in every mode. */
+ORACLE_API int kpal_oracle_count_flat_mt_mode(const uint8_t *buf, size_t n, int k, int threads, int mode, int64_t *counts)
 {
-    if (k < 1 || k > 31 || threads < 1) return -1;
+    if (k < 1 || k > 31 || threads < 1 || mode < 0 || mode > 2) return -1;
     const size_t bins = (size_t)1 << (2 * k);
     const int T = threads > 256 ? 256 : threads;
-    const int shared = bins * sizeof(int64_t) > ((size_t)1 << 20);
+    const int shared = mode == 1 || (mode == 0 && bins * sizeof(int64_t) > ((size_t)1 << 20));
     int rc = 0;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * T);
     char *joinable = (char *)calloc(T, 1);
@@ -826,6 +829,11 @@ ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, in
     free(joinable);
     free(th);
     return rc;
+}
+
+ORACLE_API int kpal_oracle_count_flat_mt(const uint8_t *buf, size_t n, int k, int threads, int64_t *counts)
+{
+    return kpal_oracle_count_flat_mt_mode(buf, n, k, threads, 0, counts);
 }
 
 /* ------------------------------------------------------------------------------------ *

@@ -38,6 +38,8 @@ def lib():
         L.kpal_oracle_count_piece.restype = ctypes.c_int
         L.kpal_oracle_count_flat_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_i64p]
         L.kpal_oracle_count_flat_mt.restype = ctypes.c_int
+        L.kpal_oracle_count_flat_mt_mode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64p]
+        L.kpal_oracle_count_flat_mt_mode.restype = ctypes.c_int
         L.kpal_oracle_count_blocks_mt.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.c_int, ctypes.c_int, _c_i64p, _c_i64p]
         L.kpal_oracle_count_blocks_mt.restype = ctypes.c_int
@@ -115,9 +117,13 @@ def from_sequences(sequences, length):
     return counts
 
 
-def count_flat(buf, length, threads=1):
-    """Count a flat byte stream (any non-AaCcGgTt byte separates); optionally N threads
-    with private histograms + integer merge (the all-cores baseline / at-scale oracle)."""
+COUNT_MODES = {'auto': 0, 'shared': 1, 'private': 2}
+
+
+def count_flat(buf, length, threads=1, mode='auto'):
+    """Count a flat byte stream (any non-AaCcGgTt byte separates); optionally N threads (the all-cores
+    baseline / at-scale oracle).  mode: 'shared' = one table, relaxed atomic adds; 'private' = one table per
+    thread + integer merge; 'auto' = private for k <= 8, else shared.  Same result in every mode."""
     b = _bytes_view(buf)
     L = lib()
     n = b.size
@@ -127,9 +133,9 @@ def count_flat(buf, length, threads=1):
             L.kpal_oracle_count_piece(b.ctypes.data, 0, n, length, counts.ctypes.data_as(_c_i64p))
         return counts
     counts = np.zeros(4 ** length, dtype=np.int64)
-    rc = L.kpal_oracle_count_flat_mt(b.ctypes.data, n, length, int(threads), counts.ctypes.data_as(_c_i64p))
+    rc = L.kpal_oracle_count_flat_mt_mode(b.ctypes.data, n, length, int(threads), COUNT_MODES[mode], counts.ctypes.data_as(_c_i64p))
     if rc:
-        raise MemoryError('kpal_oracle_count_flat_mt failed (%d)' % rc)
+        raise MemoryError('kpal_oracle_count_flat_mt_mode failed (%d)' % rc)
     return counts
 
 

@@ -81,3 +81,5 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
         assert line['config'][mode + '_ms_per_step'] > 0
     # (at 3 M reads the fixed-cost histogram stage may be the longest kernel: an intermediate kernel has no algorithmic bytes of its own)
     assert line['value'] > 0 and line['roofline']['pipeline_frac'] > 0 and 'rccl_reduce' in line['roofline']['kernels_ms_per_step']
+    # the N > 1 line carries the CPU baseline too (rank 0's host cores, the N = 1 sample)
+    assert 'cpu_baseline' in line and line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['kind'] == 'port'

@@ -192,7 +192,11 @@ def test_chunk_seams_everywhere(tmp_path):
     rnd = random.Random(31)
     texts = ['no header at all\nACGT\n', '>only header', '>h\nACGT', 'junk\njunk2\n>a desc\nAC\nGT\n>b\n\n>c\nTT',
              '>a\r\nAC\r\nGT\r\n>b\r\nNN\r\nACGTACGTAC\r\n', '>t\nAC \t \nGT\tA  \t\nACGT\n', '>' + 'h' * 300 + '\nACGTACGTACGTACGT\n' * 5,
-             'junk\r>a x\rACGTAC\rGTTGCA\r>b\r\rTTGACC\r', '>only\n' + 'ACGT' * 50 + ' \t' * 40 + '\n' + 'TTGCA' * 30 + '\t' * 9 + 'ACG\n']
+             'junk\r>a x\rACGTAC\rGTTGCA\r>b\r\rTTGACC\r', '>only\n' + 'ACGT' * 50 + ' \t' * 40 + '\n' + 'TTGCA' * 30 + '\t' * 9 + 'ACG\n',
+             # runs of blanks longer than a chunk (several whole chunks of nothing but blanks): trailing their line, inside it, at the
+             # end of the text with and without an end of line -- what they are is decided by the first byte BEHIND the chunk
+             '>long\nACGTACGTACGT' + '\t ' * 3000 + '\nTTGACCAGT' + '\t' * 5500 + 'ACGTTGCAACGT\n>next\nAC' + ' \x0b' * 2600,
+             '>tail\nACGTACGTACGTA' + '\t' * 700 + '\r\n' + '\x0c' * 9000 + '\r\nGGGTTTACGTAC\t' + ' ' * 6000 + '\tACGTACGTTT' + '\t' * 5001 + '\n']
     for _ in range(10):
         texts.append(random_fasta(rnd, rnd.randint(1, 12), 3000, eol=rnd.choice(['\n', '\n', '\r\n'])))
     texts.append(random_fasta(rnd, 3, 60000))
