@@ -119,6 +119,17 @@ int kpal_fasta_flatten(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes, ui
  * receives n_records tables of 4^k int64, record-major.  Independent of the begin/feed/finish state. */
 int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nbytes, const uint64_t *host_starts,
                        size_t n_records, int64_t *host_out);
+/* Profile.from_fasta_by_record, klib.py:114-133, with the records found on the device (what the reference leaves to
+ * Bio.SeqIO.parse, klib.py:131).  kpal_fasta_records_begin takes FASTA text that holds whole records (text before its first
+ * header line is ignored, as at the start of a file), flattens it and indexes its records: *n_records, *flat_bytes.
+ * kpal_fasta_records_index copies out, per record, the offset of its header line ('>') in host_text (n_records values: the
+ * caller reads the name there, klib.py:132) and its start in the flattened stream (n_records + 1 values, the last = flat_bytes);
+ * either pointer may be NULL.  kpal_fasta_records_count counts records [first, first + n) of that text into host_out: n tables of
+ * 4^k int64, record-major -- as many records per call as the caller has room for.  The index lives until the next
+ * kpal_fasta_records_begin of the context.  Independent of the begin / feed / finish state. */
+int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, uint64_t *n_records, uint64_t *flat_bytes);
+int kpal_fasta_records_index(kpal_ctx *ctx, uint64_t *header_off, uint64_t *flat_start);
+int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *host_out);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
 /* Profile.balance (klib.py:285-298) on the count table in place, on the device: count + balance is the unit the
  * north-star metric is quoted on.  Call after the last feed, before kpal_count_finish (which then returns the balanced
@@ -130,6 +141,15 @@ int kpal_count_balance(kpal_ctx *ctx);
  * level 2; 0 where not applicable).  The environment variables KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2, read when the context is
  * created, force those tile sizes. */
 int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int *steps2);
+/* Diagnostics: how often the slow paths of the quad pipelines ran since the context was created (cumulative; tests assert that
+ * skewed inputs -- poly-A, (AC)n, adapter prefixes: every k-mer still counted once, klib.py:157-168 -- really exercised them).
+ * out[0] entries of the per-workgroup hot-item tables in use at kernel ends, out[1] items that rode in a spill list,
+ * out[2] items a spill list could not hold (counted on the spot), out[3] pieces finalised FRESH (k >= 13: table written, not
+ * added to), out[4] FRESH pieces run again the classic way (a bypass list overflowed), out[5] pieces through a quad pipeline,
+ * out[6] pieces through the chunked / round-1 pipelines, out[7] pieces halved (pool or offset limits).  n <= KPAL_COUNT_STATS
+ * values are written.  Synchronises the context's stream. */
+#define KPAL_COUNT_STATS 8
+int kpal_count_stats(kpal_ctx *ctx, uint64_t *out, int n);
 int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
 
 /* Deterministic synthetic reads (same bytes as oracle/kpal_oracle.c

@@ -76,6 +76,7 @@ SIGNATURES = {
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_balance': (ctypes.c_int, [_vp]),
     'kpal_count_last_plan': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'kpal_count_stats': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]),
     'kpal_comm_probe': (ctypes.c_int, [ctypes.c_char_p]),
     'kpal_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p, _vp]),
     'kpal_comm_init': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp]),
@@ -368,6 +369,13 @@ class Context(object):
         _check(self._L.kpal_count_last_plan(self._h, ctypes.byref(st), ctypes.byref(s1), ctypes.byref(s2)))
         names = {v: n for n, v in STRATEGY.items()}
         return names.get(st.value, str(st.value)), s1.value, s2.value
+
+    def count_stats(self):
+        """Cumulative slow-path statistics of the quad pipelines since the context was created (kpal_count_stats)."""
+        out = (ctypes.c_uint64 * 8)()
+        _check(self._L.kpal_count_stats(self._h, out, 8))
+        names = ('hot_entries', 'spilled_items', 'unlisted_items', 'fresh_pieces', 'fresh_reruns', 'quad_pieces', 'chunked_pieces', 'split_pieces')
+        return dict(zip(names, (int(v) for v in out)))
 
     def count_table_view(self):
         ptr, n = self.count_table()

@@ -232,4 +232,64 @@ __global__ __launch_bounds__(kFaThreads) void fa_scatter_kernel(const uint8_t *_
     for (uint32_t t = threadIdx.x; t < total; t += kFaThreads) dst[t] = stage[t];
 }
 
+// ---- record index (Profile.from_fasta_by_record, kpal/klib.py:114-133: one profile per record, named by the record) ----
+// Which bytes start a record: MODE 0, in the FLATTENED stream: every '\n' (the only '\n' bytes of that stream are the separators the
+// headers became); MODE 1, in the RAW text: a '>' at a line start (byte 0 of the text begins a line).  The r-th mark of either kind
+// belongs to record r.  Two passes around fa_offset_kernel: marks per 4 KiB block, then their positions written in order.
+template <int MODE>
+__device__ __forceinline__ bool fa_is_mark(const uint8_t *__restrict__ in, uint64_t i)
+{
+    if (MODE == 0) return in[i] == '\n';
+    return in[i] == '>' && (i == 0 || fa_is_eol(in[i - 1]));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kFaThreads) void fa_mark_count_kernel(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ marks)
+{
+    __shared__ uint32_t shc[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kFaBlockBytes + (uint64_t)threadIdx.x * kFaPerThread;
+    uint32_t c = 0;
+    for (int j = 0; j < kFaPerThread; ++j)
+        if (i0 + j < n && fa_is_mark<MODE>(in, i0 + j)) ++c;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) shc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) marks[blockIdx.x] = shc[0] + shc[1] + shc[2] + shc[3];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kFaThreads) void fa_mark_scatter_kernel(const uint8_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ offs,
+                                                                     uint64_t *__restrict__ positions)
+{
+    __shared__ uint32_t wsum[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * kFaBlockBytes + (uint64_t)threadIdx.x * kFaPerThread;
+    uint32_t mask = 0;
+    for (int j = 0; j < kFaPerThread; ++j)
+        if (i0 + j < n && fa_is_mark<MODE>(in, i0 + j)) mask |= 1u << j;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = __popc(mask);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t at = offs[blockIdx.x] + (incl - c);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) at += wsum[w];
+    for (int j = 0; j < kFaPerThread; ++j)
+        if (mask & (1u << j)) positions[at++] = i0 + (uint64_t)j;
+}
+
+// starts of a batch of records relative to the batch's first byte (count_records_kernel takes them so)
+__global__ __launch_bounds__(256) void fa_rebase_kernel(const uint64_t *__restrict__ starts, uint64_t n, uint64_t base, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = starts[i] - base;
+}
+
 }  // namespace kpal

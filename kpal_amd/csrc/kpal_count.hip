@@ -448,12 +448,18 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
             ctx->plan_strategy = strat;
             ctx->plan_steps1 = ctx->plan_steps2 = 0;
         }
+        if (strat == KPAL_STRATEGY_PARTITION || strat == KPAL_STRATEGY_PARTITION_CHUNKED || strat == KPAL_STRATEGY_PARTITION2) ++ctx->stat_chunked_pieces;
         if (strat == KPAL_STRATEGY_GLOBAL_ATOMIC) CHK(launch_global_atomic(ctx, s));
         else if (strat == KPAL_STRATEGY_LDS_DIRECT) CHK(launch_lds_direct(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION) CHK(launch_partition(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION_CHUNKED) CHK(launch_partition_chunked(ctx, s));
         else if (strat == KPAL_STRATEGY_PARTITION2_QUADS) {
             const int rc = launch_partition2_quads(ctx, s, fresh);
+            if (rc == KPAL_OK) {
+                ++ctx->stat_quad_pieces;
+                if (fresh) ++ctx->stat_fresh_pieces;
+            }
+            if (rc == kSplitBatch) ++ctx->stat_split_pieces;
             if (rc == kQuadsUseChunked || rc == kSplitBatch) CHK(table_ready(ctx));   // (nothing was launched: the other paths need the zeros)
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the round-1 two-level pipeline
                 ctx->strategy = KPAL_STRATEGY_PARTITION2;
@@ -468,6 +474,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         }
         else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
             const int rc = launch_partition_quads(ctx, s);
+            if (rc == KPAL_OK) ++ctx->stat_quad_pieces;
+            if (rc == kSplitBatch) ++ctx->stat_split_pieces;
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size
                 ctx->strategy = KPAL_STRATEGY_PARTITION_CHUNKED;
                 const int r2 = count_device_range(ctx, addr + off, len, halo + off);
@@ -833,6 +841,137 @@ KPAL_API int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, 
     return KPAL_OK;
 }
 
+// ----------------------------------------------------------------------------------------------
+// Profile.from_fasta_by_record (kpal/klib.py:114-133) with the records tokenised on the device: the text (whole records; the
+// caller cuts at record boundaries) is flattened by the kernels of the FASTA ingest, and two compactions list where every record
+// starts in the flattened stream and where its header line starts in the text -- the host reads the header lines only (names).
+// kpal_fasta_records_count then counts batches of records into one table each (count_records_kernel), as many as the caller has
+// room for.
+// ----------------------------------------------------------------------------------------------
+KPAL_API int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, uint64_t *n_records, uint64_t *flat_bytes)
+{
+    CTX_ENTER(ctx);
+    if (!n_records || !flat_bytes || (nbytes && !host_text)) return set_err(KPAL_E_INVALID, "NULL pointer");
+    *n_records = *flat_bytes = 0;
+    ctx->rec_n = ctx->rec_nf = 0;
+    ctx->rec_starts_host.clear();
+    ctx->rec_hdr_host.clear();
+    const size_t first = nbytes ? fasta_first_header(host_text, nbytes, true) : 0;   // text before the first header is no record (klib.py:131: SeqIO)
+    if (first >= nbytes) return KPAL_OK;
+    const uint8_t *text = host_text + first;
+    const size_t m = nbytes - first;
+    const size_t pad = kpal_ctx::kStagePad;
+    const uint32_t nblocks = (uint32_t)((m + kFaBlockBytes - 1) / kFaBlockBytes);
+    CHK(ensure(ctx, ctx->rec_raw, m + 64));
+    CHK(ensure(ctx, ctx->rec_flat, m + pad + 64));
+    CHK(ensure(ctx, ctx->rec_meta, (size_t)nblocks * (8 + 8 + 4 + 4) + 2 * (size_t)(nblocks + 1) * 8 + 128));
+    uint8_t *raw = (uint8_t *)ctx->rec_raw.p;
+    uint8_t *flat = (uint8_t *)ctx->rec_flat.p + pad;
+    long long *last_eol = (long long *)ctx->rec_meta.p;
+    long long *eol_before = last_eol + nblocks;
+    uint64_t *offs = (uint64_t *)(eol_before + nblocks);
+    uint64_t *offs2 = offs + nblocks + 1;
+    uint32_t *kept = (uint32_t *)(offs2 + nblocks + 1);
+    uint32_t *marks = kept + nblocks;
+    // text -> device through the pinned staging buffers (host threads copy piece i + 1 while the DMA takes piece i)
+    CHK(ensure_pinned(ctx));
+    {
+        const size_t stage = kpal_ctx::kStage;
+        int slot = 0;
+        for (size_t off = 0; off < m; off += stage, slot ^= 1) {
+            const size_t len = std::min(stage, m - off);
+            if (ctx->stage_used[slot]) HIPCHK(hipEventSynchronize(ctx->ev_copied[slot]));
+            staged_memcpy(ctx->pinned[slot], text + off, len);
+            HIPCHK(hipMemcpyAsync(raw + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->copy_stream));
+            HIPCHK(hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+            ctx->stage_used[slot] = true;
+            if (off + stage >= m) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[slot], 0));
+        }
+    }
+    LAUNCH(ctx, "fa_last_eol", fa_last_eol_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, last_eol);
+    LAUNCH(ctx, "fa_carry", fa_carry_kernel, dim3(1), dim3(256), (const long long *)last_eol, nblocks, eol_before);
+    LAUNCH(ctx, "fa_count", fa_count_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)eol_before, 0, 1, kept);
+    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)kept, nblocks, offs);
+    LAUNCH(ctx, "fa_scatter", fa_scatter_kernel, dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const long long *)eol_before, 0, 1,
+           (const uint64_t *)offs, flat);
+    // header lines of the text
+    LAUNCH(ctx, "fa_mark_count", (fa_mark_count_kernel<1>), dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, marks);
+    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)marks, nblocks, offs2);
+    uint64_t sizes[2] = {0, 0};   // flattened bytes, records
+    HIPCHK(hipMemcpyAsync(&sizes[0], offs + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&sizes[1], offs2 + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint64_t nf = sizes[0], R = sizes[1];
+    if (R == 0 || nf < R) return set_err(KPAL_E_HIP, "record index: %llu records in %llu flattened bytes", (unsigned long long)R, (unsigned long long)nf);
+    CHK(ensure(ctx, ctx->rec_hdr, (size_t)R * 8));
+    CHK(ensure(ctx, ctx->rec_starts, (size_t)(R + 1) * 8));
+    LAUNCH(ctx, "fa_mark_scatter", (fa_mark_scatter_kernel<1>), dim3(nblocks), dim3(kFaThreads), (const uint8_t *)raw, (uint64_t)m, (const uint64_t *)offs2,
+           (uint64_t *)ctx->rec_hdr.p);
+    // record starts of the flattened stream: its '\n' bytes (offs / marks are free again: the flattening is done)
+    const uint32_t fblocks = (uint32_t)((nf + kFaBlockBytes - 1) / kFaBlockBytes);   // <= nblocks
+    LAUNCH(ctx, "fa_mark_count", (fa_mark_count_kernel<0>), dim3(fblocks), dim3(kFaThreads), (const uint8_t *)flat, nf, marks);
+    LAUNCH(ctx, "fa_offset", fa_offset_kernel, dim3(1), dim3(256), (const uint32_t *)marks, fblocks, offs);
+    LAUNCH(ctx, "fa_mark_scatter", (fa_mark_scatter_kernel<0>), dim3(fblocks), dim3(kFaThreads), (const uint8_t *)flat, nf, (const uint64_t *)offs,
+           (uint64_t *)ctx->rec_starts.p);
+    uint64_t seps = 0;
+    HIPCHK(hipMemcpyAsync(&seps, offs + fblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync((uint64_t *)ctx->rec_starts.p + R, &nf, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->rec_hdr_host.resize((size_t)R);
+    ctx->rec_starts_host.resize((size_t)R + 1);
+    HIPCHK(hipMemcpyAsync(ctx->rec_hdr_host.data(), ctx->rec_hdr.p, (size_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->rec_starts_host.data(), ctx->rec_starts.p, (size_t)R * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (seps != R) return set_err(KPAL_E_HIP, "record index: %llu header lines but %llu separators", (unsigned long long)R, (unsigned long long)seps);
+    ctx->rec_starts_host[(size_t)R] = nf;
+    for (uint64_t &h : ctx->rec_hdr_host) h += first;
+    ctx->rec_n = R;
+    ctx->rec_nf = nf;
+    *n_records = R;
+    *flat_bytes = nf;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_fasta_records_index(kpal_ctx *ctx, uint64_t *header_off, uint64_t *flat_start)
+{
+    CTX_ENTER(ctx);
+    if (ctx->rec_n == 0) return set_err(KPAL_E_STATE, "kpal_fasta_records_index without records (kpal_fasta_records_begin)");
+    if (header_off) memcpy(header_off, ctx->rec_hdr_host.data(), (size_t)ctx->rec_n * 8);
+    if (flat_start) memcpy(flat_start, ctx->rec_starts_host.data(), (size_t)(ctx->rec_n + 1) * 8);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    if (n == 0) return KPAL_OK;
+    if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
+    if (first > ctx->rec_n || n > ctx->rec_n - first) return set_err(KPAL_E_INVALID, "records %llu..%llu of %llu", (unsigned long long)first,
+                                                                      (unsigned long long)(first + n), (unsigned long long)ctx->rec_n);
+    if (n >= 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "too many records in one batch");
+    const uint64_t bins = 1ULL << (2 * k);
+    const size_t out_bytes = (size_t)n * bins * sizeof(int64_t);
+    const uint64_t b0 = ctx->rec_starts_host[(size_t)first], b1 = ctx->rec_starts_host[(size_t)(first + n)];
+    CHK(ensure(ctx, ctx->scratch[0], out_bytes));
+    CHK(ensure(ctx, ctx->scratch[2], (size_t)(n + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(ctx->scratch[0].p, 0, out_bytes, ctx->stream));
+    if (b1 > b0) {
+        LAUNCH(ctx, "fa_rebase", fa_rebase_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), (const uint64_t *)ctx->rec_starts.p + first, n + 1, b0,
+               (uint64_t *)ctx->scratch[2].p);
+        const Span s = make_span((const uint8_t *)ctx->rec_flat.p + kpal_ctx::kStagePad + b0, (size_t)(b1 - b0), 0);
+        const uint64_t steps = (s.nchunks + 63) / 64;
+        const uint64_t max_waves = (uint64_t)ctx->num_cu * 8 * 4;
+        const uint64_t spw = std::max<uint64_t>(1, (steps + max_waves - 1) / max_waves);
+        const uint64_t waves = (steps + spw - 1) / spw;
+        const unsigned grid = (unsigned)((waves + 3) / 4);
+        DISPATCH_K_1_16(k, LAUNCH(ctx, "count_records", (count_records_kernel<K>), dim3(grid), dim3(256), s, spw,
+                                  (const uint64_t *)ctx->scratch[2].p, (uint32_t)n, (unsigned long long *)ctx->scratch[0].p));
+    }
+    HIPCHK(hipMemcpyAsync(host_out, ctx->scratch[0].p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
 KPAL_API int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out)
 {
     CTX_ENTER(ctx);
@@ -874,6 +1013,21 @@ KPAL_API int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int
     if (strategy) *strategy = ctx->plan_strategy;
     if (steps1) *steps1 = ctx->plan_steps1;
     if (steps2) *steps2 = ctx->plan_steps2;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_count_stats(kpal_ctx *ctx, uint64_t *out, int n)
+{
+    CTX_ENTER(ctx);
+    if (!out || n < 1) return set_err(KPAL_E_INVALID, "out is NULL");
+    uint32_t words[4] = {0, 0, 0, 0};
+    if (ctx->quad_error_word) {
+        HIPCHK(hipMemcpyAsync(words, ctx->quad_error_word, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    const uint64_t all[KPAL_COUNT_STATS] = {words[1], words[2], words[3], ctx->stat_fresh_pieces, ctx->stat_fresh_reruns, ctx->stat_quad_pieces,
+                                            ctx->stat_chunked_pieces, ctx->stat_split_pieces};
+    for (int i = 0; i < n; ++i) out[i] = i < KPAL_COUNT_STATS ? all[i] : 0;
     return KPAL_OK;
 }
 

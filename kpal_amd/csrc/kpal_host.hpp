@@ -86,6 +86,8 @@ struct kpal_ctx {
     bool quad_verbose = false;               // KPAL_QUAD_VERBOSE
     // what the last piece of the last feed took (kpal_count_last_plan): strategy, wave-steps per wave and tile of level 1 / level 2
     int plan_strategy = 0, plan_steps1 = 0, plan_steps2 = 0;
+    // kpal_count_stats: pieces by pipeline and the FRESH pieces / re-runs, since the context was created
+    uint64_t stat_fresh_pieces = 0, stat_fresh_reruns = 0, stat_quad_pieces = 0, stat_chunked_pieces = 0, stat_split_pieces = 0;
     // tile sizes chosen from the sample of an earlier feed of this count (kpal_count_begin clears them): a file streamed in
     // many feeds is sampled once per 16 feeds, not once per feed (the sample costs a D2H copy + a host synchronisation)
     int cached_steps1 = 0, cached_steps2 = 0;
@@ -118,6 +120,11 @@ struct kpal_ctx {
     // FASTA ingest (kpal_count.hip): raw text and flattened stream of two chunks in flight, scan metadata, the flattened tail of
     // the previous chunk (the k-1 bytes the next one's first windows begin in), the chunks' flattened sizes in pinned host memory
     DevBuf fa_raw[2], fa_flat[2], fa_meta[2], fa_tail;
+    // record index of the text of the last kpal_fasta_records_begin (from_fasta_by_record): raw text, flattened stream, scan metadata,
+    // record starts in the flattened stream (R + 1) and header offsets in the raw text (R) on the device and on the host
+    DevBuf rec_raw, rec_flat, rec_meta, rec_starts, rec_hdr;
+    std::vector<uint64_t> rec_starts_host, rec_hdr_host;
+    uint64_t rec_n = 0, rec_nf = 0;
     uint64_t *fa_nflat_host = nullptr;
     std::vector<void *> host_allocs;         // kpal_host_alloc buffers still owned by callers (released with the context at the latest)
     size_t fa_chunk = kStage;                // text bytes per chunk (KPAL_FASTA_CHUNK: tests put the seams everywhere)

@@ -197,6 +197,7 @@ int quad2_resolve_fresh(kpal_ctx *ctx)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->fresh_resolved = true;
     if (overflow) {
+        ++ctx->stat_fresh_reruns;
         ctx->finalize_pending = false;
         ctx->finalize_fresh = false;
         HIPCHK(hipMemsetAsync(ctx->table.p, 0, ctx->bins * sizeof(int64_t), ctx->stream));

@@ -485,6 +485,17 @@ __device__ __forceinline__ void quad_tile_priority(int st)
 #endif
 }
 
+// Statistics of the slow paths (kpal_count_stats; tests assert that skewed inputs really took them): error[2] += items that rode in
+// the spill list this round, error[3] += items the list could not hold (counted on the spot: hot-item table or the table itself).
+// One fire-and-forget atomic per workgroup and round that spilled at all.
+__device__ __forceinline__ void quad_note_spill(uint32_t *__restrict__ error, uint32_t appended, uint32_t cap)
+{
+    if (threadIdx.x == 0 && appended) {
+        atomicAdd(error + 2, min(appended, cap));
+        if (appended > cap) atomicAdd(error + 3, appended - cap);
+    }
+}
+
 // Q0: row loads of a sample of the input.  Workgroup g encodes `steps` wave-steps starting at its share of the
 // stream and adds every item to load[row] (global atomics: a few hundred thousand).  The host picks the tile size
 // from these loads: rows that would be over-full every round (compositional skew, e.g. an AT-rich genome) call
@@ -704,6 +715,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         quad_tile_priority<1>(0);                // (the flush and the carried items: everybody is needed at the next barrier)
         lds_barrier();                           // rows, pos and the spill list are complete (loads and stores stay in flight)
         const uint32_t spilled = min(*spill_n, CAP);         // (beyond CAP: counted directly by quad_place); reset only during the flush of the NEXT tile
+        quad_note_spill(error, *spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
         // ---- flush: every row becomes one record of S items (null padded), kept in registers
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
@@ -954,6 +966,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         quad_tile_priority<1>(0);
         lds_barrier();
         const uint32_t spilled = min(*spill_n, CAP);
+        quad_note_spill(error, *spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
         {
