@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('KPAL_HIP_LIBRARY', os.path.join(_HERE, 'libkpal_hip.s
 KPAL_MAX_K = 16
 PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN, COSINE = 0, 1, 2, 3
 SUMMARY_MIN, SUMMARY_AVERAGE, SUMMARY_MEDIAN = 0, 1, 2
-STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7}
+STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7, 'partition_hex': 8}
 
 _E_INVALID, _E_NOMEM, _E_HIP, _E_STATE, _E_IO = -1, -2, -3, -4, -5
 
@@ -72,6 +72,12 @@ SIGNATURES = {
     'kpal_count_feed_fasta_file': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _vp, ctypes.c_size_t]),
     'kpal_fasta_flatten': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+    'kpal_fasta_records_begin': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_fasta_records_index': (ctypes.c_int, [_vp, _vp, _vp]),
+    'kpal_fasta_records_file_open': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
+    'kpal_fasta_records_file_next': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
+    'kpal_fasta_records_file_close': (ctypes.c_int, [_vp]),
+    'kpal_fasta_records_count': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
     'kpal_count_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_count_balance': (ctypes.c_int, [_vp]),
@@ -395,6 +401,46 @@ class Context(object):
         if n > 0:
             _check(self._L.kpal_count_records(self._h, int(k), a.ctypes.data if a.size else None, a.size, st.ctypes.data, n,
                                               out.ctypes.data))
+        return out
+
+    def fasta_records_begin(self, text):
+        """Tokenise FASTA text (whole records) on the device -> (n_records, flattened bytes); the index stays in the context."""
+        a = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+        n, nf = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._L.kpal_fasta_records_begin(self._h, a.ctypes.data if a.size else None, a.size, ctypes.byref(n), ctypes.byref(nf)))
+        self._records = n.value
+        self._records_scan = getattr(self, '_records_scan', 0) + 1      # (a scan interleaved with another one would read the other's index)
+        return n.value, nf.value
+
+    def fasta_records_file_open(self, path, begin=0, end=0):
+        """Start a by-record scan of bytes [begin, end) of a FASTA file the library reads itself (end = 0: to its end)."""
+        _check(self._L.kpal_fasta_records_file_open(self._h, os.fsencode(path), int(begin), int(end)))
+
+    def fasta_records_file_next(self):
+        """Index the next piece of whole records -> (n_records, flattened bytes, file offset of the piece), or None at the end."""
+        n, nf, off, done = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int(0)
+        _check(self._L.kpal_fasta_records_file_next(self._h, ctypes.byref(n), ctypes.byref(nf), ctypes.byref(off), ctypes.byref(done)))
+        self._records = n.value
+        self._records_scan = getattr(self, '_records_scan', 0) + 1
+        return None if done.value else (n.value, nf.value, off.value)
+
+    def fasta_records_file_close(self):
+        _check(self._L.kpal_fasta_records_file_close(self._h))
+
+    def fasta_records_index(self):
+        """-> (offset of every record's header line in the text, start of every record in the flattened stream [n + 1])."""
+        n = getattr(self, '_records', 0)
+        hdr = np.empty(n, dtype=np.uint64)
+        starts = np.empty(n + 1, dtype=np.uint64)
+        if n:
+            _check(self._L.kpal_fasta_records_index(self._h, hdr.ctypes.data, starts.ctypes.data))
+        return hdr, starts
+
+    def fasta_records_count(self, k, first, n):
+        """Tables of records [first, first + n) of the indexed text -> int64[n, 4**k]."""
+        out = np.empty((max(n, 0), 4 ** k), dtype=np.int64)
+        if n > 0:
+            _check(self._L.kpal_fasta_records_count(self._h, int(k), int(first), int(n), out.ctypes.data))
         return out
 
     def count_bytes(self, k, buf, strategy='auto'):

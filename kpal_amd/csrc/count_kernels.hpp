@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void count_records_kernel(Span s, uint64_t ste
         if (mask == 0) continue;
         // record of the lane's first byte: largest r with starts[r] <= position (positions are relative
         // to the first fed byte, s.lo)
+        // (the stream may begin inside the lane's chunk -- a batch of records that starts at any byte of the flattened text,
+        // kpal_fasta_records_count -- so every byte's position is taken relative to s.lo on its own)
         const uint64_t p0 = (st * 64 + lane) * 16;
         const uint64_t rel0 = p0 >= s.lo ? p0 - s.lo : 0;
         uint32_t lo = 0, hi = n_records;   // invariant: starts[lo] <= rel0 < starts[hi]
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void count_records_kernel(Span s, uint64_t ste
         uint64_t next_start = starts[r + 1];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint64_t rel = rel0 + j;
+            const uint64_t rel = p0 + j >= s.lo ? p0 + j - s.lo : 0;
             while (rel >= next_start && r + 1 < n_records) {   // records shorter than a chunk: may advance more than once
                 ++r;
                 next_start = starts[r + 1];

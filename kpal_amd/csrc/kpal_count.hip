@@ -51,7 +51,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2_QUADS)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_HEX)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -63,9 +63,12 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
         s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2_QUADS);
+    static const bool hex_auto = [] { const char *e = getenv("KPAL_K12_HEX"); return e && atoi(e) != 0; }();
+    if (ctx->strategy == KPAL_STRATEGY_AUTO && k == 12 && hex_auto) s = KPAL_STRATEGY_PARTITION_HEX;
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
     if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED || s == KPAL_STRATEGY_PARTITION_QUADS) && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
+    if (s == KPAL_STRATEGY_PARTITION_HEX && k != 12) return set_err(KPAL_E_INVALID, "the hex strategy needs k = 12 (k=%d)", k);
     if ((s == KPAL_STRATEGY_PARTITION2 || s == KPAL_STRATEGY_PARTITION2_QUADS) && (k < 13 || k > 16))
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
     *out = s;
@@ -386,7 +389,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     // 0.1 - 0.5 ms (launches, one merge of the whole table); a quarter million atomics do not
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
-    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
     // The two-level quad pipeline pays per FEED for the whole table -- its forms are staged (4 bytes per entry) and the finalisation
     // reads them and the table and writes the table -- where the round-1 two-level pipeline adds into the table with atomics and
     // pays for the table once per count (memset, Profile.balance).  Measured at the end of round 4 (same box, count + balance,
@@ -418,7 +421,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         const size_t cap = (size_t)(spb_max * G * 1024);
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
     }
-    else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+    else if (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) {
         // the record pool takes 4/3 of the input bytes (up to 8 x that for heavily skewed input, whose tiles are
         // smaller): pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
@@ -444,7 +447,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         if (!fresh) CHK(table_ready(ctx));   // zeros materialised; the staged forms of the previous piece added before their buffer is reused
         const size_t h = std::min(km1, halo + off);
         const Span s = make_span(addr + off, len, h);
-        if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS) {
+        if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS && strat != KPAL_STRATEGY_PARTITION_HEX) {
             ctx->plan_strategy = strat;
             ctx->plan_steps1 = ctx->plan_steps2 = 0;
         }
@@ -472,8 +475,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
                 return rc;
             }
         }
-        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
-            const int rc = launch_partition_quads(ctx, s);
+        else if (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) {
+            const int rc = strat == KPAL_STRATEGY_PARTITION_HEX ? launch_partition_hex(ctx, s) : launch_partition_quads(ctx, s);
             if (rc == KPAL_OK) ++ctx->stat_quad_pieces;
             if (rc == kSplitBatch) ++ctx->stat_split_pieces;
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size
@@ -848,10 +851,9 @@ KPAL_API int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, 
 // kpal_fasta_records_count then counts batches of records into one table each (count_records_kernel), as many as the caller has
 // room for.
 // ----------------------------------------------------------------------------------------------
-KPAL_API int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, uint64_t *n_records, uint64_t *flat_bytes)
+// in_pinned0: host_text lies in ctx->pinned[0] (the file reader put it there): the DMA engine reads it in place
+static int fasta_records_index_text(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, bool in_pinned0, uint64_t *n_records, uint64_t *flat_bytes)
 {
-    CTX_ENTER(ctx);
-    if (!n_records || !flat_bytes || (nbytes && !host_text)) return set_err(KPAL_E_INVALID, "NULL pointer");
     *n_records = *flat_bytes = 0;
     ctx->rec_n = ctx->rec_nf = 0;
     ctx->rec_starts_host.clear();
@@ -875,7 +877,13 @@ KPAL_API int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, s
     uint32_t *marks = kept + nblocks;
     // text -> device through the pinned staging buffers (host threads copy piece i + 1 while the DMA takes piece i)
     CHK(ensure_pinned(ctx));
-    {
+    if (in_pinned0) {
+        if (ctx->stage_used[0]) HIPCHK(hipEventSynchronize(ctx->ev_copied[0]));   // (an earlier DMA out of the buffer: long done, the caller has refilled it)
+        HIPCHK(hipMemcpyAsync(raw, text, m, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(hipEventRecord(ctx->ev_copied[0], ctx->copy_stream));
+        ctx->stage_used[0] = true;
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_copied[0], 0));
+    } else {
         const size_t stage = kpal_ctx::kStage;
         int slot = 0;
         for (size_t off = 0; off < m; off += stage, slot ^= 1) {
@@ -928,6 +936,146 @@ KPAL_API int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, s
     ctx->rec_nf = nf;
     *n_records = R;
     *flat_bytes = nf;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, uint64_t *n_records, uint64_t *flat_bytes)
+{
+    CTX_ENTER(ctx);
+    if (!n_records || !flat_bytes || (nbytes && !host_text)) return set_err(KPAL_E_INVALID, "NULL pointer");
+    return fasta_records_index_text(ctx, host_text, nbytes, false, n_records, flat_bytes);
+}
+
+// ---- the same over a FILE the library reads itself (the pool's threads pread into the pinned staging buffer: no byte of the text
+// passes through Python): every kpal_fasta_records_file_next indexes the next piece of WHOLE records -- up to the end of line
+// before the last header line of what fits the 64 MiB staging buffer; the unfinished record behind it is carried to the next
+// piece; a record longer than the buffer is gathered in pageable memory first.
+static void fasta_records_file_reset(kpal_ctx *ctx)
+{
+    if (ctx->rec_fd >= 0) close(ctx->rec_fd);
+    ctx->rec_fd = -1;
+    ctx->rec_pos = ctx->rec_end = ctx->rec_piece_at = 0;
+    ctx->rec_carry.clear();
+    ctx->rec_carry.shrink_to_fit();
+}
+
+KPAL_API int kpal_fasta_records_file_open(kpal_ctx *ctx, const char *path, uint64_t begin, uint64_t end)
+{
+    CTX_ENTER(ctx);
+    if (!path) return set_err(KPAL_E_INVALID, "path is NULL");
+    fasta_records_file_reset(ctx);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return set_err(KPAL_E_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return set_err(KPAL_E_IO, "%s is not a regular file", path);
+    }
+    const uint64_t size = (uint64_t)st.st_size;
+    if (end == 0) end = size;
+    if (begin > end || end > size) {
+        close(fd);
+        return set_err(KPAL_E_INVALID, "byte range %llu..%llu outside %s (%llu bytes)", (unsigned long long)begin, (unsigned long long)end, path,
+                       (unsigned long long)size);
+    }
+    (void)posix_fadvise(fd, (off_t)begin, (off_t)(end - begin), POSIX_FADV_SEQUENTIAL);
+    ctx->rec_fd = fd;
+    ctx->rec_pos = ctx->rec_piece_at = begin;
+    ctx->rec_end = end;
+    return KPAL_OK;
+}
+
+// index of the end-of-line byte before the LAST header line of buf[0, n) that begins at or after `from` (a '>' behind an
+// end of line), or n when there is none
+static size_t fasta_last_boundary(const uint8_t *buf, size_t n, size_t from)
+{
+    size_t i = n;
+    while (i > from + 1) {
+        const void *p = memrchr(buf + from + 1, '>', i - from - 1);
+        if (!p) break;
+        const size_t at = (size_t)((const uint8_t *)p - buf);
+        if (fa_host_is_eol(buf[at - 1])) return at - 1;
+        i = at;
+    }
+    return n;
+}
+
+KPAL_API int kpal_fasta_records_file_next(kpal_ctx *ctx, uint64_t *n_records, uint64_t *flat_bytes, uint64_t *text_offset, int *done)
+{
+    CTX_ENTER(ctx);
+    if (!n_records || !flat_bytes || !text_offset || !done) return set_err(KPAL_E_INVALID, "NULL pointer");
+    *n_records = *flat_bytes = *text_offset = 0;
+    *done = 1;
+    if (ctx->rec_fd < 0) return set_err(KPAL_E_STATE, "kpal_fasta_records_file_next without kpal_fasta_records_file_open");
+    CHK(ensure_pinned(ctx));
+    const size_t stage = std::min<size_t>(kpal_ctx::kStage, ctx->fa_chunk);   // (KPAL_FASTA_CHUNK: tests put the seams everywhere)
+    FaSource src;
+    src.fd = ctx->rec_fd;
+    for (;;) {
+        if (ctx->rec_carry.empty() && ctx->rec_pos >= ctx->rec_end) {   // the end
+            fasta_records_file_reset(ctx);
+            *n_records = *flat_bytes = *text_offset = 0;
+            *done = 1;
+            return KPAL_OK;
+        }
+        const size_t c = ctx->rec_carry.size();
+        const bool fits = c < stage;
+        uint8_t *buf;
+        size_t n;
+        if (fits) {   // the carried tail + the next bytes of the file into the pinned buffer
+            if (ctx->stage_used[0]) HIPCHK(hipEventSynchronize(ctx->ev_copied[0]));
+            buf = (uint8_t *)ctx->pinned[0];
+            if (c) memcpy(buf, ctx->rec_carry.data(), c);
+            const size_t want = (size_t)std::min<uint64_t>(stage - c, ctx->rec_end - ctx->rec_pos);
+            if (want) {
+                std::vector<int> ok;
+                fa_copy_start(src, buf + c, ctx->rec_pos, want, ok);
+                HostPool::instance().wait();
+                for (int e : ok)
+                    if (e) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(e));
+                ctx->rec_pos += want;
+            }
+            n = c + want;
+        } else {      // a record longer than the staging buffer: gathered in pageable memory, 64 MiB at a time
+            const size_t want = (size_t)std::min<uint64_t>(stage, ctx->rec_end - ctx->rec_pos);
+            ctx->rec_carry.resize(c + want);
+            if (want) {
+                std::vector<int> ok;
+                fa_copy_start(src, ctx->rec_carry.data() + c, ctx->rec_pos, want, ok);
+                HostPool::instance().wait();
+                for (int e : ok)
+                    if (e) return set_err(KPAL_E_IO, "reading the FASTA input failed: %s", strerror(e));
+                ctx->rec_pos += want;
+            }
+            buf = ctx->rec_carry.data();
+            n = c + want;
+        }
+        const bool at_end = ctx->rec_pos >= ctx->rec_end;
+        // whole records: up to the end of line before the last header line (searched in the new bytes only; a boundary is two bytes)
+        const size_t cut = at_end ? n : fasta_last_boundary(buf, n, c ? c - 1 : 0);
+        if (cut >= n && !at_end) {   // no record ends in this piece: keep gathering
+            if (fits) ctx->rec_carry.assign(buf, buf + n);
+            continue;
+        }
+        const size_t piece = at_end ? n : cut + 1;
+        const uint64_t at = ctx->rec_piece_at;
+        const int rc = fasta_records_index_text(ctx, buf, piece, fits, n_records, flat_bytes);
+        if (rc != KPAL_OK) return rc;
+        // the unfinished record behind the piece is carried (the DMA out of the pinned buffer has been waited for: the index is complete)
+        std::vector<uint8_t> tail(buf + piece, buf + n);
+        ctx->rec_carry.swap(tail);
+        ctx->rec_piece_at = at + piece;
+        *text_offset = at;
+        *done = 0;
+        if (*n_records == 0 && !(ctx->rec_carry.empty() && at_end)) continue;   // (text before the first header only: next piece)
+        return KPAL_OK;
+    }
+}
+
+KPAL_API int kpal_fasta_records_file_close(kpal_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    fasta_records_file_reset(ctx);
     return KPAL_OK;
 }
 

@@ -1,6 +1,8 @@
 // kpal_ctx.hip -- errors, context, device memory helpers and the per-kernel timing API of the C-ABI.
 #include "kpal_host.hpp"
 
+#include <unistd.h>
+
 // ----------------------------------------------------------------------------------------------
 // errors
 // ----------------------------------------------------------------------------------------------
@@ -187,6 +189,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->fa_nflat_host) (void)hipHostFree(ctx->fa_nflat_host);
+    if (ctx->rec_fd >= 0) (void)close(ctx->rec_fd);
     for (void *p : ctx->host_allocs) (void)hipHostFree(p);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);

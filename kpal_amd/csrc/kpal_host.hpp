@@ -95,6 +95,7 @@ struct kpal_ctx {
     size_t cached_bytes = 0;
     // two-level quad pipeline: the staged forms of the last piece have not been added to the table yet (quad2_finalize)
     bool finalize_pending = false;
+    bool finalize_hex = false;               // ... of the hex pipeline (k = 12, kpal_hex.hip): six planes in table order
     const void *finalize_stage = nullptr;
     // FRESH mode of that pipeline (kpal_quads2.hip): kpal_count_begin leaves the table of a k >= 13 count UNZEROED
     // (table_zero_pending) -- the first piece, if it is a whole device feed on the two-level quad pipeline, lets its
@@ -125,6 +126,10 @@ struct kpal_ctx {
     DevBuf rec_raw, rec_flat, rec_meta, rec_starts, rec_hdr;
     std::vector<uint64_t> rec_starts_host, rec_hdr_host;
     uint64_t rec_n = 0, rec_nf = 0;
+    // ... over a file the library reads itself (kpal_fasta_records_file_*): the open range, the unfinished record carried between pieces
+    int rec_fd = -1;
+    uint64_t rec_pos = 0, rec_end = 0, rec_piece_at = 0;
+    std::vector<uint8_t> rec_carry;
     uint64_t *fa_nflat_host = nullptr;
     std::vector<void *> host_allocs;         // kpal_host_alloc buffers still owned by callers (released with the context at the latest)
     size_t fa_chunk = kStage;                // text bytes per chunk (KPAL_FASTA_CHUNK: tests put the seams everywhere)
@@ -279,6 +284,8 @@ inline unsigned stream_grid(kpal_ctx *ctx, uint64_t n_items, unsigned block = 25
 constexpr int kQuadsUseChunked = 2;   // launch_partition*_quads (AUTO): the sample shows a feed for the round-1 pipeline
 constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
 int launch_partition_quads(kpal_ctx *ctx, const Span &s);                 // kpal_quads.hip
+int launch_partition_hex(kpal_ctx *ctx, const Span &s);                   // kpal_hex.hip (k = 12)
+int hex_finalize(kpal_ctx *ctx, bool balance);                            // kpal_hex.hip
 int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh = false);   // kpal_quads2.hip
 int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
                       size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr);   // kpal_quads.hip

@@ -115,6 +115,51 @@ def _last_boundary(text, begin):
     return max(a, b)
 
 
+def _line_end(text, start):
+    """Index of the first end-of-line byte (``\\n`` or ``\\r``) of ``text`` at or after ``start``, or ``len(text)``."""
+    a = text.find(b'\n', start)
+    if a < 0:
+        a = len(text)
+    b = text.find(b'\r', start, a)
+    return a if b < 0 else b
+
+
+def _whole_record_chunks(handle):
+    """FASTA text of ``handle`` in pieces of about ``_FASTA_CHUNK`` bytes that hold WHOLE records: ``(bytes, str or None, encoding)`` --
+    the text as bytes (what the device tokenises) and, for handles that yield ``str`` in an encoding of their own, the same
+    text as the ``str`` the names are read from (one byte per character: positions agree)."""
+    reader, keep_str, encoding = handle, False, 'ascii'
+    if isinstance(handle, io.TextIOWrapper):
+        try:                              # an ASCII-compatible text encoding: its bytes, undecoded (titles are decoded with it)
+            if codecs.lookup(handle.encoding or '').name in ('utf-8', 'ascii', 'iso8859-1') and handle.tell() == 0:
+                reader, encoding = handle.buffer, handle.encoding
+        except (LookupError, OSError, ValueError):
+            reader = handle
+    pending = bytearray()                 # text not handed out yet: ends inside a record
+    pending_str = []
+    while True:
+        text = reader.read(_FASTA_CHUNK)
+        if not text:
+            break
+        if not isinstance(text, bytes):
+            keep_str = True
+            pending_str.append(text)
+            text = text.encode('latin-1', 'replace')
+        searched = max(len(pending) - 1, 0)   # (a boundary is two bytes: EOL + '>')
+        pending += text
+        cut = _last_boundary(pending, searched)
+        if cut >= 0:                      # whole records up to the end of line before the last header line
+            out = bytes(pending[:cut + 1])
+            del pending[:cut + 1]
+            out_str = None
+            if keep_str:
+                joined = ''.join(pending_str)
+                out_str, pending_str = joined[:cut + 1], [joined[cut + 1:]]
+            yield out, out_str, encoding
+    if pending:
+        yield bytes(pending), (''.join(pending_str) if keep_str else None), encoding
+
+
 def _join_block(block):
     """One flat byte string for a block of sequences, ``\\n`` between them: C-speed joins for the
     homogeneous cases (all ``str`` / all ``bytes``), per-item encoding otherwise."""
@@ -268,9 +313,12 @@ class Profile(object):
     def from_fasta_by_record(cls, handle, length, prefix=None):
         """One profile per FASTA record, named by record (kpal/klib.py:114-133).
 
-        Records are counted in batches (``kpal_count_records``: one kernel launch and one table
-        download for up to ``_RECORD_BATCH_BYTES`` of tables) instead of one count per record; a
-        record whose table alone exceeds that budget falls back to ``from_sequences``."""
+        The text is handed to the GPU in chunks of whole records: the records are found ON THE DEVICE
+        (``kpal_fasta_records_begin``: the flattening kernels of ``from_fasta`` + an index of record starts and header
+        lines) and counted in batches (``kpal_fasta_records_count``: one kernel launch and one table download for up to
+        ``_RECORD_BATCH_BYTES`` of tables).  The host reads the HEADER lines only, for the names; there is no per-line or
+        per-character Python work.  A k whose table alone exceeds that budget falls back to ``from_sequences`` per
+        record."""
         length = int(length)
         if length < 1 or length > _native.KPAL_MAX_K:
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
@@ -282,26 +330,61 @@ class Profile(object):
                 yield cls.from_sequences([seq], length, name=prefix + (record_name or str(i + 1)))
             return
         ctx = _native.context()
-        names, seqs, size = [], [], 0
-
-        def flush():
-            data = [_encode(s) for s in seqs]
-            starts = np.zeros(len(data) + 1, dtype=np.uint64)
-            starts[1:] = np.cumsum([len(d) + 1 for d in data])       # one separator after every record
-            tables = ctx.count_records(length, b''.join(d + b'\n' for d in data), starts)
-            return [cls(tables[j], name=names[j]) for j in range(len(data))]
-
-        for i, (record_name, seq) in enumerate(_fasta_records(handle)):
-            names.append(prefix + (record_name or str(i + 1)))
-            seqs.append(seq)
-            size += len(seq) + 1
-            if len(seqs) >= per_batch or size >= _FEED_BYTES:
-                for profile in flush():
-                    yield profile
-                names, seqs, size = [], [], 0
-        if seqs:
-            for profile in flush():
-                yield profile
+        index = 0                                  # records seen so far (kpal/klib.py:132: the 1-based index names an untitled record)
+        plain = _plain_file(handle)
+        if plain is not None and os.path.getsize(plain[0]) > plain[1]:
+            # an ordinary file: the library reads it itself (parallel preads into pinned memory, pieces of whole records);
+            # the names are read from the header lines through a read-only mapping of the file
+            import mmap
+            encoding = handle.encoding if isinstance(handle, io.TextIOWrapper) else 'ascii'
+            with open(plain[0], 'rb') as raw, mmap.mmap(raw.fileno(), 0, access=mmap.ACCESS_READ) as text:
+                ctx.fasta_records_file_open(plain[0], plain[1], 0)
+                try:
+                    while True:
+                        piece = ctx.fasta_records_file_next()
+                        if piece is None:
+                            break
+                        n_records, _, at = piece
+                        if n_records == 0:
+                            continue
+                        header_off, _ = ctx.fasta_records_index()
+                        names = []
+                        for h in (header_off + np.uint64(at)).tolist():
+                            words = text[h + 1:_line_end(text, h)].decode(encoding, 'replace').split(None, 1)
+                            index += 1
+                            names.append(prefix + (words[0] if words else str(index)))
+                        scan = ctx._records_scan
+                        for first in range(0, n_records, per_batch):
+                            if ctx._records_scan != scan:
+                                raise RuntimeError('from_fasta_by_record: another by-record scan ran on this context meanwhile')
+                            n = min(per_batch, n_records - first)
+                            tables = ctx.fasta_records_count(length, first, n)
+                            for j in range(n):
+                                yield cls(tables[j], name=names[first + j])
+                finally:
+                    ctx.fasta_records_file_close()
+            handle.seek(0, os.SEEK_END)          # the handle has been consumed, as by the reference's SeqIO.parse loop
+            return
+        for text, text_str, encoding in _whole_record_chunks(handle):
+            n_records, _ = ctx.fasta_records_begin(text)
+            if n_records == 0:
+                continue
+            header_off, _ = ctx.fasta_records_index()
+            names = []
+            for h in header_off.tolist():
+                end = _line_end(text, h)
+                title = text_str[h + 1:end] if text_str is not None else text[h + 1:end].decode(encoding, 'replace')
+                words = title.split(None, 1)
+                index += 1
+                names.append(prefix + (words[0] if words else str(index)))
+            scan = ctx._records_scan
+            for first in range(0, n_records, per_batch):
+                if ctx._records_scan != scan:
+                    raise RuntimeError('from_fasta_by_record: another by-record scan ran on this context meanwhile')
+                n = min(per_batch, n_records - first)
+                tables = ctx.fasta_records_count(length, first, n)
+                for j in range(n):
+                    yield cls(tables[j], name=names[first + j])
 
     @classmethod
     def from_sequences(cls, sequences, length, name=None):

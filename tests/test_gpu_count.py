@@ -38,6 +38,8 @@ def strategies(k):
             s.append('partition')
         s.append('partition_chunked')
         s.append('partition_quads')
+        if k == 12:
+            s.append('partition_hex')
     if 13 <= k <= 16:
         s.append('partition2')
         s.append('partition2_quads')

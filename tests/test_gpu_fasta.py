@@ -182,6 +182,42 @@ def test_from_fasta_by_record_batched(ctx, monkeypatch):
         ctx.count_records(2, flat, [0, 9, 8, 15])
 
 
+def test_from_fasta_by_record_file(tmp_path, monkeypatch):
+    """from_fasta_by_record on FILES: the library reads the file itself and cuts it into pieces of whole records
+    (kpal_fasta_records_file_*); with the piece size forced down to 64 .. 5000 bytes records span many pieces, pieces hold many
+    records, and records longer than a piece are gathered first.  Names, order and every table against the independent
+    tokeniser + the oracle; text and binary handles; CRLF; text before the first header; an untitled record; an empty file."""
+    from kpal_amd import _native, klib
+    rnd = random.Random(77)
+    texts = ['junk before\n>r1 first\nACGTNACGT\n>\nAC\n>r3\n\n>r4\nA\n>r5\nC\n>r6\nGGGTTTAAACCC\n' + random_fasta(rnd, 120, 900),
+             random_fasta(rnd, 40, 9000, eol='\r\n'), '>only\n' + 'ACGTTGCA' * 4000, 'no header at all\nACGT\n', '>a\nACGT\n>b desc\nTTGA']
+    for chunk in (64, 257, 5000, 64 << 20):
+        monkeypatch.setenv('KPAL_FASTA_CHUNK', str(chunk))
+        ctx2 = _native.Context(_native.default_device())
+        monkeypatch.delenv('KPAL_FASTA_CHUNK')
+        monkeypatch.setattr(_native, 'context', lambda: ctx2)
+        try:
+            for t, text in enumerate(texts):
+                path = tmp_path / ('rec%d_%d.fa' % (chunk, t))
+                path.write_bytes(text.encode('latin-1'))
+                recs = seqio_records(text)
+                for k, mode in ((3, 'r'), (7, 'rb')):
+                    monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', 5 * 8 * 4 ** k)
+                    with open(str(path), mode) as fh:
+                        profiles = list(klib.Profile.from_fasta_by_record(fh, k, prefix='f'))
+                    assert [p.name for p in profiles] == ['f_' + (name or str(i + 1)) for i, (name, _) in enumerate(recs)], (chunk, t)
+                    for i, (p, (_, seq)) in enumerate(zip(profiles, recs)):
+                        if i < 30 or i % 11 == 0:
+                            np.testing.assert_array_equal(p.counts, oracle.from_sequences([seq], k), err_msg='chunk %d text %d record %d k=%d' % (chunk, t, i, k))
+                    assert sum(int(p.counts.sum()) for p in profiles) == sum(int(oracle.from_sequences([seq], k).sum()) for _, seq in recs)
+            empty = tmp_path / 'empty.fa'
+            empty.write_bytes(b'')
+            with open(str(empty)) as fh:
+                assert list(klib.Profile.from_fasta_by_record(fh, 4)) == []
+        finally:
+            ctx2.close()
+
+
 def test_chunk_seams_everywhere(tmp_path):
     """The pipelined ingest (kpal_count_feed_fasta / _file: chunks cut ANYWHERE, flattened with the state the previous chunk
     left -- line start / inside a header / inside a sequence line --, k-mer windows carried across the seams by the saved tail)

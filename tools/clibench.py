@@ -58,6 +58,61 @@ def write_fasta(ctx, path, gb, record_bases=100_020_000):
     return os.path.getsize(path), lines_total * width, records
 
 
+def by_record_bench(ctx, args):
+    """`--by-record`: Profile.from_fasta_by_record (records found on the device, names read from the header lines only) on files of
+    many records: Gbases/s of the generator consumed to the end (every profile built, its total summed, then dropped), next to the
+    host tokeniser alone (klib._fasta_records: the per-line interpreter loop the device index replaced) and to from_fasta on the
+    same file.  The tables are n_records x 4^k x 8 bytes -- at k = 8 that is 52 x the input for 10 kb records: they, not the
+    sequence, are what moves over PCIe and through NumPy."""
+    from kpal_amd import klib
+    shapes = [(100_000, 10_020, 4), (20_000, 10_020, 8), (1_000, 1_000_020, 8), (200_000, 300, 6)]
+    if args.records:
+        shapes = [(args.records, args.record_bases, args.k)]
+    out = []
+    for records, record_bases, k in shapes:
+        path = os.path.join(args.dir, 'kpal_clibench_rec_%d.fa' % os.getpid())
+        try:
+            gb = records * (record_bases // 60) * 61 / 1e9
+            nbytes, bases, nrec = write_fasta(ctx, path, gb, record_bases=record_bases)
+            row = {'records': nrec, 'record_bases': record_bases, 'k': k, 'file_bytes': nbytes, 'bases': bases, 'table_bytes_total': nrec * 8 * 4 ** k}
+
+            def consume(check):
+                total, n, names = 0, 0, []
+                with open(path) as fh:
+                    for p in klib.Profile.from_fasta_by_record(fh, k):
+                        if check:              # (summing the tables is the bench's own work: the first pass checks, the timed ones only iterate)
+                            total += int(p.counts.sum())
+                        n += 1
+                        if n <= 2 or n == nrec:
+                            names.append(p.name)
+                return total, n, names
+            total, n, names = consume(True)
+            times = []
+            for _ in range(args.repeat):
+                t = time.perf_counter()
+                _, n2, _ = consume(False)
+                times.append(time.perf_counter() - t)
+                assert n2 == n
+            with open(path) as fh:
+                whole = klib.Profile.from_fasta(fh, k)
+            per_record_kmers = max(record_bases // 60 * 60 - k + 1, 0)
+            assert n == nrec and names[:2] == ['chr1', 'chr2'] and names[-1] == 'chr%d' % nrec, (n, names)
+            assert total <= int(whole.total) and total >= (nrec - 1) * per_record_kmers, (total, int(whole.total))
+            row['by_record'] = {'s': min(times), 'Gbases_per_s': bases / min(times) / 1e9, 'records_per_s': nrec / min(times),
+                                'tables_GBs': nrec * 8 * 4 ** k / min(times) / 1e9}
+            t = time.perf_counter()
+            with open(path) as fh:
+                m = sum(len(sq) for _, sq in klib._fasta_records(fh))
+            dt = time.perf_counter() - t
+            assert m == bases
+            row['host_tokeniser_alone'] = {'s': dt, 'Gbases_per_s': bases / dt / 1e9}
+            out.append(row)
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)
+    return out
+
+
 def pread_rate(path, threads, limit=4 << 30):
     size = min(os.path.getsize(path), limit)
     buf = np.empty(64 << 20, dtype=np.uint8)
@@ -91,10 +146,16 @@ def main():
     ap.add_argument('--dir', default='/dev/shm')
     ap.add_argument('--keep', action='store_true')
     ap.add_argument('--repeat', type=int, default=2)
+    ap.add_argument('--by-record', action='store_true', help='time Profile.from_fasta_by_record on files of many records instead')
+    ap.add_argument('--records', type=int, default=0, help='--by-record: one shape only: this many records ...')
+    ap.add_argument('--record-bases', type=int, default=10_020, help='... of this many bases each (at --k)')
     args = ap.parse_args()
     from kpal_amd import _native, dist, files, klib, kmer
     import memh5
     ctx = _native.context()
+    if args.by_record:
+        print(json.dumps({'by_record': by_record_bench(ctx, args), 'host_cores': os.cpu_count()}))
+        return
     path = os.path.join(args.dir, 'kpal_clibench_%d.fa' % os.getpid())
     out = {'k': args.k, 'dir': args.dir, 'host_cores': os.cpu_count(), 'read_threads': int(os.environ.get('KPAL_READ_THREADS', '16')), 'read_pin': os.environ.get('KPAL_READ_PIN', '0')}
     try:
