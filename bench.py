@@ -827,6 +827,14 @@ def multi_gpu_worker(args):
     if library:
         modes = ['library_serial', 'library_pipelined'] if args.serial_reduce else ['library_pipelined', 'library_serial']
     modes.append('torch_serial')
+    # the bin-range merge (ncclReduceScatter + mirrored-range exchange: every rank keeps and balances 1 / W of the table): the
+    # merge k >= 13 needs (8 GiB per rank at k = 15); measured at every k as `extra` -- LAST, a collective pattern no run has
+    # exercised yet must not stand between the run and its other figures -- the headline only when asked (--range-merge)
+    if library and world & (world - 1) == 0 and 4 ** k >= world * world:
+        if args.range_merge:
+            modes.insert(0, 'library_range')
+        else:
+            modes.append('library_range')
     if args.only_headline_mode:
         modes = modes[:1]
 
@@ -842,11 +850,17 @@ def multi_gpu_worker(args):
             reducer = kdist.TableReducer(kdist.table_as_tensor(ctx), sync=ctx.sync, balance=lambda t: ctx.balance_device(k, t.data_ptr()),
                                          mode=args.reduce, overlap=args.overlap_reduce)
         pipelined = mode == 'library_pipelined'
+        ranged = mode == 'library_range'
 
         def step():
             ctx.count_begin(k, args.strategy)           # zero the 4^k table
             ctx.count_feed_device(dev_buf, nbytes)
-            if reducer is None:
+            if ranged:
+                # ONE ncclReduceScatter (every rank keeps its range of the merged table) + the balance of that range through one
+                # all-to-all of the mirrored entries: queued by the library on the context's stream
+                ctx.comm_reduce_scatter_table(balance=True)
+                ctx.sync()
+            elif reducer is None:
                 # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step
                 ctx.comm_reduce_table(0, balance=True, pipelined=pipelined)
                 if not pipelined:
@@ -873,6 +887,9 @@ def multi_gpu_worker(args):
         ctx.prof_enable(False)
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         td.all_reduce(t, op=td.ReduceOp.MAX)
+        if ranged:
+            ctx.comm_gather_table()                     # (collective, outside the timed region: the whole vector on rank 0 for the check)
+            ctx.sync()
         merged = None
         if rank == 0:
             merged = np.empty(bins, dtype=np.int64)
@@ -906,7 +923,8 @@ def multi_gpu_worker(args):
             'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'int64', 'data': 'synthetic',
             'config': {'workload': 'k=%d, %d synthetic %dbp reads per GPU resident in HBM, count+RCCL reduce+balance' % (k, n_reads, L),
                        'k': k, 'reads_per_gpu': n_reads, 'read_len': L, 'strategy': args.strategy,
-                       'parallelism': 'reads sharded x%d, 1 ncclReduce(int64 sum) of the 4^k table to rank 0 per step' % world,
+                       'parallelism': ('reads sharded x%d, 1 ncclReduceScatter(int64 sum) of the 4^k table + 1 all-to-all of 4^k/W mirrored entries per step' if mode == 'library_range'
+                                       else 'reads sharded x%d, 1 ncclReduce(int64 sum) of the 4^k table to rank 0 per step') % world,
                        'reduce_mode': mode, 'attempt': args.attempt, 'merged_equals_single_stream': r['same']},
             'checksum_ok': r['sum_ok'], 'merged_equals_single_stream': r['same'], 'rccl_ranks': td.get_world_size(),
             'reduce_via': 'library' if lib else 'torch', 'pipelined_reduce': mode == 'library_pipelined', 'reduce_mode': mode, 'attempt': args.attempt,
@@ -914,7 +932,7 @@ def multi_gpu_worker(args):
         }
         extra = {}
         for other, o in results.items():
-            key = {'library_pipelined': 'pipelined_reduce', 'library_serial': 'serial_reduce', 'torch_serial': 'torch_reduce'}[other]
+            key = {'library_pipelined': 'pipelined_reduce', 'library_serial': 'serial_reduce', 'torch_serial': 'torch_reduce', 'library_range': 'range_merge'}[other]
             extra[key] = {'ms_per_step': o['elapsed'] / steps * 1e3, 'value': total_reads * L / (o['elapsed'] / steps) / 1e9,
                           'merged_equals_single_stream': o['same'], 'checksum_ok': o['sum_ok'],
                           'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(o['prof'].items())}}
@@ -985,6 +1003,9 @@ def main():
                     help='N>1, library: the headline is count -> reduce -> balance in ONE stream per step instead of the pipelined default (the reduce + '
                          'balance of step i run on a copy of the table and a second stream while step i+1 counts); the other form is measured as `extra`')
     ap.add_argument('--only-headline-mode', action='store_true', help='N>1: measure the headline reduce mode only')
+    ap.add_argument('--range-merge', action='store_true',
+                    help='N>1, library: the headline is the bin-range merge (ncclReduceScatter + mirrored-range exchange: every rank keeps and balances '
+                         '1 / W of the table) instead of the reduce to rank 0; it is measured as `extra` either way')
     ap.add_argument('--reduce', default='int64', choices=['int64', 'u32'], help='N>1, torch reduce only: dtype moved by the reduce')
     ap.add_argument('--overlap-reduce', action='store_true', help='N>1, torch reduce only: reduce on a second buffer while the next step counts')
     ap.add_argument('--stub', action='store_true', help='plumbing self-test on CPU/gloo, no counting (tests of the launcher and the supervisors)')

@@ -188,6 +188,20 @@ int kpal_comm_destroy(kpal_ctx *ctx);
 int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance);
 int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance);
 int kpal_comm_merged_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins);
+/* The bin-range merge (k >= 13, where one rank cannot usefully hold and balance the whole merged vector): ONE ncclReduceScatter
+ * (int64 sum) leaves rank r the merged bins [r * 4^k / W, (r + 1) * 4^k / W) in place in its count table; with balance,
+ * Profile.balance (klib.py:285-298) of that range -- the entries rc(i) it needs lie 1 / W on every rank: one all-to-all of
+ * 4^k / W^2 entries per pair of ranks between two permutation kernels (csrc/range_index.hpp).  W must be a power of two with
+ * W^2 <= 4^k.  kpal_comm_merged_range tells where a rank's part lies (first_bin, n_bins; after the whole-table reduces: 0, 4^k);
+ * kpal_comm_gather_table (collective, after the range merge) completes every rank's table by one ncclAllGather. */
+int kpal_comm_reduce_scatter_table(kpal_ctx *ctx, int balance);
+int kpal_comm_gather_table(kpal_ctx *ctx);
+int kpal_comm_merged_range(kpal_ctx *ctx, void **dev_table, uint64_t *first_bin, uint64_t *n_bins);
+/* The two permutation kernels of that exchange for callers that move the blocks themselves (kpal_amd.dist over torch.distributed):
+ * dev_send / dev_recv hold 4^k / W entries, block q = what goes to / came from rank q; dev_table is the whole table, of which only
+ * the rank's range is read (pack) or balanced in place (unpack). */
+int kpal_range_pack_device(kpal_ctx *ctx, int k, int rank, int world, const int64_t *dev_table, int64_t *dev_send);
+int kpal_range_unpack_device(kpal_ctx *ctx, int k, int rank, int world, int64_t *dev_table, const int64_t *dev_recv);
 /* kdistlib.distance_matrix (kdistlib.py:164-186) over several GPUs, sharded by BIN RANGE: every rank holds the same bins
  * [first, first + bin_count) of all P profiles (dev_slices: int64[P][bin_count] on the device, profile-major; ranges of different
  * ranks tile 0 .. 4^k; the LDS-staged and matrix-core kernels run when EVERY rank's range is a multiple of 64 bins and >= 4096 -- the

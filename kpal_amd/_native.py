@@ -91,6 +91,11 @@ SIGNATURES = {
     'kpal_comm_reduce_table_async': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     'kpal_comm_merged_table': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_comm_max_f64': (ctypes.c_int, [_vp, _f64p]),
+    'kpal_comm_reduce_scatter_table': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'kpal_comm_gather_table': (ctypes.c_int, [_vp]),
+    'kpal_comm_merged_range': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    'kpal_range_pack_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'kpal_range_unpack_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'kpal_comm_distance_matrix_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64, _vp, ctypes.c_int, _f64p]),
     'kpal_synth_reads_device': (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_int, ctypes.c_int, _vp]),
@@ -469,6 +474,27 @@ class Context(object):
         n = ctypes.c_uint64(0)
         _check(self._L.kpal_comm_merged_table(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def comm_reduce_scatter_table(self, balance=False):
+        """The bin-range merge: ONE ncclReduceScatter leaves this rank its range of the merged table (in place), balanced through
+        one all-to-all of the mirrored entries when asked (power-of-two worlds)."""
+        _check(self._L.kpal_comm_reduce_scatter_table(self._h, int(bool(balance))))
+
+    def comm_gather_table(self):
+        """After comm_reduce_scatter_table: every rank's table completed by one ncclAllGather (collective)."""
+        _check(self._L.kpal_comm_gather_table(self._h))
+
+    def comm_merged_range(self):
+        """-> (device pointer, first bin, number of bins) of this rank's part of the merged table."""
+        p, first, n = _vp(), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._L.kpal_comm_merged_range(self._h, ctypes.byref(p), ctypes.byref(first), ctypes.byref(n)))
+        return p.value, first.value, n.value
+
+    def range_pack_device(self, k, rank, world, dev_table, dev_send):
+        _check(self._L.kpal_range_pack_device(self._h, int(k), int(rank), int(world), _vp(dev_table), _vp(dev_send)))
+
+    def range_unpack_device(self, k, rank, world, dev_table, dev_recv):
+        _check(self._L.kpal_range_unpack_device(self._h, int(k), int(rank), int(world), _vp(dev_table), _vp(dev_recv)))
 
     def comm_distance_matrix_device(self, P, bin_count, dev_slices, metric):
         """distance_matrix values from bin-range shards: this rank's int64[P][bin_count] slices on the device -> the full lower

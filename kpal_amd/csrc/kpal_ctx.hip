@@ -183,7 +183,7 @@ KPAL_API void kpal_ctx_destroy(kpal_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     (void)kpal_comm_destroy(ctx);
-    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->direct_list, &ctx->direct_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw[0], &ctx->fa_raw[1], &ctx->fa_flat[0], &ctx->fa_flat[1], &ctx->fa_meta[0], &ctx->fa_meta[1], &ctx->fa_tail, &ctx->rec_raw, &ctx->rec_flat, &ctx->rec_meta, &ctx->rec_starts, &ctx->rec_hdr, &ctx->dstage[0],
+    DevBuf *bufs[] = {&ctx->table, &ctx->keys, &ctx->cntmat, &ctx->offs, &ctx->bucket_start, &ctx->slice_start, &ctx->chunk_meta, &ctx->chunk_table, &ctx->chunk_ovf, &ctx->chunk_sorted, &ctx->quad_meta, &ctx->quad_meta2, &ctx->direct_list, &ctx->direct_meta, &ctx->residuals, &ctx->cnt1, &ctx->offs1, &ctx->start1, &ctx->fa_raw[0], &ctx->fa_raw[1], &ctx->fa_flat[0], &ctx->fa_flat[1], &ctx->fa_meta[0], &ctx->fa_meta[1], &ctx->fa_tail, &ctx->rec_raw, &ctx->rec_flat, &ctx->rec_meta, &ctx->rec_starts, &ctx->rec_hdr, &ctx->xsend, &ctx->xrecv, &ctx->dstage[0],
                       &ctx->dstage[1], &ctx->scratch[0], &ctx->scratch[1], &ctx->scratch[2], &ctx->scratch[3],
                       &ctx->partials, &ctx->result, &ctx->canon, &ctx->opt_l, &ctx->opt_r, &ctx->opt_levels, &ctx->opt_profiles};
     for (DevBuf *b : bufs)

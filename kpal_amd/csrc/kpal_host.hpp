@@ -160,6 +160,8 @@ struct kpal_ctx {
     int side_turn = 0;
     void *merged = nullptr;                  // where the last merged table lies (the count table or a side buffer)
     uint64_t merged_bins = 0;                // ... and how many bins it has (kpal_count_begin with another k discards it)
+    uint64_t merged_first = 0;               // ... and which bin its first one is (bin-range merge: a rank holds its range only)
+    DevBuf xsend, xrecv;                     // the packed blocks of the mirror exchange (kpal_comm_reduce_scatter_table)
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;

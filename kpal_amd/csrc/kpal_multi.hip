@@ -13,6 +13,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include "range_index.hpp"
+
 namespace {
 
 struct RcclApi {
@@ -23,6 +25,13 @@ struct RcclApi {
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // the bin-range merge (optional: a library without them only lacks kpal_comm_reduce_scatter_table / _gather_table)
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 RcclApi g_rccl;
@@ -55,6 +64,12 @@ int rccl_load(const char *path)
     KPAL_RCCL_SYM(AllReduce, "ncclAllReduce")
     KPAL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef KPAL_RCCL_SYM
+    a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     g_rccl = a;
     return KPAL_OK;
 }
@@ -152,6 +167,7 @@ KPAL_API int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance)
     }
     ctx->merged = ctx->table.p;
     ctx->merged_bins = ctx->bins;
+    ctx->merged_first = 0;
     if (balance && ctx->comm_rank == root) CHK(launch_balance(ctx, ctx->k, (const int64_t *)ctx->table.p, (int64_t *)ctx->table.p));
     return KPAL_OK;
 }
@@ -195,6 +211,148 @@ KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
     ctx->side_used[t] = true;
     ctx->merged = ctx->side[t].p;
     ctx->merged_bins = ctx->bins;
+    ctx->merged_first = 0;
+    return KPAL_OK;
+}
+
+// ---- bin-range merge (k >= 13: the whole-table reduce to one rank moves and then balances 8 GiB per rank at k = 15) -------------
+// ncclReduceScatter leaves rank r the merged bins [r * 4^k / W, (r + 1) * 4^k / W); Profile.balance of that range needs the
+// entries rc(i), of which every rank holds 1 / W (range_index.hpp): one all-to-all of 4^k / W^2 entries per pair of ranks,
+// packed and unpacked by two permutation kernels.  Nothing leaves the ranks unless a caller wants the whole vector on one
+// (kpal_comm_gather_table).
+__global__ __launch_bounds__(256) void range_pack_kernel(RangeIndex R, uint32_t rank, const unsigned long long *__restrict__ table, unsigned long long *__restrict__ send)
+{
+    const uint64_t n1 = R.range_bins(), n2 = R.pair_bins();
+    for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n1; l += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = (uint64_t)rank * n1 + l;
+        const uint32_t q = R.owner(RangeIndex::revcomp(j, R.k));
+        send[(uint64_t)q * n2 + R.pos(j)] = table[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void range_unpack_kernel(RangeIndex R, uint32_t rank, unsigned long long *__restrict__ table, const unsigned long long *__restrict__ recv)
+{
+    const uint64_t n1 = R.range_bins(), n2 = R.pair_bins();
+    for (uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n1; l += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = (uint64_t)rank * n1 + l;
+        const uint64_t j = RangeIndex::revcomp(i, R.k);
+        table[i] += recv[(uint64_t)R.owner(j) * n2 + R.pos(j)];     // (klib.py:285-298: a palindrome meets itself -- doubled)
+    }
+}
+
+static int comm_range_geometry(kpal_ctx *ctx, RangeIndex &R)
+{
+    const int W = ctx->comm_world;
+    if (W < 1 || (W & (W - 1))) return set_err(KPAL_E_INVALID, "the bin-range merge needs a power-of-two number of ranks (%d): use kpal_comm_reduce_table", W);
+    int w = 0;
+    while ((1 << w) < W) ++w;
+    R = RangeIndex{ctx->k, w};
+    if (!R.valid()) return set_err(KPAL_E_INVALID, "the bin-range merge needs 4^k >= W^2 (k=%d, %d ranks)", ctx->k, W);
+    return KPAL_OK;
+}
+
+// The packed range a rank's mirror entries travel in: rank_pack / rank_unpack of the library for callers that move the blocks
+// themselves (kpal_amd.dist over torch.distributed): send/recv hold 4^k / W entries, block q = what goes to / came from rank q.
+KPAL_API int kpal_range_pack_device(kpal_ctx *ctx, int k, int rank, int world, const int64_t *dev_table, int64_t *dev_send)
+{
+    CTX_ENTER(ctx);
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) return set_err(KPAL_E_INVALID, "bad rank / power-of-two world %d / %d", rank, world);
+    int w = 0;
+    while ((1 << w) < world) ++w;
+    const RangeIndex R{k, w};
+    if (k < 1 || k > KPAL_MAX_K || !R.valid()) return set_err(KPAL_E_INVALID, "k=%d with %d ranks", k, world);
+    if (!dev_table || !dev_send) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const unsigned grid = (unsigned)std::min<uint64_t>((R.range_bins() + 255) / 256, (uint64_t)ctx->num_cu * 16);
+    LAUNCH(ctx, "range_pack", range_pack_kernel, dim3(grid), dim3(256), R, (uint32_t)rank, (const unsigned long long *)dev_table, (unsigned long long *)dev_send);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_range_unpack_device(kpal_ctx *ctx, int k, int rank, int world, int64_t *dev_table, const int64_t *dev_recv)
+{
+    CTX_ENTER(ctx);
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world) return set_err(KPAL_E_INVALID, "bad rank / power-of-two world %d / %d", rank, world);
+    int w = 0;
+    while ((1 << w) < world) ++w;
+    const RangeIndex R{k, w};
+    if (k < 1 || k > KPAL_MAX_K || !R.valid()) return set_err(KPAL_E_INVALID, "k=%d with %d ranks", k, world);
+    if (!dev_table || !dev_recv) return set_err(KPAL_E_INVALID, "NULL pointer");
+    const unsigned grid = (unsigned)std::min<uint64_t>((R.range_bins() + 255) / 256, (uint64_t)ctx->num_cu * 16);
+    LAUNCH(ctx, "range_unpack", range_unpack_kernel, dim3(grid), dim3(256), R, (uint32_t)rank, (unsigned long long *)dev_table, (const unsigned long long *)dev_recv);
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_reduce_scatter_table(kpal_ctx *ctx, int balance)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->counting) return set_err(KPAL_E_STATE, "kpal_comm_reduce_scatter_table before kpal_count_begin");
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (!g_rccl.ReduceScatter || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return set_err(KPAL_E_HIP, "this RCCL library lacks ncclReduceScatter / ncclSend / ncclRecv");
+    RangeIndex R{0, 0};
+    CHK(comm_range_geometry(ctx, R));
+    CHK(table_ready(ctx));
+    const uint32_t W = (uint32_t)ctx->comm_world, r = (uint32_t)ctx->comm_rank;
+    const uint64_t n1 = R.range_bins(), n2 = R.pair_bins();
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    {
+        ProfScope ps_(ctx, "rccl_reduce_scatter");
+        NCCLCHK(g_rccl.ReduceScatter(table, table + (uint64_t)r * n1, (size_t)n1, ncclInt64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));   // in place
+    }
+    if (balance) {
+        CHK(ensure(ctx, ctx->xsend, (size_t)n1 * 8));
+        CHK(ensure(ctx, ctx->xrecv, (size_t)n1 * 8));
+        unsigned long long *send = (unsigned long long *)ctx->xsend.p, *recv = (unsigned long long *)ctx->xrecv.p;
+        const unsigned grid = (unsigned)std::min<uint64_t>((n1 + 255) / 256, (uint64_t)ctx->num_cu * 16);
+        LAUNCH(ctx, "range_pack", range_pack_kernel, dim3(grid), dim3(256), R, r, (const unsigned long long *)table, send);
+        HIPCHK(hipMemcpyAsync(recv + (uint64_t)r * n2, send + (uint64_t)r * n2, (size_t)n2 * 8, hipMemcpyDeviceToDevice, ctx->stream));   // a rank's own block
+        if (W > 1) {
+            ProfScope ps_(ctx, "rccl_mirror_exchange");
+            NCCLCHK(g_rccl.GroupStart());
+            ncclResult_t bad = ncclSuccess;
+            for (uint32_t q = 0; q < W; ++q) {
+                if (q == r) continue;
+                ncclResult_t e = g_rccl.Send(send + (uint64_t)q * n2, (size_t)n2, ncclInt64, (int)q, (ncclComm_t)ctx->comm, ctx->stream);
+                if (e == ncclSuccess) e = g_rccl.Recv(recv + (uint64_t)q * n2, (size_t)n2, ncclInt64, (int)q, (ncclComm_t)ctx->comm, ctx->stream);
+                if (e != ncclSuccess) bad = e;
+            }
+            const ncclResult_t ge = g_rccl.GroupEnd();      // (always closed: an open group would swallow every later call)
+            if (bad != ncclSuccess || ge != ncclSuccess) return set_err(KPAL_E_HIP, "the mirror exchange failed: %s", g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
+        }
+        LAUNCH(ctx, "range_unpack", range_unpack_kernel, dim3(grid), dim3(256), R, r, table, (const unsigned long long *)recv);
+    }
+    ctx->merged = table + (uint64_t)r * n1;
+    ctx->merged_bins = n1;
+    ctx->merged_first = (uint64_t)r * n1;
+    return KPAL_OK;
+}
+
+// the ranges of all ranks into every rank's table (in place): the whole merged vector where a caller wants it
+KPAL_API int kpal_comm_gather_table(kpal_ctx *ctx)
+{
+    CTX_ENTER(ctx);
+    if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    if (!g_rccl.AllGather) return set_err(KPAL_E_HIP, "this RCCL library lacks ncclAllGather");
+    RangeIndex R{0, 0};
+    CHK(comm_range_geometry(ctx, R));
+    unsigned long long *table = (unsigned long long *)ctx->table.p;
+    if (!table || ctx->merged != table + (uint64_t)ctx->comm_rank * R.range_bins()) return set_err(KPAL_E_STATE, "kpal_comm_gather_table follows kpal_comm_reduce_scatter_table");
+    {
+        ProfScope ps_(ctx, "rccl_allgather");
+        NCCLCHK(g_rccl.AllGather(table + (uint64_t)ctx->comm_rank * R.range_bins(), table, (size_t)R.range_bins(), ncclInt64, (ncclComm_t)ctx->comm, ctx->stream));
+    }
+    ctx->merged = table;
+    ctx->merged_bins = ctx->bins;
+    ctx->merged_first = 0;
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_comm_merged_range(kpal_ctx *ctx, void **dev_table, uint64_t *first_bin, uint64_t *n_bins)
+{
+    if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
+    if (!ctx->merged) return set_err(KPAL_E_STATE, "no merged table (kpal_comm_reduce_table[_async] / kpal_comm_reduce_scatter_table)");
+    if (dev_table) *dev_table = ctx->merged;
+    if (first_bin) *first_bin = ctx->merged_first;
+    if (n_bins) *n_bins = ctx->merged_bins;
     return KPAL_OK;
 }
 
@@ -250,20 +408,24 @@ KPAL_API int kpal_comm_distance_matrix_device(kpal_ctx *ctx, int P, uint64_t bin
 {
     CTX_ENTER(ctx);
     if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
+    // The ranks must take the SAME kernel family: the Gram path all-reduces dot products, the others per-pair sums and counts.
+    // Which one a rank would take depends on its own slice (>= 4096 bins, a multiple of 64), so the choice is agreed first:
+    // the LDS-staged kernels only if EVERY rank's slice allows them.  A rank whose own arguments are bad must not return before
+    // that collective (the others would wait in it for ever): validity rides in the same all-reduce(MIN) -- agreed values
+    // 1 = all valid, LDS-staged kernels; 0 = all valid, plain kernels; -1 = some rank's arguments are invalid: every rank returns
+    // KPAL_E_INVALID.  (P and metric are the same on all ranks by contract: checked before, they cannot differ.)
     if (P < 1) return set_err(KPAL_E_INVALID, "P must be >= 1");
     if (metric < 0 || metric > 2) return set_err(KPAL_E_INVALID, "unknown metric %d", metric);
     if (P == 1) return KPAL_OK;
-    if (!dev_slices || !out_lower) return set_err(KPAL_E_INVALID, "NULL pointer");
-    if (bin_count == 0 || ((uintptr_t)dev_slices & 15)) return set_err(KPAL_E_INVALID, "every rank needs a non-empty, 16-byte aligned slice");
-    // The ranks must take the SAME kernel family: the Gram path all-reduces dot products, the others per-pair sums and counts.
-    // Which one a rank would take depends on its own slice (>= 4096 bins, a multiple of 64), so the choice is agreed first:
-    // the LDS-staged kernels only if EVERY rank's slice allows them (one 4-byte all-reduce(MIN)).
-    int tiled = bin_count >= 4096 && bin_count % 64 == 0;
+    const bool valid = dev_slices && out_lower && bin_count != 0 && ((uintptr_t)dev_slices & 15) == 0;
+    int tiled = !valid ? -1 : ((bin_count >= 4096 && bin_count % 64 == 0) ? 1 : 0);
     CHK(ensure(ctx, ctx->result, 64));
     HIPCHK(hipMemcpyAsync(ctx->result.p, &tiled, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     NCCLCHK(g_rccl.AllReduce(ctx->result.p, ctx->result.p, 1, ncclInt32, ncclMin, (ncclComm_t)ctx->comm, ctx->stream));
     HIPCHK(hipMemcpyAsync(&tiled, ctx->result.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (tiled < 0)
+        return set_err(KPAL_E_INVALID, valid ? "another rank's slice is empty, misaligned or NULL" : "every rank needs a non-empty, 16-byte aligned slice and an output array");
     return distance_matrix_core(ctx, P, bin_count, dev_slices, metric, out_lower, true, tiled);
 }
 

@@ -72,6 +72,107 @@ def count_synth_sharded(ctx, k, seed, n_reads_total, read_len, rank, world_size,
     return first, n
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The bin-range merge (k >= 13): reduce-scatter + mirrored-range exchange.  The library does it with RCCL on its own stream
+# (kpal_comm_reduce_scatter_table); this is the torch.distributed variant of the same protocol, with the same index arithmetic
+# (csrc/range_index.hpp, restated here in NumPy for CPU tensors: the gloo tests).
+# ----------------------------------------------------------------------------------------------------------------------
+def _revcomp(idx, k):
+    """Profile.reverse_complement (kpal/klib.py:394-412) on a uint64 array."""
+    x = ~idx.astype(np.uint64)
+    for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+        m = np.uint64(m)
+        x = ((x >> np.uint64(sh)) & m) | ((x & m) << np.uint64(sh))
+    x = (x >> np.uint64(32)) | (x << np.uint64(32))
+    return x >> np.uint64(64 - 2 * k)
+
+
+def range_geometry(k, world):
+    """-> (w, bins per rank, bins per pair of ranks) of the bin-range merge; ``world`` must be a power of two with world^2 <= 4^k."""
+    w = int(world).bit_length() - 1
+    if world < 1 or (1 << w) != world:
+        raise ValueError('the bin-range merge needs a power-of-two number of ranks (got %d)' % world)
+    if 4 * ((w + 1) // 2) > 2 * k:
+        raise ValueError('the bin-range merge needs 4^k >= world^2 (k=%d, %d ranks)' % (k, world))
+    n1 = 4 ** k >> w
+    return w, n1, n1 >> w
+
+
+def range_owner_pos(j, k, world):
+    """RangeIndex::owner / pos of csrc/range_index.hpp for a uint64 array of table indices -> (owner rank, position in its block)."""
+    w, n1, _ = range_geometry(k, world)
+    j = j.astype(np.uint64)
+    owner = (j >> np.uint64(2 * k - w)) if w else np.zeros_like(j)
+    lb = 2 * ((w + 1) // 2)
+    spare = lb - w
+    mid = (j & np.uint64(n1 - 1)) >> np.uint64(lb)
+    if spare:
+        sub = (_revcomp(j, k) >> np.uint64(2 * k - lb)) & np.uint64(1)
+        return owner, (mid << np.uint64(1)) | sub
+    return owner, mid
+
+
+def range_pack(table, k, rank, world):
+    """NumPy restatement of range_pack_kernel: this rank's range of ``table`` (int64[4^k]) -> int64[4^k / world], block q = what rank q gets."""
+    w, n1, n2 = range_geometry(k, world)
+    j = np.arange(rank * n1, (rank + 1) * n1, dtype=np.uint64)
+    q, _ = range_owner_pos(_revcomp(j, k), k, world)
+    _, p = range_owner_pos(j, k, world)
+    send = np.empty(n1, dtype=np.int64)
+    send[(q * np.uint64(n2) + p).astype(np.int64)] = table[rank * n1:(rank + 1) * n1]
+    return send
+
+
+def range_unpack(table, recv, k, rank, world):
+    """NumPy restatement of range_unpack_kernel: balances this rank's range of ``table`` in place with the received blocks."""
+    w, n1, n2 = range_geometry(k, world)
+    i = np.arange(rank * n1, (rank + 1) * n1, dtype=np.uint64)
+    j = _revcomp(i, k)
+    q, p = range_owner_pos(j, k, world)
+    table[rank * n1:(rank + 1) * n1] += recv[(q * np.uint64(n2) + p).astype(np.int64)]
+
+
+def reduce_scatter_balance(table, k, balance=True, ctx=None, group=None):
+    """The bin-range merge over torch.distributed: ``table`` (torch int64[4^k]: this rank's counts; a CUDA tensor viewing the
+    context's table under nccl / RCCL -- then ``ctx`` runs the library's pack / unpack kernels -- or a CPU tensor under gloo) ->
+    this rank's range of the merged (and balanced) table, in place: ONE reduce_scatter of 4^k int64 + ONE all_to_all of 4^k / W.
+    Returns ``(first_bin, n_bins)``."""
+    import torch
+    import torch.distributed as td
+    on = td.is_available() and td.is_initialized()
+    rank = td.get_rank(group) if on else 0
+    world = td.get_world_size(group) if on else 1
+    w, n1, n2 = range_geometry(k, world)
+    mine = table[rank * n1:(rank + 1) * n1]
+    if world > 1:
+        td.reduce_scatter_tensor(mine, table, op=td.ReduceOp.SUM, group=group)      # in place: the output is the input's own block
+    if balance:
+        if table.is_cuda:
+            if ctx is None:
+                raise ValueError('a CUDA table needs the context whose kernels pack and unpack it')
+            send = torch.empty(n1, dtype=torch.int64, device=table.device)
+            recv = torch.empty(n1, dtype=torch.int64, device=table.device)
+            torch.cuda.synchronize()                           # (torch's stream -> the context's)
+            ctx.range_pack_device(k, rank, world, table.data_ptr(), send.data_ptr())
+            ctx.sync()
+            if world > 1:
+                td.all_to_all_single(recv, send, group=group)
+            else:
+                recv.copy_(send)
+            torch.cuda.synchronize()
+            ctx.range_unpack_device(k, rank, world, table.data_ptr(), recv.data_ptr())
+            ctx.sync()
+        else:
+            send = torch.from_numpy(range_pack(table.numpy(), k, rank, world))
+            recv = torch.empty_like(send)
+            if world > 1:
+                td.all_to_all_single(recv, send, group=group)
+            else:
+                recv.copy_(send)
+            range_unpack(table.numpy(), recv.numpy(), k, rank, world)
+    return rank * n1, n1
+
+
 class TableReducer(object):
     """The multi-GPU merge step of the counting path: per-rank count tables -> their sum on rank 0
     (+ ``balance`` there), one collective per step.

@@ -282,14 +282,88 @@ for k in (4, 9):
         assert np.array_equal(t.numpy(), want), 'FASTA shards: merged counts differ from the whole-file count (k=%%d)' %% k
 if rank == 0:
     print('FASTA_SHARDS_OK')
+# the bin-range merge (reduce-scatter + mirrored-range exchange, kpal_amd.dist.reduce_scatter_balance): every rank's range of the
+# merged + balanced table against oracle.balance of the single-stream count
+for k in (4, 7):
+    mine = oracle.count_flat(oracle.synth_reads(50 + k, first, n, 150), k)
+    t = torch.from_numpy(mine.copy())
+    lo, cnt = dist.reduce_scatter_balance(t, k, balance=True)
+    want = oracle.balance(oracle.count_flat(oracle.synth_reads(50 + k, 0, n_reads, 150), k), k)
+    assert (lo, cnt) == (rank * 4 ** k // world, 4 ** k // world)
+    assert np.array_equal(t.numpy()[lo:lo + cnt], want[lo:lo + cnt]), 'bin-range merge: rank %%d range differs (k=%%d)' %% (rank, k)
+    t2 = torch.from_numpy(mine.copy())
+    dist.reduce_scatter_balance(t2, k, balance=False)
+    plain = oracle.count_flat(oracle.synth_reads(50 + k, 0, n_reads, 150), k)
+    assert np.array_equal(t2.numpy()[lo:lo + cnt], plain[lo:lo + cnt])
+ok = torch.ones(1, dtype=torch.int64)
+td.all_reduce(ok)
+if rank == 0 and int(ok.item()) == world:
+    print('RANGE_MERGE_OK')
 td.barrier()
 td.destroy_process_group()
 '''
 
 
+_GLOO_RANGE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as td
+import oracle
+from kpal_amd import dist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+td.init_process_group('gloo', rank=rank, world_size=world)
+n_reads = 803
+first, n = dist.shard_range(n_reads, rank, world)
+for k in (3, 6, 8):
+    mine = oracle.count_flat(oracle.synth_reads(70 + k, first, n, 150, noisy=True), k)
+    t = torch.from_numpy(mine.copy())
+    lo, cnt = dist.reduce_scatter_balance(t, k, balance=True)
+    want = oracle.balance(oracle.count_flat(oracle.synth_reads(70 + k, 0, n_reads, 150, noisy=True), k), k)
+    assert np.array_equal(t.numpy()[lo:lo + cnt], want[lo:lo + cnt]), (rank, k)
+ok = torch.ones(1, dtype=torch.int64)
+td.all_reduce(ok)
+if rank == 0 and int(ok.item()) == world:
+    print('RANGE_MERGE_OK')
+td.barrier()
+td.destroy_process_group()
+'''
+
+
+def test_world_size_4_gloo_bin_range_merge(tmp_path):
+    """The bin-range merge at world 4 (an even number of range bits; world 2 -- an odd one -- runs in
+    test_world_size_2_gloo_reduce): reduce_scatter + one all_to_all of the mirrored entries, every rank's range against the
+    oracle's balance of the single-stream count (the oracle stands in for the per-rank GPU count)."""
+    script = tmp_path / 'range_worker.py'
+    script.write_text(_GLOO_RANGE_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', WORLD_SIZE='4')
+    procs = []
+    for rank in range(4):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'RANGE_MERGE_OK' in outs[0], outs[0]
+
+
+def test_range_and_hex_index_arithmetic(tmp_path):
+    """CPU emulations of two index schemes the device kernels share their header with: the bin-range merge of per-rank tables
+    (csrc/range_index.hpp: W ranks, reduce-scatter, pack, all-to-all, unpack against balance of the summed table; k = 2..8 for
+    every W, packing bijection at k = 13..16) and the hex pipeline's items (csrc/hex_index.hpp: stream -> 48-byte lanes -> groups ->
+    full / half items -> six forms -> table against the rolling-window count)."""
+    import shutil
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    for name, token in (('range_index_check', 'RANGE_INDEX_OK'), ('hex_index_check', 'HEX_INDEX_OK')):
+        exe = str(tmp_path / name)
+        b = subprocess.run(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'native', name + '.cpp')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert b.returncode == 0, b.stdout.decode()[-3000:]
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0 and token in r.stdout.decode(), r.stdout.decode()[-3000:]
+
+
 def test_world_size_2_gloo_reduce(tmp_path):
     """N > 1 path on CPU: shard reads over 2 ranks, reduce the int64 tables with one collective
-    (gloo here, RCCL on the GPUs), compare with the single-stream count."""
+    (gloo here, RCCL on the GPUs), compare with the single-stream count; the bin-range merge at world 2."""
     script = tmp_path / 'worker.py'
     corpus = fasta_corpus(tmp_path)
     fasta = [corpus['many'], corpus['giant_wrapped'], corpus['messy'], corpus['giant_one_line']]
@@ -304,6 +378,7 @@ def test_world_size_2_gloo_reduce(tmp_path):
     assert 'GLOO_OK %d' % (1001 * 145) in outs[0]
     assert 'REDUCER_OK' in outs[0], outs[0]
     assert 'FASTA_SHARDS_OK' in outs[0], outs[0]
+    assert 'RANGE_MERGE_OK' in outs[0], outs[0]
 
 
 def test_quad2_index_arithmetic(tmp_path):

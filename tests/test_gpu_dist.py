@@ -76,7 +76,7 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     assert line['reduce_mode'] == 'library_pipelined' and line['pipelined_reduce'] is True and line['reduce_via'] == 'library'
     assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
     assert line['config']['merged_equals_single_stream'] is True and line['config']['reduce_mode'] == 'library_pipelined'
-    for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce'):
+    for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce', 'range_merge'):
         assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['ms_per_step'] > 0, mode
         assert line['config'][mode + '_ms_per_step'] > 0
     # (at 3 M reads the fixed-cost histogram stage may be the longest kernel: an intermediate kernel has no algorithmic bytes of its own)

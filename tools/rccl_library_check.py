@@ -35,6 +35,49 @@ for k in (12, 13):
             gots.append(got)
         for g, w in zip(gots, wants):
             assert np.array_equal(g, w), (k, pipelined)
+# the bin-range merge (kpal_comm_reduce_scatter_table: ncclReduceScatter + the mirrored-range exchange; world 1: the one range is
+# the whole table, the rank's own block a device copy) + kpal_comm_gather_table, and the two permutation kernels alone at every
+# power-of-two "world" -- one process playing all ranks: every rank's range of the balanced table against the oracle
+for k in (9, 12, 13):
+    buf = oracle.synth_reads(90 + k, 0, 30000, 150, noisy=True)
+    want_plain = oracle.count_flat(buf, k)
+    want = oracle.balance(want_plain, k)
+    for balance in (True, False):
+        ctx.count_begin(k, 'partition2_quads' if k == 13 else 'auto')
+        ctx.count_feed(buf)
+        ctx.comm_reduce_scatter_table(balance=balance)
+        ctx.sync()
+        ptr, first, bins = ctx.comm_merged_range()
+        assert (first, bins) == (0, 4 ** k)
+        got = np.empty(bins, dtype=np.int64)
+        ctx.d2h(got, ptr)
+        assert np.array_equal(got, want if balance else want_plain), (k, balance)
+        ctx.comm_gather_table()
+        ctx.sync()
+        assert ctx.comm_merged_range()[1:] == (0, 4 ** k)
+    # pack / unpack kernels at world 2, 4, 8: rank r's blocks to rank q are exchanged on the host
+    tab = ctx.alloc(8 * 4 ** k)
+    for world in (2, 4, 8):
+        n1 = 4 ** k // world
+        n2 = n1 // world
+        sends = []
+        d_send = ctx.alloc(8 * n1)
+        for r in range(world):
+            ctx.h2d(tab, want_plain)
+            ctx.range_pack_device(k, r, world, tab, d_send)
+            h = np.empty(n1, dtype=np.int64)
+            ctx.d2h(h, d_send)
+            sends.append(h)
+        for r in range(world):
+            recv = np.concatenate([sends[q][r * n2:(r + 1) * n2] for q in range(world)])
+            ctx.h2d(d_send, recv)
+            ctx.h2d(tab, want_plain)
+            ctx.range_unpack_device(k, r, world, tab, d_send)
+            out = np.empty(4 ** k, dtype=np.int64)
+            ctx.d2h(out, tab)
+            assert np.array_equal(out[r * n1:(r + 1) * n1], want[r * n1:(r + 1) * n1]), (k, world, r)
+        ctx.free(d_send)
+    ctx.free(tab)
 # distance matrix from bin-range shards (world size 1: the one shard is the whole range; the split / all-reduce / join of the
 # per-pair partials runs all the same): LDS-staged kernels (64-bin multiples) and the register-tile kernel (a ragged range)
 rs = np.random.RandomState(3)
