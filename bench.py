@@ -462,6 +462,43 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
 
     guarded('end_to_end', lambda: end_to_end(ctx, args.k, dev_buf, nbytes, args.reads, L, headline_ms * 1e-3))
 
+    def skew():
+        """Not every read set is i.i.d. uniform: 1 GiB of (a) the uniform reads, (b) the same with 2 % of the reads replaced by poly-A /
+        (AC)n reads, (c) a homopolymer, counted at k = 12 and k = 15 through AUTO, whole buffer resident in HBM (kernel time of
+        begin + feed + finish, best of three).  Parity of exactly these inputs at exactly this size: tests/test_gpu_skew_full.py."""
+        n_reads = (1 << 30) // (L + 1)
+        n = n_reads * (L + 1)
+        host = np.empty(n, dtype=np.uint8)
+        ctx.synth_reads_device(2, 0, n_reads, L, dev_buf)
+        ctx.d2h(host, dev_buf)
+        rs = np.random.RandomState(5)
+        low = host.reshape(n_reads, L + 1).copy()
+        hit = np.flatnonzero(rs.rand(n_reads) < 0.02)
+        poly = rs.rand(hit.size) < 0.5
+        low[hit[poly], :L] = ord('A')
+        low[hit[~poly], :L] = np.frombuffer((b'AC' * L)[:L], dtype=np.uint8)
+        cases = (('uniform', host), ('low_complexity_2pct', low.reshape(-1)), ('homopolymer', np.full(n, ord('A'), dtype=np.uint8)))
+        out = {}
+        for k2 in (12, 15):
+            for name, buf in cases:
+                ctx.h2d(dev_buf, buf)
+                best, plan = None, None
+                for it in range(4):
+                    ctx.prof_enable(True)
+                    ctx.prof_reset()
+                    ctx.count_begin(k2)
+                    ctx.count_feed_device(dev_buf, n)
+                    plan = ctx.count_last_plan()
+                    ctx.count_finish(to_host=False)
+                    ctx.sync()
+                    ms = sum(v[0] for v in ctx.prof_get().values())
+                    ctx.prof_enable(False)
+                    if it and (best is None or ms < best):     # (the first pass is the warm-up)
+                        best = ms
+                out['k%d_%s' % (k2, name)] = {'ms': best, 'Gbases_per_s': n_reads * L / best / 1e6, 'plan': '%s/%d/%d' % plan}
+        return out
+    guarded('skew', skew)
+
     def k15():
         ctx.synth_reads_device(4, 0, args.reads, L, dev_buf)             # SURVEY.md 8d config 4: seed 4
         r = count_measure(ctx, 15, dev_buf, nbytes, args.reads, L, 'auto', 3, 1)
@@ -713,6 +750,14 @@ def stub_rank(args):
     import torch.distributed as td
     from kpal_amd import dist as kdist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    # what RCCL chose (rings / trees, channels, transports, protocol per collective) goes to one file per rank; rank 0 condenses
+    # its own into one string of the line (rccl_info)
+    nccl_log = None
+    if os.environ.get('KPAL_BENCH_RUN_DIR') and os.environ.get('KPAL_BENCH_NCCL_INFO', '1') != '0':
+        nccl_log = os.path.join(os.environ['KPAL_BENCH_RUN_DIR'], 'nccl_attempt%d_rank%d.log' % (args.attempt, rank))
+        os.environ.setdefault('NCCL_DEBUG', 'INFO')
+        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+        os.environ.setdefault('NCCL_DEBUG_FILE', nccl_log)
     if args.worker:
         set_flag(args.attempt, 'started', rank)
     if args.attempt == 1 and args.stub_fail_rank == rank:
@@ -754,6 +799,34 @@ def stub_rank(args):
     td.destroy_process_group()
 
 
+def rccl_info(path):
+    """One short string from a rank's NCCL_DEBUG=INFO log: version, channels, rings / trees, transports seen, and the algorithm /
+    protocol lines of the tuning subsystem if it printed any.  Never raises: '' when there is nothing to say."""
+    try:
+        import re
+        with open(path, errors='replace') as fh:
+            text = fh.read()
+        out = []
+        m = re.search(r'(RCCL version [^\n]*|NCCL version [^\n]*)', text)
+        if m:
+            out.append(m.group(1).strip()[:60])
+        chans = re.findall(r'Channel (\d+)/(\d+)', text)
+        if chans:
+            out.append('%s channels' % chans[-1][1])
+        for word, label in (('Connected all rings', 'rings'), ('Connected all trees', 'trees')):
+            if word in text:
+                out.append(label)
+        via = sorted(set(re.findall(r'via ([A-Za-z0-9/_]+)', text)))
+        if via:
+            out.append('via ' + '+'.join(via[:4]))
+        algo = sorted(set(re.findall(r'(?:Algo(?:rithm)?\s*[=:]?\s*)(\w+)[^\n]{0,40}?(?:proto(?:col)?\s*[=:]?\s*)(\w+)', text)))
+        if algo:
+            out.append('algo/proto ' + ','.join('%s/%s' % a for a in algo[:4]))
+        return '; '.join(out)[:240]
+    except Exception:
+        return ''
+
+
 def multi_gpu_worker(args):
     """One worker of an N > 1 job (BASELINE config 3): this rank's shard resident in HBM; per step zero + count + ONE reduce of
     the 4^k tables to rank 0 + balance there.  Up to three reduce modes are measured in one invocation, each with its own
@@ -773,6 +846,14 @@ def multi_gpu_worker(args):
         sys.exit('bench.py needs a GPU (no CPU fallback for the hot path)')
     torch.cuda.set_device(local_rank)
     ctx = _native.Context(local_rank)
+    # what RCCL chose (rings / trees, channels, transports, protocol per collective) goes to one file per rank; rank 0 condenses
+    # its own into one string of the line (rccl_info)
+    nccl_log = None
+    if os.environ.get('KPAL_BENCH_RUN_DIR') and os.environ.get('KPAL_BENCH_NCCL_INFO', '1') != '0':
+        nccl_log = os.path.join(os.environ['KPAL_BENCH_RUN_DIR'], 'nccl_attempt%d_rank%d.log' % (args.attempt, rank))
+        os.environ.setdefault('NCCL_DEBUG', 'INFO')
+        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+        os.environ.setdefault('NCCL_DEBUG_FILE', nccl_log)
     if args.worker:
         set_flag(args.attempt, 'started', rank)
         join_process_group('nccl', rank, world, args.attempt, device_id=torch.device('cuda', local_rank))
@@ -822,7 +903,29 @@ def multi_gpu_worker(args):
             ident.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
         td.broadcast(ident, src=0)
         torch.cuda.synchronize()
-        ctx.comm_init(rank, world, bytes(ident.cpu().numpy().tobytes()))
+        # ncclCommInitRank is a collective over a bootstrap socket: time-boxed on its own (a rank that cannot reach the others must
+        # not eat the whole run limit) -- a timeout ends this attempt with its reason, the supervisors start the conservative one
+        import threading
+        init_error, init_done = [None], threading.Event()
+        comm_id = bytes(ident.cpu().numpy().tobytes())
+
+        def comm_init():
+            try:
+                ctx.comm_init(rank, world, comm_id)
+            except Exception as e:
+                init_error[0] = '%s: %s' % (type(e).__name__, e)
+            finally:
+                init_done.set()
+        threading.Thread(target=comm_init, daemon=True).start()
+        init_limit = float(os.environ.get('KPAL_BENCH_COMM_INIT_TIMEOUT', '120'))
+        if not init_done.wait(init_limit):
+            init_error[0] = 'kpal_comm_init (ncclCommInitRank of the library) did not return within %.0f s on rank %d' % (init_limit, rank)
+        if init_error[0]:
+            why = 'library_rccl_error: ' + init_error[0]
+            print('bench.py worker: ' + why, file=sys.stderr, flush=True)
+            if args.worker:
+                set_flag(args.attempt, 'failed', rank, why)
+            os._exit(3)                                 # (a thread may still sit in the collective: no orderly teardown)
     modes = []
     if library:
         modes = ['library_serial', 'library_pipelined'] if args.serial_reduce else ['library_pipelined', 'library_serial']
@@ -938,6 +1041,8 @@ def multi_gpu_worker(args):
                           'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(o['prof'].items())}}
             line['config'][key + '_ms_per_step'] = extra[key]['ms_per_step']       # (scalars: the driver's record keeps them)
         line['extra'] = extra
+        if nccl_log:
+            line['config']['rccl_info'] = rccl_info(nccl_log)
         if cpu[0] is not None:
             line['cpu_baseline'] = cpu[0]
         if library_error:
@@ -1072,6 +1177,10 @@ def main():
                                 ('fasta_file_Gbases_per_s', 'fasta_end_to_end', 'Gbases_per_s')):
             if isinstance(ex.get(src), dict) and field in ex[src]:
                 line['config'][key] = ex[src][field]
+        if isinstance(ex.get('skew'), dict):
+            for name, v in ex['skew'].items():
+                if isinstance(v, dict) and 'Gbases_per_s' in v:
+                    line['config']['skew_%s_Gbases_per_s' % name] = v['Gbases_per_s']
         line['config']['extras_ok'] = all(v.get('checksum_ok', True) is True and 'error' not in v for v in ex.values() if isinstance(v, dict))
     line['config']['checksum_ok'] = r['checksum_ok']
     print(json.dumps(line), flush=True)

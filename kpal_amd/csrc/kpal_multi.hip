@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include "comm_schedule.hpp"
 #include "range_index.hpp"
 
 namespace {
@@ -174,7 +175,48 @@ KPAL_API int kpal_comm_reduce_table(kpal_ctx *ctx, int root, int balance)
 
 // Pipelined: the table is copied to one of two side buffers (0.05 ms at k = 12) and reduced + balanced THERE, on the
 // communicator's stream, while the context's stream goes on with the next count.  The side buffers alternate: the merged
-// table of step i stays valid until the reduce of step i+2 is issued.
+// table of step i stays valid until the reduce of step i+2 is issued.  The schedule itself is comm_schedule.hpp (shared with a
+// CPU harness that runs it on a fake runtime under ThreadSanitizer); this is its HIP + RCCL runtime.
+namespace {
+struct HipCommRuntime {
+    kpal_ctx *ctx;
+    int rc = KPAL_OK;   // the first library error (its message is in kpal_last_error)
+    size_t side_capacity(int t) { return ctx->side[t].p ? ctx->side[t].cap : 0; }
+    void *side_ptr(int t) { return ctx->side[t].p; }
+    int hip(hipError_t e, const char *what)
+    {
+        if (e == hipSuccess) return 0;
+        rc = set_err(e == hipErrorOutOfMemory ? KPAL_E_NOMEM : KPAL_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return rc;
+    }
+    int side_grow(int t, size_t bytes) { return rc = ensure(ctx, ctx->side[t], bytes); }
+    int host_wait_side_free(int t) { return hip(hipEventSynchronize(ctx->ev_side_free[t]), "hipEventSynchronize"); }
+    int main_wait_side_free(int t) { return hip(hipStreamWaitEvent(ctx->stream, ctx->ev_side_free[t], 0), "hipStreamWaitEvent"); }
+    int main_copy_table_to_side(int t, size_t bytes) { return hip(hipMemcpyAsync(ctx->side[t].p, ctx->table.p, bytes, hipMemcpyDeviceToDevice, ctx->stream), "hipMemcpyAsync"); }
+    int main_record_copied() { return hip(hipEventRecord(ctx->ev_table_copied, ctx->stream), "hipEventRecord"); }
+    int comm_wait_copied() { return hip(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_table_copied, 0), "hipStreamWaitEvent"); }
+    int comm_reduce_side(int t, int root)
+    {
+        std::swap(ctx->stream, ctx->comm_stream);   // (ProfScope works on ctx->stream)
+        {
+            ProfScope ps_(ctx, "rccl_reduce");
+            const ncclResult_t r = g_rccl.Reduce(ctx->side[t].p, ctx->side[t].p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream);
+            if (r != ncclSuccess) rc = set_err(KPAL_E_HIP, "ncclReduce failed: %s", g_rccl.GetErrorString(r));
+        }
+        std::swap(ctx->stream, ctx->comm_stream);
+        return rc;
+    }
+    int comm_balance_side(int t)
+    {
+        std::swap(ctx->stream, ctx->comm_stream);   // (LAUNCH works on ctx->stream)
+        rc = launch_balance(ctx, ctx->k, (const int64_t *)ctx->side[t].p, (int64_t *)ctx->side[t].p);
+        std::swap(ctx->stream, ctx->comm_stream);
+        return rc;
+    }
+    int comm_record_side_free(int t) { return hip(hipEventRecord(ctx->ev_side_free[t], ctx->comm_stream), "hipEventRecord"); }
+};
+}  // namespace
+
 KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
 {
     CTX_ENTER(ctx);
@@ -182,37 +224,22 @@ KPAL_API int kpal_comm_reduce_table_async(kpal_ctx *ctx, int root, int balance)
     if (!ctx->comm) return set_err(KPAL_E_STATE, "no communicator (kpal_comm_init)");
     if (root < 0 || root >= ctx->comm_world) return set_err(KPAL_E_INVALID, "root %d not in 0..%d", root, ctx->comm_world - 1);
     CHK(table_ready(ctx));
-    ctx->side_turn ^= 1;
-    const int t = ctx->side_turn;
-    const size_t bytes = (size_t)ctx->bins * sizeof(int64_t);
-    if (ctx->side[t].cap < bytes && ctx->side_used[t]) {   // (re-allocation: its last reader -- on the communicator's stream -- is done)
-        HIPCHK(hipEventSynchronize(ctx->ev_side_free[t]));
-        ctx->side_used[t] = false;
-        if (ctx->merged == ctx->side[t].p) ctx->merged = nullptr, ctx->merged_bins = 0;
-    }
-    CHK(ensure(ctx, ctx->side[t], bytes));
-    // the buffer's previous content (the merged table of two steps ago) may go once its reduce + balance are done
-    if (ctx->side_used[t]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side_free[t], 0));
-    HIPCHK(hipMemcpyAsync(ctx->side[t].p, ctx->table.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev_table_copied, ctx->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_table_copied, 0));
-    std::swap(ctx->stream, ctx->comm_stream);   // (LAUNCH / ProfScope work on ctx->stream)
-    int rc = KPAL_OK;
-    {
-        ProfScope ps_(ctx, "rccl_reduce");
-        const ncclResult_t r = g_rccl.Reduce(ctx->side[t].p, ctx->side[t].p, (size_t)ctx->bins, ncclInt64, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream);
-        if (r != ncclSuccess) rc = set_err(KPAL_E_HIP, "ncclReduce failed: %s", g_rccl.GetErrorString(r));
-    }
-    if (rc == KPAL_OK && balance && ctx->comm_rank == root)
-        rc = launch_balance(ctx, ctx->k, (const int64_t *)ctx->side[t].p, (int64_t *)ctx->side[t].p);
-    std::swap(ctx->stream, ctx->comm_stream);
-    if (rc != KPAL_OK) return rc;
-    HIPCHK(hipEventRecord(ctx->ev_side_free[t], ctx->comm_stream));
-    ctx->side_used[t] = true;
-    ctx->merged = ctx->side[t].p;
-    ctx->merged_bins = ctx->bins;
-    ctx->merged_first = 0;
-    return KPAL_OK;
+    HipCommRuntime rt{ctx};
+    CommPipeState st;
+    st.side_turn = ctx->side_turn;
+    st.side_used[0] = ctx->side_used[0];
+    st.side_used[1] = ctx->side_used[1];
+    st.merged = ctx->merged;
+    st.merged_bins = ctx->merged_bins;
+    st.merged_first = ctx->merged_first;
+    const int rc = comm_reduce_async_schedule(rt, st, ctx->bins, ctx->comm_rank, root, balance != 0);
+    ctx->side_turn = st.side_turn;
+    ctx->side_used[0] = st.side_used[0];
+    ctx->side_used[1] = st.side_used[1];
+    ctx->merged = st.merged;
+    ctx->merged_bins = st.merged_bins;
+    ctx->merged_first = st.merged_first;
+    return rc;
 }
 
 // ---- bin-range merge (k >= 13: the whole-table reduce to one rank moves and then balances 8 GiB per rank at k = 15) -------------

@@ -196,7 +196,7 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // 12 spilled, and a kernel that uses scratch memory at all ran ~10 % slower in same-box comparisons -- so four steps ahead there;
     // k = 12 fits its 128 registers either way and a four-step ring changed nothing: 7.44 vs 7.40 ms)
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
-    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 && K != 12 ? 4 : S)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
+    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 ? 4 : S)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
            error, table)
     DISPATCH_K_8_12(ctx->k, {
         switch (steps) {

@@ -241,7 +241,8 @@ __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
 }
 
-template <int K, int LEVEL = 1, typename SINK = TableOnly>
+// mult: every active lane stands for `mult` occurrences of its item (the repeat lanes of quad_scatter_kernel: 4).
+template <int K, int LEVEL = 1, typename SINK = TableOnly, uint32_t mult = 1u>
 __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
 {
     const int lane = threadIdx.x & 63;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
         const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(row, src);
         const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(item, src);
         const unsigned long long same = __builtin_amdgcn_ballot_w64(active && row == hot_row && item == hot_item) & todo;
-        const uint32_t n = (uint32_t)__popcll(same);
+        const uint32_t n = (uint32_t)__popcll(same) * mult;
         const unsigned long long key = ((unsigned long long)hot_row << 32) | hot_item;
         const uint32_t slot = (quad_hot_hash(hot_row, hot_item) + (uint32_t)(lane & 3)) & (uint32_t)(kQuadHotEntries - 1);
         const unsigned long long seen = lane < 4 ? hot[slot].key : ~0ull;
@@ -285,21 +286,21 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
         for (int pr = 0; pr < 4 && !done; ++pr) {
             const uint32_t slot = (h + (uint32_t)pr) & (uint32_t)(kQuadHotEntries - 1);
             if (hot[slot].key == key) {
-                atomicAdd(&hot[slot].count, 1u);
+                atomicAdd(&hot[slot].count, mult);
                 done = true;
             }
         }
-        if (!done) to_table(row, item, 1ULL);
+        if (!done) to_table(row, item, (unsigned long long)mult);
     }
 }
 
 // (rare path, called from the unrolled placement loop: kept out of line there; the scatter kernels' epilogues inline the body -- an
 // out-of-line call next to everything that is live there cost spilled registers, and kernels that use scratch memory at all ran
 // 8 % slower in same-box comparisons, wherever the spill sat)
-template <int K, int LEVEL = 1, typename SINK = TableOnly>
+template <int K, int LEVEL = 1, typename SINK = TableOnly, uint32_t MULT = 1u>
 __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
 {
-    quad_items_direct_body<K, LEVEL, SINK>(active, row, item, table, hot, coarse);
+    quad_items_direct_body<K, LEVEL, SINK, MULT>(active, row, item, table, hot, coarse);
 }
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
@@ -705,6 +706,21 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                 const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, (uint32_t)lane, row[q], item[q]);
             }
+#if !defined(KPAL_QUAD_NO_REPEAT)   // A/B builds
+            // REPEAT LANES.  Inside a homopolymer or a repeat of period 2 or 4 (poly-A tails, (AC)n, (ACGT)n ...) the four items of a
+            // lane are one and the same: all such lanes of the reads of a tile want the same row, round after round -- that row
+            // overflows, its items ride in the spill list, fail again as carried items and end in the hot-item table one by one
+            // (2 % of such reads cost the kernel 3.4 x).  They go there at once: one ballot-counted update per distinct item and
+            // wave, each lane standing for four occurrences, and nothing of them enters the rows.
+            {
+                const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
+                                 row[2] == row[0] && row[3] == row[0];
+                if (__builtin_expect(__any(rep), 0)) {   // wave-uniform
+                    quad_items_direct<K, 1, SINK2, 4u>(rep, row[0], item[0], table, hot);
+                    if (rep) item[0] = item[1] = item[2] = item[3] = 0u;
+                }
+            }
+#endif
 #if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
             asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
 #else

@@ -83,3 +83,4 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     assert line['value'] > 0 and line['roofline']['pipeline_frac'] > 0 and 'rccl_reduce' in line['roofline']['kernels_ms_per_step']
     # the N > 1 line carries the CPU baseline too (rank 0's host cores, the N = 1 sample)
     assert 'cpu_baseline' in line and line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['kind'] == 'port'
+    assert isinstance(line['config'].get('rccl_info'), str)       # (what RCCL said it chose: rank 0's NCCL_DEBUG=INFO log, condensed)

@@ -1,7 +1,8 @@
 """The product's own GPU-free host code under AddressSanitizer + UBSan and ThreadSanitizer (CPU only: sanitizers are not
 available on the GPU pool): the pool of copy threads (kpal_amd/csrc/host_pool.hpp), the host side of the FASTA ingest --
 source, read-ahead, chunk cutting, the state carried across chunk seams (kpal_amd/csrc/fasta_host.hpp) -- and the copy phase
-of the CPython gatherer behind Profile.from_sequences (kpal_amd/csrc/kpal_join_core.h).  The harnesses are tests/native/*."""
+of the CPython gatherer behind Profile.from_sequences (kpal_amd/csrc/kpal_join_core.h), and the stream / event schedule of the
+pipelined multi-GPU table reduce (kpal_amd/csrc/comm_schedule.hpp) driven by a fake runtime.  The harnesses are tests/native/*."""
 import os
 import shutil
 import subprocess
@@ -21,6 +22,8 @@ CASES = [
     ('host_pool_check.cpp', 'g++', ['-std=c++17'], ['1', '2', '16']),
     ('fasta_host_check.cpp', 'g++', ['-std=c++17'], ['1', '5']),
     ('join_check.c', 'gcc', ['-std=c11'], ['']),
+    # the stream / event schedule of the pipelined multi-GPU reduce on a fake runtime: ranks, streams and events as threads
+    ('comm_schedule_check.cpp', 'g++', ['-std=c++17'], ['']),
 ]
 
 
