@@ -466,7 +466,7 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
         """Not every read set is i.i.d. uniform: 1 GiB of (a) the uniform reads, (b) the same with 2 % of the reads replaced by poly-A /
         (AC)n reads, (c) a homopolymer, counted at k = 12 and k = 15 through AUTO, whole buffer resident in HBM (kernel time of
         begin + feed + finish, best of three).  Parity of exactly these inputs at exactly this size: tests/test_gpu_skew_full.py."""
-        n_reads = (1 << 30) // (L + 1)
+        n_reads = min((1 << 30) // (L + 1), args.reads)     # (1 GiB, or the whole resident buffer when that is smaller)
         n = n_reads * (L + 1)
         host = np.empty(n, dtype=np.uint8)
         ctx.synth_reads_device(2, 0, n_reads, L, dev_buf)

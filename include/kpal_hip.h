@@ -154,9 +154,10 @@ int kpal_count_last_plan(kpal_ctx *ctx, int *strategy, int *steps1, int *steps2)
  * out[0] entries of the per-workgroup hot-item tables in use at kernel ends, out[1] items that rode in a spill list,
  * out[2] items a spill list could not hold (counted on the spot), out[3] pieces finalised FRESH (k >= 13: table written, not
  * added to), out[4] FRESH pieces run again the classic way (a bypass list overflowed), out[5] pieces through a quad pipeline,
- * out[6] pieces through the chunked / round-1 pipelines, out[7] pieces halved (pool or offset limits).  n <= KPAL_COUNT_STATS
+ * out[6] pieces through the chunked / round-1 pipelines, out[7] pieces halved (pool or offset limits), out[8] quad pieces whose
+ * scatter ran as the REPEAT instantiation (hot rows in the sample: repeat lanes straight to the hot-item table).  n <= KPAL_COUNT_STATS
  * values are written.  Synchronises the context's stream. */
-#define KPAL_COUNT_STATS 8
+#define KPAL_COUNT_STATS 9
 int kpal_count_stats(kpal_ctx *ctx, uint64_t *out, int n);
 int kpal_count_table(kpal_ctx *ctx, void **dev_table, uint64_t *n_bins); /* device pointer of the int64 table (for the RCCL reduce) */
 

@@ -383,9 +383,9 @@ class Context(object):
 
     def count_stats(self):
         """Cumulative slow-path statistics of the quad pipelines since the context was created (kpal_count_stats)."""
-        out = (ctypes.c_uint64 * 8)()
-        _check(self._L.kpal_count_stats(self._h, out, 8))
-        names = ('hot_entries', 'spilled_items', 'unlisted_items', 'fresh_pieces', 'fresh_reruns', 'quad_pieces', 'chunked_pieces', 'split_pieces')
+        out = (ctypes.c_uint64 * 9)()
+        _check(self._L.kpal_count_stats(self._h, out, 9))
+        names = ('hot_entries', 'spilled_items', 'unlisted_items', 'fresh_pieces', 'fresh_reruns', 'quad_pieces', 'chunked_pieces', 'split_pieces', 'repeat_pieces')
         return dict(zip(names, (int(v) for v in out)))
 
     def count_table_view(self):

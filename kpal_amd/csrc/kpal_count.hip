@@ -1174,7 +1174,7 @@ KPAL_API int kpal_count_stats(kpal_ctx *ctx, uint64_t *out, int n)
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const uint64_t all[KPAL_COUNT_STATS] = {words[1], words[2], words[3], ctx->stat_fresh_pieces, ctx->stat_fresh_reruns, ctx->stat_quad_pieces,
-                                            ctx->stat_chunked_pieces, ctx->stat_split_pieces};
+                                            ctx->stat_chunked_pieces, ctx->stat_split_pieces, ctx->stat_repeat_pieces};
     for (int i = 0; i < n; ++i) out[i] = i < KPAL_COUNT_STATS ? all[i] : 0;
     return KPAL_OK;
 }

@@ -134,6 +134,7 @@ static int ctx_init(kpal_ctx *ctx, int device)
     if (const char *e = getenv("KPAL_QUAD_STEPS")) ctx->quad_steps_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_STEPS2")) ctx->quad_steps2_forced = atoi(e);
     if (const char *e = getenv("KPAL_QUAD_VERBOSE")) ctx->quad_verbose = atoi(e) != 0;
+    if (const char *e = getenv("KPAL_QUAD_REPEAT")) ctx->quad_repeat_forced = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("KPAL_HIST_PACKED")) ctx->quad_hist_unpacked = atoi(e) == 0;
     if (const char *e = getenv("KPAL_DIRECT_SEG")) {   // tests: tiny TableSink segments force the overflow fallback of the FRESH mode
         const long v = atol(e);

@@ -84,10 +84,12 @@ struct kpal_ctx {
     bool chunk_error_armed = false;
     int quad_steps_forced = 0, quad_steps2_forced = 0;   // KPAL_QUAD_STEPS / KPAL_QUAD_STEPS2 at context creation (tests, A/B): tile sizes of the quad scatters
     bool quad_verbose = false;               // KPAL_QUAD_VERBOSE
+    int quad_repeat_forced = -1;             // KPAL_QUAD_REPEAT=0 / 1: the scatter instantiation without / with the repeat lanes' shortcut (-1: by the sample)
+    bool sample_hot_rows = false;            // the last row-load sample showed hot rows (quad_choose_steps)
     // what the last piece of the last feed took (kpal_count_last_plan): strategy, wave-steps per wave and tile of level 1 / level 2
     int plan_strategy = 0, plan_steps1 = 0, plan_steps2 = 0;
     // kpal_count_stats: pieces by pipeline and the FRESH pieces / re-runs, since the context was created
-    uint64_t stat_fresh_pieces = 0, stat_fresh_reruns = 0, stat_quad_pieces = 0, stat_chunked_pieces = 0, stat_split_pieces = 0;
+    uint64_t stat_fresh_pieces = 0, stat_fresh_reruns = 0, stat_quad_pieces = 0, stat_chunked_pieces = 0, stat_split_pieces = 0, stat_repeat_pieces = 0;
     // tile sizes chosen from the sample of an earlier feed of this count (kpal_count_begin clears them): a file streamed in
     // many feeds is sampled once per 16 feeds, not once per feed (the sample costs a D2H copy + a host synchronisation)
     int cached_steps1 = 0, cached_steps2 = 0;

@@ -4,6 +4,7 @@
 
 #include "quad_kernels.hpp"
 
+
 // Expected number of items in the spill list of a workgroup in the steady state.  A row is a queue: Poisson(mu) items
 // arrive per round, `slots` leave with the record, the rest is carried to the next round.  The single-round overflow
 // E[max(X - slots, 0)] underestimates the backlog of a well-filled row (carried items arrive again: at 83 % fill of a
@@ -110,6 +111,7 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
         // hot rows fill the spill list first (their excess is carried every round before it is counted directly): the
         // ordinary rows then get a quarter of the list (k = 13, 2 % low-complexity reads: level 1 0.55 instead of 2.9 ms)
         if (all > 0.0 && hot > 0.003 * all) budget = kQuadBacklogMax / 4;
+        ctx->sample_hot_rows = all > 0.0 && hot > 0.003 * all;   // (the scatter then takes its REPEAT instantiation)
     }
     per_step.resize((size_t)buckets - 32);
     std::vector<double> mu(per_step.size());
@@ -159,9 +161,12 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         steps = ctx->cached_steps1;
         ++ctx->cached_uses;
     }
+    bool repeat = true;                          // (forced tile sizes: no sample -- the instantiation that knows repeats)
+    if (steps && ctx->cached_steps1 == steps && !ctx->quad_steps_forced) repeat = ctx->sample_hot_rows;
     if (!steps) {
         const int rc = quad_choose_steps(ctx, s, load, buckets, slots, waves, candidates, sizeof(candidates) / sizeof(candidates[0]), &steps);
         if (rc != KPAL_OK) return rc;
+        repeat = ctx->sample_hot_rows;
         ctx->cached_steps1 = steps;
         ctx->cached_uses = 0;
         ctx->cached_bytes = feed_bytes;
@@ -195,9 +200,20 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // (input chunks are requested S steps ahead; at k <= 11 with eight steps that ring costs the registers the kernel does not have --
     // 12 spilled, and a kernel that uses scratch memory at all ran ~10 % slower in same-box comparisons -- so four steps ahead there;
     // k = 12 fits its 128 registers either way and a four-step ring changed nothing: 7.44 vs 7.40 ms)
+    // REPEAT: the instantiation that sends the repeat lanes of low-complexity sequence straight to the hot-item table (quad_kernels.hpp);
+    // taken when the sample shows hot rows (KPAL_QUAD_REPEAT=0 / 1 forces one: A/B, tests).  Its call site costs registers: a
+    // four-step input ring in the 8-step tile.
+    if (ctx->quad_repeat_forced >= 0) repeat = ctx->quad_repeat_forced != 0;
+    if (repeat) ++ctx->stat_repeat_pieces;
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
-    LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 ? 4 : S)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, nrounds, \
-           error, table)
+    do {                                                                                                                     \
+        if (repeat)                                                                                                          \
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 ? 4 : S), TableOnly, true>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, \
+                   nrounds, error, table);                                                                                   \
+        else                                                                                                                 \
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 && K != 12 ? 4 : S), TableOnly, false>), dim3(G), dim3(1024), s, tpb, pool,    \
+                   (uint32_t)tpb, nrounds, error, table);                                                                    \
+    } while (0)
     DISPATCH_K_8_12(ctx->k, {
         switch (steps) {
         case 8: KPAL_QUAD_LAUNCH(8); break;

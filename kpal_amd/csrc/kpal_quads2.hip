@@ -46,6 +46,8 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
         if (rc != KPAL_OK) return rc;
         if (!steps1) steps1 = chosen;
     }
+    const bool repeat1 = ctx->quad_repeat_forced >= 0 ? ctx->quad_repeat_forced != 0 : ctx->sample_hot_rows;   // (the last sample's verdict)
+    if (repeat1 && steps1 != 7) ++ctx->stat_repeat_pieces;
     const uint64_t tile_steps = 16ull * steps1;
     const uint64_t tiles1 = (total_steps + tile_steps - 1) / tile_steps;
     const uint32_t G1 = (uint32_t)std::min<uint64_t>((uint64_t)std::min(ctx->num_cu, 256), tiles1);
@@ -130,15 +132,20 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
 #define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
     LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
            (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)cap2, nrounds2, error, table2)
+    // (REPEAT: the level-1 instantiation with the repeat lanes' shortcut, when the sample shows hot rows -- kpal_quads.hip; the
+        // seven-step tile has no such instantiation: at 128 registers the call site cost it spilled ones)
+#define KPAL_QUAD1_LAUNCH(S, D)                                                                                                        \
+    do {                                                                                                                               \
+        if (repeat1 && S != 7)                                                                                                         \
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, D, TableSink, (S != 7)>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table); \
+        else                                                                                                                           \
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, D, TableSink, false>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);    \
+    } while (0)
     DISPATCH_K_13_16(ctx->k, {
-        if (steps1 == 8)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 8, KPAL_L1_DEPTH8, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
-        else if (steps1 == 7)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 7, 7, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
-        else if (steps1 == 6)
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 6, 6, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
-        else
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, 3, 3, TableSink>), dim3(G1), dim3(1024), s, tpb1, pool1, (uint32_t)cap1, nrounds1, error, table);
+        if (steps1 == 8) KPAL_QUAD1_LAUNCH(8, KPAL_L1_DEPTH8);
+        else if (steps1 == 7) KPAL_QUAD1_LAUNCH(7, 7);
+        else if (steps1 == 6) KPAL_QUAD1_LAUNCH(6, 6);
+        else KPAL_QUAD1_LAUNCH(3, 3);
         switch (steps2) {
         case 8: KPAL_QUAD2_LAUNCH(8); break;
         case 7: KPAL_QUAD2_LAUNCH(7); break;

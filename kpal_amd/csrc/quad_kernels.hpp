@@ -567,7 +567,7 @@ __device__ __forceinline__ uint4 fetch_wave_step(const Span &s, uint64_t step, u
 // round) + one per-thread 32-bit offset fixed for the whole kernel.
 // pool word address of record (row, g, round): ((row * G + g) * rounds_cap + round) * kSlots
 // (k = 12, kPairRows: (((row / 2) * G + g) * rounds_cap + round) * 32 + (row % 2) * 16).
-template <int K, int WAVES, int STEPS, int DEPTH, typename SINK = TableOnly>
+template <int K, int WAVES, int STEPS, int DEPTH, typename SINK = TableOnly, bool REPEAT = false>
 __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64_t tiles_per_block, uint32_t *__restrict__ pool,
                                                                   uint32_t rounds_cap, uint32_t *__restrict__ nrounds,
                                                                   uint32_t *__restrict__ error, SINK sink_arg)
@@ -706,21 +706,24 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                 const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, (uint32_t)lane, row[q], item[q]);
             }
-#if !defined(KPAL_QUAD_NO_REPEAT)   // A/B builds
-            // REPEAT LANES.  Inside a homopolymer or a repeat of period 2 or 4 (poly-A tails, (AC)n, (ACGT)n ...) the four items of a
-            // lane are one and the same: all such lanes of the reads of a tile want the same row, round after round -- that row
-            // overflows, its items ride in the spill list, fail again as carried items and end in the hot-item table one by one
-            // (2 % of such reads cost the kernel 3.4 x).  They go there at once: one ballot-counted update per distinct item and
-            // wave, each lane standing for four occurrences, and nothing of them enters the rows.
-            {
-                const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
-                                 row[2] == row[0] && row[3] == row[0];
-                if (__builtin_expect(__any(rep), 0)) {   // wave-uniform
-                    quad_items_direct<K, 1, SINK2, 4u>(rep, row[0], item[0], table, hot);
-                    if (rep) item[0] = item[1] = item[2] = item[3] = 0u;
+            // REPEAT LANES (REPEAT: the instantiation the host launches when the sample of the feed shows hot rows -- on uniform reads
+            // the test below and the registers of its call cost the 8-step tile of k = 12 1.4 %, same-box A/B).  Inside a homopolymer
+            // or a repeat of period 2 or 4 (poly-A tails, (AC)n, (ACGT)n ...) the four items of a lane are one and the same: all such
+            // lanes of the reads of a tile want the same row, round after round -- that row overflows, its items ride in the spill
+            // list, fail again as carried items and end in the hot-item table one by one (2 % of such reads cost the kernel 3.4 x).
+            // They go there at once: one ballot-counted update per distinct item and wave, each lane standing for four occurrences,
+            // and nothing of them enters the rows.  (One compare per step on the fast path: two equal neighbours are the necessary
+            // condition -- 2^-23 per lane by chance.)
+            if constexpr (REPEAT) {
+                if (__builtin_expect(__any(item[1] == item[0]), 0)) {   // wave-uniform
+                    const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
+                                     row[2] == row[0] && row[3] == row[0];
+                    if (__any(rep)) {
+                        quad_items_direct<K, 1, SINK2, 4u>(rep, row[0], item[0], table, hot);
+                        if (rep) item[0] = item[1] = item[2] = item[3] = 0u;
+                    }
                 }
             }
-#endif
 #if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
             asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
 #else

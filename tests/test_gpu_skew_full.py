@@ -107,6 +107,8 @@ def test_full_size_skewed_k12(cases):
         print('k=12 plans and slow-path statistics (two counts per case):', seen)
         assert seen['uniform'][0][0] == 'partition_quads' and seen['uniform'][0][1] == 8      # the benchmarked tile
         assert seen['uniform'][1]['spilled_items'] > 0                                          # Poisson tails ride in the spill list
+        assert seen['uniform'][1]['repeat_pieces'] == 0 and seen['homopolymer'][1]['repeat_pieces'] == 2   # the scatter instantiation follows the sample
+        assert seen['low_complexity_2pct'][1]['repeat_pieces'] == 2
         for name in ('homopolymer', 'low_complexity_2pct'):
             assert seen[name][0][0] == 'partition_quads', seen[name]
             assert seen[name][1]['hot_entries'] > 0, seen[name]                                # over-full rows: counted in the hot-item tables
