@@ -112,7 +112,29 @@ def test_full_size_skewed_k12(cases):
         for name in ('homopolymer', 'low_complexity_2pct'):
             assert seen[name][0][0] == 'partition_quads', seen[name]
             assert seen[name][1]['hot_entries'] > 0, seen[name]                                # over-full rows: counted in the hot-item tables
-        assert seen['homopolymer'][1]['unlisted_items'] > 0                                     # ... and more items than the spill list holds
+        # the repeat lanes of the homopolymer never reach the rows: nothing spills (round 4: 33 M items in the lists, 503 M beyond them)
+        assert seen['homopolymer'][1]['spilled_items'] == 0 and seen['homopolymer'][1]['unlisted_items'] == 0
+        # ... and the chain they took before -- row, spill list, carried, hot-item table / beyond the list -- still counts right:
+        # the instantiation without the shortcut (KPAL_QUAD_REPEAT=0) on the same 1 GiB
+        os.environ['KPAL_QUAD_REPEAT'] = '0'
+        try:
+            plain = _native.Context(0)
+        finally:
+            os.environ.pop('KPAL_QUAD_REPEAT', None)
+        try:
+            for name in ('homopolymer', 'low_complexity_2pct'):
+                t = cases[name]
+                before = plain.count_stats()
+                plain.count_begin(k)
+                plain.count_feed_device(t.data_ptr(), t.numel())
+                got = plain.count_finish()
+                after = plain.count_stats()
+                np.testing.assert_array_equal(got, oracle.count_flat(t.cpu().numpy(), k, threads=threads, mode='private'), err_msg=name + ' without the repeat shortcut')
+                assert after['repeat_pieces'] == before['repeat_pieces'] and after['spilled_items'] > before['spilled_items'], name
+                if name == 'homopolymer':
+                    assert after['unlisted_items'] > before['unlisted_items']      # more items than the spill list holds
+        finally:
+            plain.close()
         assert seen['adapter_prefixed'][0][0] in ('partition_chunked', 'partition_quads')       # (AUTO: a spread hot excess goes to the chunked pipeline)
     finally:
         ctx.close()

@@ -10,7 +10,7 @@
 #   bench_k15_*                        BASELINE config 4 as its own command, + kernel stats
 #   matrix_k12_P64_*                   BASELINE config 5 (multiset prod, euclidean) as its own command, + kernel stats
 set -u
-ROUND=${1:-r4}
+ROUND=${1:-r5}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT" "$ROOT/profiles/$ROUND"
@@ -96,8 +96,12 @@ python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_vec" "$OUT/pmc_write_vec" 0
 cd "$ROOT"
 python3 tools/clibench.py --gb 8 > "$OUT/clibench.json" 2> "$OUT/clibench.err"
 python3 tools/hostbench.py --reads 20000000 2>&1 | head -8 > "$OUT/hostbench.log"
+python3 tools/clibench.py --by-record > "$OUT/clibench_by_record.json" 2> "$OUT/clibench_by_record.err"
 # ---- skewed inputs
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
+python3 tools/skewbench.py --k 15 > "$OUT/skewbench_k15.log" 2>&1
+# ---- the hex pipeline (k = 12, six k-mers per three-byte item) next to the quads, same box
+for st in partition_quads partition_hex; do python3 "$B" --steps 10 --warmup 2 --no-extra --no-cpu --strategy $st > "$OUT/bench_k12_$st.json" 2> "$OUT/bench_k12_$st.err"; done
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -delete
 ls -la "$OUT"; for f in "$OUT"/bench_k1[25]_n1.json "$OUT"/matrix*_bench.json; do echo "== $f"; head -c 1200 "$f"; echo; done
