@@ -714,6 +714,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             // They go there at once: one ballot-counted update per distinct item and wave, each lane standing for four occurrences,
             // and nothing of them enters the rows.  (One compare per step on the fast path: two equal neighbours are the necessary
             // condition -- 2^-23 per lane by chance.)
+            bool place = true;                   // wave-uniform
             if constexpr (REPEAT) {
                 if (__builtin_expect(__any(item[1] == item[0]), 0)) {   // wave-uniform
                     const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
@@ -721,13 +722,17 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
                     if (__any(rep)) {
                         quad_items_direct<K, 1, SINK2, 4u>(rep, row[0], item[0], table, hot);
                         if (rep) item[0] = item[1] = item[2] = item[3] = 0u;
+                        // (a step of repeat lanes only -- a homopolymer, the inside of a long repeat -- has nothing to place: the slot
+                        // atomics of its null items would add 0, but sixty-four lanes on ONE row counter still serialise in the LDS;
+                        // a homopolymer spent half its scatter there)
+                        place = !__all(rep);
                     }
                 }
             }
 #if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
             asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
 #else
-            quad_place<K, false, 1, 4, SINK2>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
+            if (place) quad_place<K, false, 1, 4, SINK2>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
 #endif
         }
         have_rec = false;
