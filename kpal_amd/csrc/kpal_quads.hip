@@ -70,9 +70,9 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
     const uint64_t want = std::max<uint64_t>(1, total_steps / (64ull * 8 * sample_steps));   // ~1/64 of the input
     const uint32_t groups = (uint32_t)std::min<uint64_t>(want, 1024);
     const uint64_t stride = std::max<uint64_t>(8 * sample_steps, total_steps / groups);
-    HIPCHK(hipMemsetAsync(load, 0, (size_t)(buckets + extra) * sizeof(uint32_t), ctx->stream));
+    HIPCHK(hipMemsetAsync(load, 0, (size_t)(buckets + extra + 1) * sizeof(uint32_t), ctx->stream));   // (+ 1: the items of repeat lanes)
     DISPATCH_K_8_16(ctx->k, LAUNCH(ctx, "quad_sample", (quad_sample_kernel<K>), dim3(groups), dim3(512), s, stride, sample_steps, load));
-    std::vector<uint32_t> h((size_t)(buckets + extra));
+    std::vector<uint32_t> h((size_t)(buckets + extra + 1));
     HIPCHK(hipMemcpyAsync(h.data(), load, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const double sampled_steps = (double)std::min<uint64_t>((uint64_t)groups * 8 * sample_steps, total_steps);
@@ -111,7 +111,10 @@ int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets,
         // hot rows fill the spill list first (their excess is carried every round before it is counted directly): the
         // ordinary rows then get a quarter of the list (k = 13, 2 % low-complexity reads: level 1 0.55 instead of 2.9 ms)
         if (all > 0.0 && hot > 0.003 * all) budget = kQuadBacklogMax / 4;
-        ctx->sample_hot_rows = all > 0.0 && hot > 0.003 * all;   // (the scatter then takes its REPEAT instantiation)
+        // the scatter takes its REPEAT instantiation when the sample holds repeat lanes (their items are not in the row loads: the
+        // scatter sends them past the rows) or hot rows of another kind
+        const double repeats = h[(size_t)(buckets + extra)] / sampled_steps;
+        ctx->sample_hot_rows = (all > 0.0 && hot > 0.003 * all) || repeats > 0.001 * (all + repeats);
     }
     per_step.resize((size_t)buckets - 32);
     std::vector<double> mu(per_step.size());

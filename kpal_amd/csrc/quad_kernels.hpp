@@ -505,10 +505,13 @@ template <int K>
 __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t stride_steps, uint32_t steps, uint32_t *__restrict__ load)
 {
     using C = QuadCfg<K>;
-    // two-level path: load[kBuckets ..] also receives the loads of the 512 FINE rows of level 2 (over all coarse buckets)
+    // two-level path: load[kBuckets ..] also receives the loads of the 512 FINE rows of level 2 (over all coarse buckets);
+    // the last word counts the items of REPEAT LANES (quad_scatter_kernel: four identical items -- they never reach a row there,
+    // so they do not count towards a row's load here either; their number tells the host to launch the REPEAT instantiation)
     constexpr int NFINE = C::kTwoLevel ? 512 : 0;
-    __shared__ uint32_t cnt[C::kBuckets + NFINE];
-    for (int i = threadIdx.x; i < C::kBuckets + NFINE; i += blockDim.x) cnt[i] = 0;
+    constexpr int NCNT = C::kBuckets + NFINE + 1;
+    __shared__ uint32_t cnt[NCNT];
+    for (int i = threadIdx.x; i < NCNT; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const uint64_t total_steps = (s.nchunks + 63) / 64;
@@ -519,21 +522,30 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
             uint64_t window;
             uint32_t mask;
             part_step<K>(s, first + st, carry, window, mask);
+            uint32_t row[4], item[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
-                uint32_t row, item;
-                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, threadIdx.x & 63u, row, item);
-                atomicAdd(&cnt[row], (item & 15u) ? 1u : 0u);
+                quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, threadIdx.x & 63u, row[q], item[q]);
+            }
+            const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
+                             row[2] == row[0] && row[3] == row[0];
+            if (rep) {
+                atomicAdd(&cnt[NCNT - 1], 4u);
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                atomicAdd(&cnt[row[q]], (item[q] & 15u) ? 1u : 0u);
                 if constexpr (C::kTwoLevel) {   // the row quad2_scatter_kernel gives the item
-                    const uint32_t fine_row = ((item >> 17) & 511u) ^ QuadCfg<11>::smask(((item >> 4) & 8191u) >> 9);
-                    atomicAdd(&cnt[C::kBuckets + fine_row], (item & 15u) ? 1u : 0u);
+                    const uint32_t fine_row = ((item[q] >> 17) & 511u) ^ QuadCfg<11>::smask(((item[q] >> 4) & 8191u) >> 9);
+                    atomicAdd(&cnt[C::kBuckets + fine_row], (item[q] & 15u) ? 1u : 0u);
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C::kBuckets + NFINE; i += blockDim.x)
+    for (int i = threadIdx.x; i < NCNT; i += blockDim.x)
         if (cnt[i]) atomicAdd(&load[i], cnt[i]);
 }
 
