@@ -241,10 +241,12 @@ __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
 }
 
-// mult: every active lane stands for `mult` occurrences of its item (the repeat lanes of quad_scatter_kernel: 4).
-template <int K, int LEVEL = 1, typename SINK = TableOnly, uint32_t mult = 1u>
-__device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
+template <int K, int LEVEL = 1, typename SINK = TableOnly, bool COUNTED = false>
+__device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0,
+                                                       uint32_t cnt = 1u)
 {
+    // COUNTED: lane l stands for cnt (0 .. 4) occurrences of its item (the repeat lanes of quad_scatter_kernel)
+    const uint32_t mult = COUNTED ? cnt : 1u;
     const int lane = threadIdx.x & 63;
     auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
 #pragma unroll
@@ -257,7 +259,12 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
         const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(row, src);
         const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(item, src);
         const unsigned long long same = __builtin_amdgcn_ballot_w64(active && row == hot_row && item == hot_item) & todo;
-        const uint32_t n = (uint32_t)__popcll(same) * mult;
+        uint32_t n = (uint32_t)__popcll(same);
+        if constexpr (COUNTED) {   // the sum of the lanes' counts: one ballot per value
+            n = 0;
+#pragma unroll
+            for (uint32_t v = 1; v <= 4u; ++v) n += v * (uint32_t)__popcll(same & __builtin_amdgcn_ballot_w64(cnt == v));
+        }
         const unsigned long long key = ((unsigned long long)hot_row << 32) | hot_item;
         const uint32_t slot = (quad_hot_hash(hot_row, hot_item) + (uint32_t)(lane & 3)) & (uint32_t)(kQuadHotEntries - 1);
         const unsigned long long seen = lane < 4 ? hot[slot].key : ~0ull;
@@ -297,10 +304,17 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
 // (rare path, called from the unrolled placement loop: kept out of line there; the scatter kernels' epilogues inline the body -- an
 // out-of-line call next to everything that is live there cost spilled registers, and kernels that use scratch memory at all ran
 // 8 % slower in same-box comparisons, wherever the spill sat)
-template <int K, int LEVEL = 1, typename SINK = TableOnly, uint32_t MULT = 1u>
+template <int K, int LEVEL = 1, typename SINK = TableOnly>
 __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
 {
-    quad_items_direct_body<K, LEVEL, SINK, MULT>(active, row, item, table, hot, coarse);
+    quad_items_direct_body<K, LEVEL, SINK>(active, row, item, table, hot, coarse);
+}
+
+// (the repeat lanes: lane l holds its item cnt times)
+template <int K, typename SINK>
+__device__ __attribute__((noinline)) void quad_items_direct_counted(uint32_t cnt, uint32_t row, uint32_t item, const SINK table, QuadHot *hot)
+{
+    quad_items_direct_body<K, 1, SINK, true>(cnt != 0u, row, item, table, hot, 0u, cnt);
 }
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
@@ -723,21 +737,32 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
             // or a repeat of period 2 or 4 (poly-A tails, (AC)n, (ACGT)n ...) the four items of a lane are one and the same: all such
             // lanes of the reads of a tile want the same row, round after round -- that row overflows, its items ride in the spill
             // list, fail again as carried items and end in the hot-item table one by one (2 % of such reads cost the kernel 3.4 x).
-            // They go there at once: one ballot-counted update per distinct item and wave, each lane standing for four occurrences,
-            // and nothing of them enters the rows.  (One compare per step on the fast path: two equal neighbours are the necessary
-            // condition -- 2^-23 per lane by chance.)
+            // They go there at once: the item of the first lane that holds two equal neighbours is the wave's repeat item, EVERY
+            // occurrence of it in the wave -- also the one to three in the lanes at the ends of the read, which alone kept the row
+            // over-full -- is counted by one update of the hot-item table, and none of them enters the rows.
             bool place = true;                   // wave-uniform
             if constexpr (REPEAT) {
-                if (__builtin_expect(__any(item[1] == item[0]), 0)) {   // wave-uniform
-                    const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
-                                     row[2] == row[0] && row[3] == row[0];
-                    if (__any(rep)) {
-                        quad_items_direct<K, 1, SINK2, 4u>(rep, row[0], item[0], table, hot);
-                        if (rep) item[0] = item[1] = item[2] = item[3] = 0u;
-                        // (a step of repeat lanes only -- a homopolymer, the inside of a long repeat -- has nothing to place: the slot
-                        // atomics of its null items would add 0, but sixty-four lanes on ONE row counter still serialise in the LDS;
-                        // a homopolymer spent half its scatter there)
-                        place = !__all(rep);
+                // (two compares per step on the fast path: equal neighbours are the necessary condition -- 2^-23 per lane by chance)
+                if (__builtin_expect(__any(item[1] == item[0] || item[3] == item[2]), 0)) {   // wave-uniform
+                    const bool c01 = item[1] == item[0] && row[1] == row[0] && (item[1] & 15u) == 15u;
+                    const bool c23 = item[3] == item[2] && row[3] == row[2] && (item[3] & 15u) == 15u;
+                    const unsigned long long cand = __builtin_amdgcn_ballot_w64(c01 || c23);
+                    if (cand) {
+                        // the wave's repeat item: that of the first such lane (a second low-complexity read in the same KiB takes the rows)
+                        const int src = __ffsll((long long)cand) - 1;
+                        const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(c01 ? item[1] : item[3], src);
+                        const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(c01 ? row[1] : row[3], src);
+                        uint32_t cnt = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool m = item[q] == hot_item && row[q] == hot_row;
+                            cnt += m ? 1u : 0u;
+                            item[q] = m ? 0u : item[q];
+                        }
+                        quad_items_direct_counted<K, SINK2>(cnt, hot_row, hot_item, table, hot);
+                        // (a step that held nothing else -- a homopolymer, the inside of a long repeat -- has nothing to place: the slot
+                        // atomics of null items add 0, but sixty-four lanes on ONE row counter still serialise in the LDS)
+                        place = __any((item[0] | item[1] | item[2] | item[3]) != 0u);
                     }
                 }
             }
