@@ -174,6 +174,10 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         ctx->cached_uses = 0;
         ctx->cached_bytes = feed_bytes;
     }
+    if (ctx->quad_repeat_forced >= 0) repeat = ctx->quad_repeat_forced != 0;
+    // (k = 12 has no REPEAT instantiation of the 7-step tile -- it would spill registers: the 6-step tile, unless the size is forced)
+    if (repeat && ctx->k == 12 && steps == 7 && !ctx->quad_steps_forced) steps = 6;
+    if (repeat && !(ctx->k == 12 && steps == 7)) ++ctx->stat_repeat_pieces;
     ctx->plan_strategy = KPAL_STRATEGY_PARTITION_QUADS;
     ctx->plan_steps1 = steps;
     ctx->plan_steps2 = 0;
@@ -206,8 +210,6 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // REPEAT: the instantiation that sends the repeat lanes of low-complexity sequence straight to the hot-item table (quad_kernels.hpp);
     // taken when the sample shows hot rows (KPAL_QUAD_REPEAT=0 / 1 forces one: A/B, tests).  Its call site costs registers: a
     // four-step input ring in the 8-step tile (and no such instantiation of the 7-step tile at k = 12: it would spill).
-    if (ctx->quad_repeat_forced >= 0) repeat = ctx->quad_repeat_forced != 0;
-    if (repeat) ++ctx->stat_repeat_pieces;
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
     do {                                                                                                                     \
         if (repeat)                                                                                                          \

@@ -542,11 +542,23 @@ __global__ __launch_bounds__(512) void quad_sample_kernel(Span s, uint64_t strid
                 const uint64_t x = (window >> (24 - 8 * q)) & C::kXMask;
                 quad_split<K>(x, (mask >> (12 - 4 * q)) & 15u, threadIdx.x & 63u, row[q], item[q]);
             }
-            const bool rep = (item[0] & 15u) == 15u && item[1] == item[0] && item[2] == item[0] && item[3] == item[0] && row[1] == row[0] &&
-                             row[2] == row[0] && row[3] == row[0];
-            if (rep) {
-                atomicAdd(&cnt[NCNT - 1], 4u);
-                continue;
+            {   // the wave's repeat item, as quad_scatter_kernel<.., REPEAT> finds it: its occurrences never reach a row
+                const bool c01 = item[1] == item[0] && row[1] == row[0] && (item[1] & 15u) == 15u;
+                const bool c23 = item[3] == item[2] && row[3] == row[2] && (item[3] & 15u) == 15u;
+                const unsigned long long cand = __builtin_amdgcn_ballot_w64(c01 || c23);
+                if (cand) {
+                    const int src = __ffsll((long long)cand) - 1;
+                    const uint32_t hot_item = (uint32_t)__builtin_amdgcn_readlane(c01 ? item[1] : item[3], src);
+                    const uint32_t hot_row = (uint32_t)__builtin_amdgcn_readlane(c01 ? row[1] : row[3], src);
+                    uint32_t n = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool m = item[q] == hot_item && row[q] == hot_row;
+                        n += m ? 1u : 0u;
+                        item[q] = m ? 0u : item[q];
+                    }
+                    if (n) atomicAdd(&cnt[NCNT - 1], n);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
