@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 FP64_VALU_PEAK_T = 39.3    # fp64 vector lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (78.6 TFLOP/s with FMA = half the guide's 157.3 TF fp32 vector rate)
 FP64_MFMA_PEAK_T = 78.6    # fp64 matrix TFLOP/s (v_mfma_f64_16x16x4_f64: 2048 flop per 64 SIMD-cycles x 1024 SIMDs x 2.4 GHz)
-PROFILE_ROUND = 'r4'
+PROFILE_ROUND = 'r5'
 PROFILE_DIR = os.path.join(ROOT, 'profiles', PROFILE_ROUND)
 
 
@@ -81,12 +81,12 @@ def pmc_traffic(kernels, dom, k, input_bytes_per_step):
     fname = 'pmc_hbm_traffic%s.json' % ('' if k == 12 else '_k%d' % k)
     prof = _load_profile(fname)
     if prof is None:
-        info['traffic_source'] = 'no committed counter profile profiles/r4/%s' % fname
+        info['traffic_source'] = 'no committed counter profile profiles/%s/%s' % (PROFILE_ROUND, fname)
         return info
     info['traffic_profile_src_sha'] = prof.get('src_sha')
     here = source_sha()
     if prof.get('src_sha') != here:
-        info['traffic_source'] = 'profiles/r4/%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (fname, prof.get('src_sha'), here)
+        info['traffic_source'] = 'profiles/%s/%s was taken from other kernel sources (src_sha %s, now %s): not reported' % (PROFILE_ROUND, fname, prof.get('src_sha'), here)
         return info
     scale = input_bytes_per_step / prof['input_bytes_per_launch_avg']
     per_kernel, total = {}, 0.0
@@ -112,8 +112,8 @@ def pmc_traffic(kernels, dom, k, input_bytes_per_step):
         info['traffic'] = per_kernel[dom] / max(launches_per_step, 1)
     info['traffic_step'] = total
     info['traffic_by_kernel_per_step'] = per_kernel
-    info['traffic_source'] = ('profiles/r4/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, '
-                              'scaled by input bytes)' % fname)
+    info['traffic_source'] = ('profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the same kernel sources, '
+                              'scaled by input bytes)' % (PROFILE_ROUND, fname))
     return info
 
 
@@ -130,7 +130,7 @@ def pmc_limiter(dom, k):
     # over the 256 CUs (tools/profile_numbers.py uses the same normalisation); wave-level shares are taken against SQ_WAVE_CYCLES
     cyc = row['SQ_BUSY_CYCLES'] / 32.0
     waves = row.get('SQ_WAVE_CYCLES') or 0.0
-    out = {'source': 'profiles/r4/pmc_lds_quad%s.json' % ('' if k == 12 else '_k%d' % k)}
+    out = {'source': 'profiles/%s/pmc_lds_quad%s.json' % (PROFILE_ROUND, '' if k == 12 else '_k%d' % k)}
     if waves:
         out['valu_issue_share_of_wave_cycles'] = row.get('SQ_ACTIVE_INST_VALU', 0.0) / waves
         out['waiting_share_of_wave_cycles'] = row.get('SQ_WAIT_ANY', 0.0) / waves
@@ -964,7 +964,8 @@ def multi_gpu_worker(args):
                 ctx.comm_reduce_scatter_table(balance=True)
                 ctx.sync()
             elif reducer is None:
-                # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step
+                # ONE ncclReduce(int64, sum) to rank 0 + balance there, queued by the library: no host synchronisation in the step at
+                # k <= 12 (k >= 13: the first feed of a count reads one word back, include/kpal_hip.h: kpal_count_feed_device)
                 ctx.comm_reduce_table(0, balance=True, pipelined=pipelined)
                 if not pipelined:
                     ctx.sync()

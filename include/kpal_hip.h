@@ -94,9 +94,12 @@ int kpal_count_feed(kpal_ctx *ctx, const uint8_t *host_buf, size_t nbytes);     
 int kpal_host_alloc(kpal_ctx *ctx, size_t nbytes, void **host_out);
 int kpal_host_free(kpal_ctx *ctx, void *host);
 int kpal_count_feed_pinned(kpal_ctx *ctx, const uint8_t *pinned_buf, size_t nbytes);   /* klib.py:154-168, as kpal_count_feed */
-int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);     /* same, input already in HBM; asynchronous and stream-ordered: work queued on
-                                                                                     * the context afterwards (kpal_memcpy_*, kpal_synth_reads_device, the next feed) may
-                                                                                     * reuse dev_buf; anything outside the context's stream waits for kpal_sync first */
+/* The same with the input already in HBM.  Stream-ordered: work queued on the context afterwards (kpal_memcpy_*,
+ * kpal_synth_reads_device, the next feed) may reuse dev_buf; anything outside the context's stream waits for kpal_sync first.
+ * The call does not wait for the GPU, with one exception: the FIRST whole-buffer feed of a k >= 13 count (FRESH mode of the
+ * two-level quad pipeline) reads one word back before it returns -- whether a bypass list overflowed, in which case the piece is
+ * counted again the classic way from the same buffer -- so that the buffer is the caller's again when the call is back. */
+int kpal_count_feed_device(kpal_ctx *ctx, const void *dev_buf, size_t nbytes);
 /* FASTA text of whole records (Profile.from_fasta, klib.py:97-112; tokenising the reference
  * delegates to Bio.SeqIO.parse, klib.py:111): header lines dropped, the lines of a record joined
  * with all ASCII whitespace removed, records separated; anything before the first header is

@@ -272,6 +272,7 @@ class Context(object):
 
     def close(self):
         if getattr(self, '_h', None):
+            self._gather_buffer = None             # (klib: the page-locked gather buffer of from_sequences -- freed with the context)
             self._L.kpal_ctx_destroy(self._h)      # (also releases what host_alloc handed out: views of it dangle from here on)
             self._h = None
 

@@ -173,18 +173,16 @@ def _join_block(block):
         return b'\n'.join(_encode(s) for s in block)
 
 
-_gather_buffers = {}      # Context -> (address, uint8 view): one page-locked buffer per context, kept for the process
-
-
 def _gather_feed(ctx, sequences):
     """Feed ``sequences`` to the running count through the C gatherer: the items of a list are copied (each followed by the
     separator ``\\n``) into a page-locked buffer by several threads and handed to ``kpal_count_feed_pinned`` buffer by
     buffer.  A sequence is never split over two feeds (windows do not span feeds); one that does not fit the buffer goes
     through ``kpal_count_feed`` on its own; items the gatherer does not know (``str`` with characters beyond latin-1,
     ``memoryview`` ...) are encoded here, one at a time."""
-    if ctx not in _gather_buffers:
-        _gather_buffers[ctx] = ctx.host_alloc(_GATHER_BYTES)
-    address, view = _gather_buffers[ctx]
+    # one page-locked buffer per context, kept ON the context: it goes when the context is closed (kpal_ctx_destroy frees it)
+    if getattr(ctx, '_gather_buffer', None) is None:
+        ctx._gather_buffer = ctx.host_alloc(_GATHER_BYTES)
+    address, view = ctx._gather_buffer
     cap = view.size
     fill = 0
     it = None if isinstance(sequences, (list, tuple)) else iter(sequences)

@@ -620,7 +620,7 @@ def test_command_line_surface_without_gpu(tmp_path, monkeypatch):
 
 
 def test_bench_traffic_comes_from_the_committed_profiles():
-    """bench.py reports roofline.traffic from profiles/r4/pmc_hbm_traffic*.json only while those were taken on the kernel sources
+    """bench.py reports roofline.traffic from profiles/<round>/pmc_hbm_traffic*.json only while those were taken on the kernel sources
     it runs (src_sha); bytes that follow the input are scaled by the input, bytes that follow the 4^k table are not, and every
     kernel of the step -- the balancing finalisation included -- is found in the profile."""
     import bench

@@ -218,6 +218,51 @@ def test_from_fasta_by_record_file(tmp_path, monkeypatch):
             ctx2.close()
 
 
+def test_fasta_records_c_abi(ctx, tmp_path):
+    """kpal_fasta_records_* through the binding: the index (header offsets into the text, record starts in the flattened stream),
+    batches of any size at any record (also starting in the middle of a 16-byte chunk of the flattened text), errors, and
+    two scans interleaved on one context (the second invalidates the first: the generator says so instead of counting wrongly)."""
+    from kpal_amd import klib
+    text = b'junk\n>a one\nACGTAC\nGT\n>\n\n>c\nTTGACCA\n>d x y\nG\n>e\n' + b'ACGTTGCA' * 300 + b'\n>f\nCC\n'
+    n, nf = ctx.fasta_records_begin(text)
+    hdr, starts = ctx.fasta_records_index()
+    seqs = [s for _, s in seqio_records(text.decode())]
+    assert n == len(seqs) == 6 and nf == sum(len(s) + 1 for s in seqs)
+    assert [text[h:h + 2] for h in hdr.tolist()] == [b'>a', b'>\n', b'>c', b'>d', b'>e', b'>f']
+    assert starts.tolist() == [0] + list(np.cumsum([len(s) + 1 for s in seqs]))
+    for k in (1, 2, 5):
+        whole = ctx.fasta_records_count(k, 0, n)
+        for r, seq in enumerate(seqs):
+            np.testing.assert_array_equal(whole[r], oracle.from_sequences([seq], k), err_msg='record %d k=%d' % (r, k))
+        for first in range(n):
+            for cnt in range(1, n - first + 1):
+                np.testing.assert_array_equal(ctx.fasta_records_count(k, first, cnt), whole[first:first + cnt])
+    with pytest.raises(ValueError):
+        ctx.fasta_records_count(3, 4, 3)                    # beyond the last record
+    assert ctx.fasta_records_begin(b'no header here\nACGT\n') == (0, 0)
+    assert ctx.fasta_records_index()[0].size == 0           # nothing indexed
+    with pytest.raises(RuntimeError):
+        ctx.fasta_records_file_next()                       # no file open
+    # interleaved generators on the one default context
+    path = tmp_path / 'two.fa'
+    path.write_bytes(b''.join(b'>r%d\nACGTACGT\n' % i for i in range(50)))
+    import io
+    a = klib.Profile.from_fasta_by_record(io.BytesIO(path.read_bytes()), 3)
+    first = next(a)
+    assert first.name == 'r0'
+    list(klib.Profile.from_fasta_by_record(io.BytesIO(b'>x\nAC\n'), 3))
+    monkey_batch = klib._RECORD_BATCH_BYTES
+    klib._RECORD_BATCH_BYTES = 4 * 8 * 4 ** 3               # four records per batch: the first generator has batches left to fetch
+    try:
+        b = klib.Profile.from_fasta_by_record(io.BytesIO(path.read_bytes()), 3)
+        next(b)
+        list(klib.Profile.from_fasta_by_record(io.BytesIO(b'>y\nACG\n'), 3))
+        with pytest.raises(RuntimeError):
+            list(b)
+    finally:
+        klib._RECORD_BATCH_BYTES = monkey_batch
+
+
 def test_chunk_seams_everywhere(tmp_path):
     """The pipelined ingest (kpal_count_feed_fasta / _file: chunks cut ANYWHERE, flattened with the state the previous chunk
     left -- line start / inside a header / inside a sequence line --, k-mer windows carried across the seams by the saved tail)

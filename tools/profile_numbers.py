@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Print the figures DESIGN.md section 5 / README / BASELINE.md quote from the artefacts of a round:
-python tools/profile_numbers.py [profiles/r4]"""
+python tools/profile_numbers.py [profiles/r5]"""
 import csv, json, os, sys
 
-d = sys.argv[1] if len(sys.argv) > 1 else 'profiles/r4'
+d = sys.argv[1] if len(sys.argv) > 1 else 'profiles/r5'
 
 
 def line(name):
