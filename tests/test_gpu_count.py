@@ -896,18 +896,15 @@ def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
     small = ctx.host_alloc(4096)
     from kpal_amd import _native
     default = _native.context()
-    saved = klib._gather_buffers.get(default)
+    saved = getattr(default, '_gather_buffer', None)
     try:
-        klib._gather_buffers[default] = small
+        default._gather_buffer = small
         for k in (4, 11):
             want = oracle.from_sequences(as_text, k)
             np.testing.assert_array_equal(klib.Profile.from_sequences(items, k).counts, want)
             np.testing.assert_array_equal(klib.Profile.from_sequences(iter(items), k).counts, want)
     finally:
-        if saved is None:
-            klib._gather_buffers.pop(default, None)
-        else:
-            klib._gather_buffers[default] = saved
+        default._gather_buffer = saved
         ctx.host_free(small[0])
     # a page-locked buffer larger than one 64 MiB staging piece fed in place: the seams carry their k - 1 bytes of halo
     big = oracle.synth_reads(62, 0, 900000, 150, noisy=True)                     # 136 MB

@@ -42,6 +42,9 @@ def test_bench_single_gpu_small():
     assert ex['k15']['ms_per_step'] > 0 and ex['k15']['roofline']['pipeline']['frac'] > 0
     assert ex['matrix_prod']['parity_pairs'] == 28 and ex['matrix_euclidean']['roofline']['bound'] == 'mfma'
     assert ex['end_to_end']['h2d_s'] > 0 and ex['end_to_end']['d2h_s'] > 0
+    # skew is a first-class figure of the line: uniform / 2 % low-complexity / homopolymer input at k = 12 and k = 15, as scalars of `config`
+    for name in ('k12_uniform', 'k12_low_complexity_2pct', 'k12_homopolymer', 'k15_uniform', 'k15_low_complexity_2pct', 'k15_homopolymer'):
+        assert ex['skew'][name]['Gbases_per_s'] > 0 and line['config']['skew_%s_Gbases_per_s' % name] == ex['skew'][name]['Gbases_per_s']
 
 
 def test_library_rccl_world_1():
