@@ -34,16 +34,21 @@ def variant(kind):
         m[hit[~half], :150] = np.frombuffer((b'AC' * 75), dtype=np.uint8)
     elif kind == 'ACG':
         m[hit, :150] = np.frombuffer((b'ACG' * 50), dtype=np.uint8)
-    elif kind == 'polyA_aligned':        # the poly-A stretch begins and ends on 16-byte boundaries of the stream: no mixed lanes
+    elif kind in ('polyA_aligned', 'polyA_inside', 'polyA_inside_N'):
+        # a poly-A stretch of 128 bases INSIDE the read, its flanks valid bases (polyA: the flanks are read ends) -- beginning on a
+        # 16-byte boundary of the stream, or 5 bases into the read; _N: an N on either side (the flanking windows do not count)
         flat = m.reshape(-1)
-        for r in hit[:]:
-            s = (r * L + 15) // 16 * 16
-            flat[s:s + 128] = ord('A')
+        starts = hit * L + 5 if kind != 'polyA_aligned' else (hit * L + 15) // 16 * 16
+        idx = (starts[:, None] + np.arange(128)[None, :]).reshape(-1)
+        flat[idx] = ord('A')
+        if kind == 'polyA_inside_N':
+            flat[starts - 1] = ord('N')
+            flat[starts + 128] = ord('N')
         return flat
     return m.reshape(-1)
 
 
-for kind in ('uniform', 'polyA', 'AC', 'both', 'ACG', 'polyA_aligned'):
+for kind in ('uniform', 'polyA', 'AC', 'both', 'ACG', 'polyA_aligned', 'polyA_inside', 'polyA_inside_N'):
     buf = variant(kind)
     ctx.h2d(d, buf)
     best = None
