@@ -189,7 +189,7 @@ struct QuadSpill {
 //   * lanes left after eight rounds probe for themselves.
 // Call wave-converged; `active` selects the lanes that hold an item.
 struct QuadHot {
-    unsigned long long key;   // row << 32 | item; 0 = free (an item always has mask bits set)
+    unsigned long long key;   // row << 32 | item (an item always has mask bits set); 1 << 63 | table index: a single k-mer; 0 = free
     uint32_t count, pad;
 };
 constexpr int kQuadHotEntries = 256;
@@ -241,17 +241,60 @@ __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
 }
 
-template <int K, int LEVEL = 1, typename SINK = TableOnly, bool COUNTED = false>
+// One k-mer of the direct path into the hot-item table as an entry keyed by its table index (see quad_items_direct_body), or, when
+// its four probe slots hold other keys, into the count table.  (Inline in quad_items_direct_body, which is itself only reached through
+// the out-of-line quad_items_direct*: a second level of calls would need a stack frame -- scratch memory in every kernel.)
+template <typename SINK>
+__device__ __forceinline__ void quad_kmer_add(const SINK table, QuadHot *hot, uint64_t index, uint32_t n)
+{
+#if defined(KPAL_AB_DIRECT_NO_TABLE)   // A/B timing builds (wrong counts): what the global atomics of the direct path cost
+    return;
+#endif
+    const unsigned long long key = (1ull << 63) | (unsigned long long)index;
+    const uint32_t h = ((uint32_t)index * 0x9E3779B1u + (uint32_t)(index >> 32)) >> 24;
+    bool done = false;
+#pragma unroll 1
+    for (uint32_t pr = 0; pr < 4u && !done; ++pr) {
+        const uint32_t slot = (h + pr) & (uint32_t)(kQuadHotEntries - 1);
+        unsigned long long cur = hot[slot].key;
+        if (cur == 0ull) {
+            cur = atomicCAS(&hot[slot].key, 0ull, key);
+            if (cur == 0ull) cur = key;
+        }
+        if (cur == key) {
+            atomicAdd(&hot[slot].count, n);
+            done = true;
+        }
+    }
+    if (!done) sink_add(table, index, (unsigned long long)n);
+}
+
+template <int K, int LEVEL = 1, typename SINK = TableOnly, bool COUNTED = false, bool KMERS = false>
 __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0,
                                                        uint32_t cnt = 1u)
 {
     // COUNTED: lane l stands for cnt (0 .. 4) occurrences of its item (the repeat lanes of quad_scatter_kernel)
     const uint32_t mult = COUNTED ? cnt : 1u;
     const int lane = threadIdx.x & 63;
-    auto to_table = [&](uint32_t r, uint32_t it, unsigned long long n) {
+    // An item the hot-item table does not hold (a singleton in its wave, no free slot) is counted k-mer by k-mer -- NOT straight into
+    // the count table: the items that end here are those of persistently over-full rows, and their k-mers repeat over the whole
+    // input even when the items do not (the flanks of poly-A stretches inside reads: A^11 X, A^10 XY ... -- a few dozen table entries
+    // for the whole chip, on which global atomics serialise: a timing build without them ran every skewed input of tools/skewdiag.py
+    // within 25 % of uniform reads, the committed kernel up to 6 x slower).  So the k-mers go into the SAME LDS table, as entries
+    // keyed by the table index (bit 63 marks them), added to the count table once per workgroup; only when their four probe slots are
+    // taken by other keys does a k-mer leave as a global atomic.
+    // (KMERS = false: the inlined copies in the kernels' epilogues -- once per kernel, what is still carried at the end -- add to the
+    // count table directly: the table code there cost the kernels spilled registers)
+    auto kmer_add = [&](uint64_t index, uint32_t n) {
+        if constexpr (KMERS) quad_kmer_add<SINK>(table, hot, index, n);
+        else sink_add(table, index, (unsigned long long)n);
+    };
+    // (the rare tail below -- more than eight different items in one wave -- keeps the plain adds: a second copy of the probe loop
+    // cost the callers of this function registers)
+    auto to_table = [&](uint32_t r, uint32_t it, uint32_t n) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((it >> (3 - i)) & 1u) sink_add(table, quad_kmer<K, LEVEL>(r, it, i, coarse), n);
+            if ((it >> (3 - i)) & 1u) sink_add(table, quad_kmer<K, LEVEL>(r, it, i, coarse), (unsigned long long)n);
     };
     unsigned long long todo = __builtin_amdgcn_ballot_w64(active);
     for (int round = 0; round < 8 && todo; ++round) {   // wave-uniform
@@ -281,7 +324,11 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
                 placed = __builtin_amdgcn_ballot_w64(lane == who && (old == 0ull || old == key)) != 0ull;
                 if (placed && lane == who) atomicAdd(&hot[slot].count, n);
             }
-            if (!placed && lane == src) to_table(hot_row, hot_item, n);
+            if constexpr (KMERS) {
+                if (!placed && lane < 4 && ((hot_item >> (3 - lane)) & 1u)) kmer_add(quad_kmer<K, LEVEL>(hot_row, hot_item, lane, coarse), n);   // lane i: k-mer i
+            } else {
+                if (!placed && lane == src) to_table(hot_row, hot_item, n);
+            }
         }
         todo &= ~same;
     }
@@ -297,29 +344,32 @@ __device__ __forceinline__ void quad_items_direct_body(bool active, uint32_t row
                 done = true;
             }
         }
-        if (!done) to_table(row, item, (unsigned long long)mult);
+        if (!done) to_table(row, item, mult);
     }
 }
 
 // (rare path, called from the unrolled placement loop: kept out of line there; the scatter kernels' epilogues inline the body -- an
 // out-of-line call next to everything that is live there cost spilled registers, and kernels that use scratch memory at all ran
 // 8 % slower in same-box comparisons, wherever the spill sat)
-template <int K, int LEVEL = 1, typename SINK = TableOnly>
+// KM: with the k-mer entries of the hot-item table (quad_kmer_add).  Only the REPEAT instantiations of quad_scatter_kernel ask for it --
+// the input whose sample showed hot rows; the larger function costs its callers a few spilled registers (16-32 bytes of scratch),
+// which uniform reads do not pay.
+template <int K, int LEVEL = 1, typename SINK = TableOnly, bool KM = false>
 __device__ __attribute__((noinline)) void quad_items_direct(bool active, uint32_t row, uint32_t item, const SINK table, QuadHot *hot, uint32_t coarse = 0)
 {
-    quad_items_direct_body<K, LEVEL, SINK>(active, row, item, table, hot, coarse);
+    quad_items_direct_body<K, LEVEL, SINK, false, KM>(active, row, item, table, hot, coarse);
 }
 
 // (the repeat lanes: lane l holds its item cnt times)
 template <int K, typename SINK>
 __device__ __attribute__((noinline)) void quad_items_direct_counted(uint32_t cnt, uint32_t row, uint32_t item, const SINK table, QuadHot *hot)
 {
-    quad_items_direct_body<K, 1, SINK, true>(cnt != 0u, row, item, table, hot, 0u, cnt);
+    quad_items_direct_body<K, 1, SINK, true, true>(cnt != 0u, row, item, table, hot, 0u, cnt);
 }
 
 // Returns the mask (bit q) of this lane's items that did not fit their row.  pos[row] counts the BYTES in use of
 // the row (the atomic returns the item's byte offset: one shift-add gives its LDS address).
-template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4, typename SINK = TableOnly>
+template <int K, bool DIRECT = false, int LEVEL = 1, int N = 4, typename SINK = TableOnly, bool KM = false>
 __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                const uint32_t (&row)[N], const uint32_t (&item)[N], const SINK &table,
                                                QuadHot *hot, uint32_t coarse = 0)
@@ -405,7 +455,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
             if (__builtin_expect(__any(unlisted != 0u), 0)) {
 #pragma unroll
                 for (int q = 0; q < N; ++q)
-                    if (__any((unlisted >> q) & 1u)) quad_items_direct<K, LEVEL, SINK>((unlisted >> q) & 1u, row[q], item[q], table, hot, coarse);
+                    if (__any((unlisted >> q) & 1u)) quad_items_direct<K, LEVEL, SINK, KM>((unlisted >> q) & 1u, row[q], item[q], table, hot, coarse);
             }
             return over;
         }
@@ -439,7 +489,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
                 base += (uint32_t)__popcll(b);
             }
             // carried items that still do not fit, and whatever the list cannot hold: counted now
-            if (list_full && __any(ov && !listed)) quad_items_direct<K, LEVEL, SINK>(ov && !listed, row[q], item[q], table, hot, coarse);
+            if (list_full && __any(ov && !listed)) quad_items_direct<K, LEVEL, SINK, KM>(ov && !listed, row[q], item[q], table, hot, coarse);
         }
     }
     return over;
@@ -447,7 +497,7 @@ __device__ __forceinline__ uint32_t quad_place(uint32_t *rows, uint32_t *pos, Qu
 
 // The items a thread carries from one round to the next (entries threadIdx.x + c * THREADS of the spill list).
 // Plain functions on array references: as [&] lambdas the arrays were kept in scratch memory.
-template <int K, int CARRY, int LEVEL = 1, typename SINK = TableOnly>
+template <int K, int CARRY, int LEVEL = 1, typename SINK = TableOnly, bool KM = false>
 __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos, QuadSpill *spill, uint32_t *spill_n, uint32_t cap,
                                                    const uint32_t (&carry_row)[CARRY], uint32_t (&carry_item)[CARRY],
                                                    const SINK &table, QuadHot *hot, uint32_t coarse = 0)
@@ -458,7 +508,7 @@ __device__ __forceinline__ void quad_place_carried(uint32_t *rows, uint32_t *pos
         const uint32_t i1[1] = {carry_item[c]};
         if (__any(carry_item[c] != 0u)) {
             // an item that does not fit even now has been counted: it is no longer carried
-            if (quad_place<K, true, LEVEL, 1, SINK>(rows, pos, spill, spill_n, cap, r1, i1, table, hot, coarse) & 1u) carry_item[c] = 0;
+            if (quad_place<K, true, LEVEL, 1, SINK, KM>(rows, pos, spill, spill_n, cap, r1, i1, table, hot, coarse) & 1u) carry_item[c] = 0;
         }
     }
 }
@@ -713,7 +763,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const bool next_inside = more && (fnext + STEPS) * 64 <= s.nchunks;
         uint32_t *spill_n = &spill_cnt[j & 1];
         // ---- place: carried items, then this tile's
-        quad_place_carried<K, CARRY, 1, SINK2>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
+        quad_place_carried<K, CARRY, 1, SINK2, REPEAT>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot);
         Chunk carry = encode16(rawh);
         range_fix(s, (int64_t)(first * 64) - 1, carry);
         if (more) rawh = fetch_chunk(s, (int64_t)(fnext * 64) - 1);
@@ -781,7 +831,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 #if defined(KPAL_AB_SCATTER_NO_PLACE)    // A/B timing builds (wrong counts): loads + encode + split + flush only
             asm volatile("" ::"v"(row[0] ^ row[1] ^ row[2] ^ row[3] ^ item[0] ^ item[1] ^ item[2] ^ item[3]));
 #else
-            if (place) quad_place<K, false, 1, 4, SINK2>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
+            if (place) quad_place<K, false, 1, 4, SINK2, REPEAT>(rows, pos, spill, spill_n, CAP, row, item, table, hot);
 #endif
         }
         have_rec = false;
@@ -859,6 +909,10 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const QuadHot h = hot[i];
         if (h.key && h.count) {
             ++used;
+            if (h.key >> 63) {                   // a k-mer of the direct path: key = 1 << 63 | table index
+                sink_add(table, (uint64_t)(h.key & 0x7FFFFFFFFFFFFFFFull), (unsigned long long)h.count);
+                continue;
+            }
             const uint32_t r = (uint32_t)(h.key >> 32), it = (uint32_t)h.key;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1100,6 +1154,10 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
         const QuadHot h = hot[i];
         if (h.key && h.count) {
+            if (h.key >> 63) {                   // a k-mer of the direct path: key = 1 << 63 | table index
+                sink_add(table, (uint64_t)(h.key & 0x7FFFFFFFFFFFFFFFull), (unsigned long long)h.count);
+                continue;
+            }
             const uint32_t r = (uint32_t)(h.key >> 32), itm = (uint32_t)h.key;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
