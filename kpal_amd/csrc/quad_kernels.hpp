@@ -190,7 +190,7 @@ struct QuadSpill {
 // Call wave-converged; `active` selects the lanes that hold an item.
 struct QuadHot {
     unsigned long long key;   // row << 32 | item (an item always has mask bits set); 1 << 63 | table index: a single k-mer; 0 = free
-    uint32_t count, pad;
+    uint32_t count, pad;      // pad: k-mer entries -- the count when the entry was last looked at (ageing, quad_scatter_kernel<.., REPEAT>)
 };
 constexpr int kQuadHotEntries = 256;
 
@@ -239,6 +239,22 @@ __device__ __forceinline__ void sink_add(const TableSink &sink, uint64_t index, 
 __device__ __forceinline__ uint32_t quad_hot_hash(uint32_t row, uint32_t item)
 {
     return ((item >> 4) * 0x9E3779B1u + row * 0x85EBCA6Bu) >> 24;   // 8 bits
+}
+
+// Ageing of the k-mer entries of the hot-item table (quad_scatter_kernel<.., REPEAT>): thread i looks at entry i.  Out of line: it
+// runs once per four tiles and must not cost the kernel registers.
+template <typename SINK>
+__device__ __attribute__((noinline)) void quad_hot_age(const SINK table, QuadHot *hot)
+{
+    const QuadHot h = hot[threadIdx.x];
+    if (h.key >> 63) {
+        if (h.count == h.pad) {
+            sink_add(table, (uint64_t)(h.key & 0x7FFFFFFFFFFFFFFFull), (unsigned long long)h.count);
+            hot[threadIdx.x] = QuadHot{0ull, 0u, 0u};
+        } else {
+            hot[threadIdx.x].pad = h.count;
+        }
+    }
 }
 
 // One k-mer of the direct path into the hot-item table as an entry keyed by its table index (see quad_items_direct_body), or, when
@@ -840,6 +856,13 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
         const uint32_t spilled = min(*spill_n, CAP);         // (beyond CAP: counted directly by quad_place); reset only during the flush of the NEXT tile
         quad_note_spill(error, *spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;   // last read before the barrier that ended the previous tile
+        if constexpr (REPEAT) {
+            // The k-mer entries of the hot-item table AGE: every fourth tile an entry that has not been added to since the last look
+            // (pad = its count then) goes to the count table and frees its slot -- the table admits every k-mer of the direct path,
+            // hot or not, and without this it was full of cold ones after a few tiles (all 256 entries in use in every case of
+            // tools/skewdiag.py).  Nobody touches the table between the two barriers of the flush.
+            if ((j & 3u) == 3u && threadIdx.x < (uint32_t)kQuadHotEntries) quad_hot_age<SINK2>(table, hot);   // (wave-uniform: waves 0..3)
+        }
         // ---- flush: every row becomes one record of S items (null padded), kept in registers
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
         {
