@@ -1,7 +1,7 @@
 """Skewed inputs at FULL size against the oracle (round-4 review, weak 2): the paths such inputs stress are size-dependent --
 the spill list and the per-workgroup hot-item table of the quad scatters, FRESH lists from 64 MiB up, pool halving -- and
 tools/skewbench.py times 1 GiB of exactly these inputs without comparing them with anything.  Here: the five inputs of
-tools/skewbench.py plus reads that share an adapter prefix, 1 GiB each, generated on the device (torch, seeded), counted through
+tools/skewbench.py plus reads that share an adapter prefix, reads with poly-A stretches inside and period-3 repeats, 1 GiB each, generated on the device (torch, seeded), counted through
 AUTO as a whole device feed (what bench.py times) and compared with the CPU oracle run on the SAME bytes downloaded:
   * k = 12: every one of the 4^12 bins, plain and balanced (oracle.count_flat on private per-thread tables, oracle.balance);
   * k = 15: 64 blocks of 2^20 table entries, plain and balanced (oracle.count_blocks) -- the poly-A / poly-T, (AC)n / (GT)n and
@@ -65,6 +65,17 @@ def make_cases(torch, dev):
     ad = as_reads(sample([.25, .25, .25, .25], READS * L)).clone()
     ad[:, :len(ADAPTER)] = torch.tensor(list(ADAPTER), dtype=torch.uint8, device=dev)[None, :]
     cases['adapter_prefixed'] = ad.reshape(-1)
+    # poly-A stretches INSIDE reads, flanked by valid bases (RNA-seq tails): the two flank items per stretch land in the poly-A row with
+    # DISTINCT values -- singletons in their wave whose k-mers (A^11 X ...) repeat over the whole input: the k-mer entries of the
+    # hot-item table and their ageing; and period-3 repeats, which are no repeat lanes (three items cycle)
+    inside = as_reads(sample([.25, .25, .25, .25], READS * L)).clone()
+    hit2 = torch.rand(READS, generator=g, device=dev) < 0.02
+    inside[:, 5:133] = torch.where(hit2[:, None], torch.full_like(inside[:, 5:133], ord('A')), inside[:, 5:133])
+    cases['polya_inside_2pct'] = inside.reshape(-1)
+    p3 = as_reads(sample([.25, .25, .25, .25], READS * L)).clone()
+    acg = torch.tensor(list(b'ACG' * 50), dtype=torch.uint8, device=dev)
+    p3[:, :150] = torch.where(hit2[:, None], acg[None, :].expand(READS, 150), p3[:, :150])
+    cases['period3_2pct'] = p3.reshape(-1)
     return cases
 
 
