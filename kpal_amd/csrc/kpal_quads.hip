@@ -175,9 +175,9 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
         ctx->cached_bytes = feed_bytes;
     }
     if (ctx->quad_repeat_forced >= 0) repeat = ctx->quad_repeat_forced != 0;
-    // (k = 12 has no REPEAT instantiation of the 7-step tile -- it would spill registers: the 6-step tile, unless the size is forced)
-    if (repeat && ctx->k == 12 && steps == 7 && !ctx->quad_steps_forced) steps = 6;
-    if (repeat && !(ctx->k == 12 && steps == 7)) ++ctx->stat_repeat_pieces;
+    // (there is no REPEAT instantiation of the 7-step tile -- it would spill registers: the 6-step tile, unless the size is forced)
+    if (repeat && steps == 7 && !ctx->quad_steps_forced) steps = 6;
+    if (repeat && steps != 7) ++ctx->stat_repeat_pieces;
     ctx->plan_strategy = KPAL_STRATEGY_PARTITION_QUADS;
     ctx->plan_steps1 = steps;
     ctx->plan_steps2 = 0;
@@ -209,11 +209,11 @@ int launch_partition_quads(kpal_ctx *ctx, const Span &s)
     // k = 12 fits its 128 registers either way and a four-step ring changed nothing: 7.44 vs 7.40 ms)
     // REPEAT: the instantiation that sends the repeat lanes of low-complexity sequence straight to the hot-item table (quad_kernels.hpp);
     // taken when the sample shows hot rows (KPAL_QUAD_REPEAT=0 / 1 forces one: A/B, tests).  Its call site costs registers: a
-    // four-step input ring in the 8-step tile (and no such instantiation of the 7-step tile at k = 12: it would spill).
+    // four-step input ring in the 8-step tile (and no such instantiation of the 7-step tile: it would spill).
 #define KPAL_QUAD_LAUNCH(S)                                                                                                  \
     do {                                                                                                                     \
         if (repeat)                                                                                                          \
-            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 ? 4 : S), TableOnly, (K != 12 || S != 7)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, \
+            LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 ? 4 : S), TableOnly, (S != 7)>), dim3(G), dim3(1024), s, tpb, pool, (uint32_t)tpb, \
                    nrounds, error, table);                                                                                   \
         else                                                                                                                 \
             LAUNCH(ctx, "quad_scatter", (quad_scatter_kernel<K, 16, S, (S == 8 && K != 12 ? 4 : S), TableOnly, false>), dim3(G), dim3(1024), s, tpb, pool,    \

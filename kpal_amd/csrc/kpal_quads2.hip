@@ -130,8 +130,14 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
         table_h = TableSink{nullptr, list + (size_t)(nseg - 1) * seg, counts + (nseg - 1), seg_h, overflow};   // global counter
     }
 #define KPAL_QUAD2_LAUNCH(S2)                                                                                                          \
-    LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
-           (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)cap2, nrounds2, error, table2)
+    do {                                                                                                                               \
+        if (repeat1)                                                                                                                   \
+            LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2, true>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
+                   (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)cap2, nrounds2, error, table2); \
+        else                                                                                                                           \
+            LAUNCH(ctx, "quad2_scatter", (quad2_scatter_kernel<K, kWaves2, S2, false>), dim3(G2, NB1), dim3(kWaves2 * 64), (const uint32_t *)pool1, \
+                   (const uint32_t *)nrounds1, G1, (uint32_t)cap1, upw, (uint32_t)tiles2, pool2, (uint32_t)cap2, nrounds2, error, table2); \
+    } while (0)
     // (REPEAT: the level-1 instantiation with the repeat lanes' shortcut, when the sample shows hot rows -- kpal_quads.hip; the
         // seven-step tile has no such instantiation: at 128 registers the call site cost it spilled ones)
 #define KPAL_QUAD1_LAUNCH(S, D)                                                                                                        \

@@ -968,7 +968,9 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
 // level-1 workgroup u % G1) is the run of nrounds1[u % G1] records that workgroup wrote for that row.  The units
 // are addressed as one stream of `unit_cap` bytes each (records never written read as null items): a wave-step is
 // 1 KiB of it, four items per lane -- the shape of the ASCII path, so the tile loop is the same.
-template <int K, int WAVES, int STEPS>
+// KM: the instantiation whose direct path aggregates k-mers in the hot-item table (with ageing): launched when the sample of the feed
+// showed hot rows, like the REPEAT instantiation of level 1.
+template <int K, int WAVES, int STEPS, bool KM = false>
 __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_t *__restrict__ pool1, const uint32_t *__restrict__ nrounds1,
                                                             uint32_t G1, uint32_t rounds_cap1, uint32_t upw, uint32_t tiles_per_block,
                                                             uint32_t *__restrict__ pool2, uint32_t rounds_cap2,
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     for (uint64_t j = 0; j < tiles_per_block && j * tile_bytes < (uint64_t)stream; ++j) {   // block-uniform
         const bool more = j + 1 < tiles_per_block && (j + 1) * tile_bytes < (uint64_t)stream;
         uint32_t *spill_n = &spill_cnt[j & 1];
-        quad_place_carried<K, CARRY, 2, TableSinkRef>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
+        quad_place_carried<K, CARRY, 2, TableSinkRef, KM>(rows, pos, spill, spill_n, CAP, carry_row, carry_item, table, hot, coarse);
         if (more) seek(j + 1);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
                 for (int i = st * DEFER; i < (st + 1) * DEFER; ++i) store_rec(i);
             }
             if (more) raw[st] = fetch_next();
-            quad_place<K, false, 2, 4, TableSinkRef>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
+            quad_place<K, false, 2, 4, TableSinkRef, KM>(rows, pos, spill, spill_n, CAP, row, item, table, hot, coarse);
         }
         have_rec = false;
         quad_tile_priority<1>(0);
@@ -1118,6 +1120,9 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
         const uint32_t spilled = min(*spill_n, CAP);
         quad_note_spill(error, *spill_n, CAP);
         if (threadIdx.x == 0) spill_cnt[(j & 1) ^ 1] = 0;
+        if constexpr (KM) {   // (ageing of the k-mer entries: see quad_scatter_kernel)
+            if ((j & 3u) == 3u && threadIdx.x < (uint32_t)kQuadHotEntries) quad_hot_age<TableSinkRef>(table, hot);
+        }
         quad_take_carried<CARRY, THREADS>(spill, spilled, carry_row, carry_item);
         {
             const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -1172,7 +1177,7 @@ __global__ __launch_bounds__(WAVES * 64) void quad2_scatter_kernel(const uint32_
     }
     if (threadIdx.x == 0) nrounds2[wg] = min(round, rounds_cap2);
 #pragma unroll
-    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2, TableSinkRef>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
+    for (int c = 0; c < CARRY; ++c) quad_items_direct<K, 2, TableSinkRef, KM>(carry_item[c] != 0u, carry_row[c], carry_item[c], table, hot, coarse);
     __syncthreads();
     for (int i = threadIdx.x; i < kQuadHotEntries; i += THREADS) {
         const QuadHot h = hot[i];
