@@ -117,7 +117,10 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
     if (fresh) {
         // the histogram stage's shared segment also takes every count that does not fit a staged form (>= 256 within one form and
         // piece: repeats of real genomes): room for 4 M entries (unless the tests force small segments)
-        const uint32_t seg = ctx->direct_seg;
+        // (a feed whose sample showed hot rows sends more counts past the records -- the k-mer entries of the hot-item tables leave as
+        // they age, a few hundred per workgroup and four tiles: four times the room, or the piece would overflow its lists and run again)
+        const uint32_t seg = (repeat1 && !ctx->direct_seg_forced) ? ctx->direct_seg * 4u : ctx->direct_seg;
+        ctx->direct_seg_used = seg;
         const uint32_t seg_h = ctx->direct_seg_forced ? seg : std::max<uint32_t>(seg, 1u << 22);
         ctx->direct_seg_hist = seg_h;
         CHK(ensure(ctx, ctx->direct_list, ((size_t)(nseg - 1) * seg + seg_h) * sizeof(unsigned long long)));
@@ -247,7 +250,7 @@ int quad2_finalize(kpal_ctx *ctx, bool balance)
             LAUNCH(ctx, "quad2_finalize", (quad2_finalize_kernel<K, false, false>), dim3(Quad2Index<K>::kSets), dim3(1024), stage, table);
         if (fresh)
             LAUNCH(ctx, "quad2_apply_list", (quad2_apply_list_kernel<K>), dim3(ctx->direct_nseg - 1 + kQuad2ListTailBlocks), dim3(256),
-                   (const unsigned long long *)ctx->direct_list.p, (const uint32_t *)ctx->direct_meta.p, ctx->direct_seg, ctx->direct_nseg - 1,
+                   (const unsigned long long *)ctx->direct_list.p, (const uint32_t *)ctx->direct_meta.p, ctx->direct_seg_used, ctx->direct_nseg - 1,
                    ctx->direct_seg_hist, balance ? 1u : 0u, table);
     });
     return KPAL_OK;
