@@ -110,7 +110,7 @@ struct kpal_ctx {
     Span fresh_span = {};                    // the piece of a FRESH finalisation (re-run classically if a list overflowed)
     DevBuf direct_list, direct_meta;         // TableSink segments ((index << 32) | count entries); per-segment counts + overflow word
     uint32_t direct_seg = 16384;             // entries per segment (KPAL_DIRECT_SEG: tests force the overflow path)
-    uint32_t direct_seg_used = 16384;        // ... of the current lists (four times that for a feed with hot rows)
+    uint32_t direct_seg_used = 16384;        // ... of the current lists (sixteen times that for a feed with hot rows)
     bool quad_hist_unpacked = false;         // KPAL_HIST_PACKED=0: the 128 KiB histogram at every k (A/B, tests)
     bool direct_seg_forced = false;          // ... then the histogram stage's segment is as small
     uint32_t direct_seg_hist = 16384;        // entries of the last segment (histogram stage, shared) of the current lists

@@ -118,8 +118,8 @@ int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh)
         // the histogram stage's shared segment also takes every count that does not fit a staged form (>= 256 within one form and
         // piece: repeats of real genomes): room for 4 M entries (unless the tests force small segments)
         // (a feed whose sample showed hot rows sends more counts past the records -- the k-mer entries of the hot-item tables leave as
-        // they age, a few hundred per workgroup and four tiles: four times the room, or the piece would overflow its lists and run again)
-        const uint32_t seg = (repeat1 && !ctx->direct_seg_forced) ? ctx->direct_seg * 4u : ctx->direct_seg;
+        // they age, a few hundred per workgroup and four tiles: sixteen times the room (2.7 GB at k = 15), or the piece would overflow its lists and run again)
+        const uint32_t seg = (repeat1 && !ctx->direct_seg_forced) ? ctx->direct_seg * 16u : ctx->direct_seg;
         ctx->direct_seg_used = seg;
         const uint32_t seg_h = ctx->direct_seg_forced ? seg : std::max<uint32_t>(seg, 1u << 22);
         ctx->direct_seg_hist = seg_h;

@@ -100,6 +100,8 @@ python3 tools/clibench.py --by-record > "$OUT/clibench_by_record.json" 2> "$OUT/
 # ---- skewed inputs
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
 python3 tools/skewbench.py --k 15 > "$OUT/skewbench_k15.log" 2>&1
+python3 tools/skewdiag.py > "$OUT/skewdiag_k12.log" 2> /dev/null
+python3 tools/skewdiag.py --k 15 > "$OUT/skewdiag_k15.log" 2> /dev/null
 # ---- the hex pipeline (k = 12, six k-mers per three-byte item) next to the quads, same box
 for st in partition_quads partition_hex; do python3 "$B" --steps 10 --warmup 2 --no-extra --no-cpu --strategy $st > "$OUT/bench_k12_$st.json" 2> "$OUT/bench_k12_$st.err"; done
 # keep only the small summaries (the merge back is capped at 64 MiB)
