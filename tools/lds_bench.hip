@@ -16,7 +16,7 @@
         }                                                                             \
     } while (0)
 
-enum Op { ADD32 = 0, ADD32_RTN, ADD64, WRITE16, WRITE32, READ32, ADD32_REP32, ADD32_RTN_WRITE16 };
+enum Op { ADD32 = 0, ADD32_RTN, ADD64, WRITE16, WRITE32, READ32, ADD32_REP32, ADD32_RTN_WRITE16, ADD32_NOCONF, ADD32_PAIRS, ADD64_NOCONF, READ32_NOCONF };
 
 __device__ __forceinline__ uint32_t rng(uint32_t &s)
 {
@@ -24,6 +24,9 @@ __device__ __forceinline__ uint32_t rng(uint32_t &s)
     return s >> 8;
 }
 
+// (the random bin of every operation comes from eight per-thread offsets advanced by one add + one and: a generator of five VALU
+// instructions per operation -- what this file used until round 5 -- bounds the loop at ~6 clk per wave-instruction per CU by itself,
+// four SIMDs issuing one VALU instruction per 4 clk each, and hid every LDS rate below that)
 template <int OP>
 __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t nbins, uint32_t *out)
 {
@@ -33,17 +36,34 @@ __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t nbins, 
     uint32_t s = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + 12345u;
     uint32_t acc = 0;
     const uint32_t mask = nbins - 1;
+    constexpr bool kNoConf = OP == ADD32_NOCONF || OP == ADD64_NOCONF || OP == READ32_NOCONF;
+    uint32_t a[8], step[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        a[u] = rng(s) & mask;
+        step[u] = (rng(s) | 1u) & mask;
+        if (kNoConf) {                       // lane = bank (64 dwords; 32 qwords): the steps leave the low bits alone
+            const uint32_t low = OP == ADD64_NOCONF ? 31u : 63u;
+            a[u] = (a[u] & ~low) | (threadIdx.x & low);
+            step[u] = (step[u] & ~low) | (low + 1u);
+        }
+        if (OP == ADD32_PAIRS) {             // neighbouring lanes share an address
+            a[u] = __shfl(a[u], (int)(threadIdx.x & 62u));
+            step[u] = __shfl(step[u], (int)(threadIdx.x & 62u));
+        }
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint32_t r = rng(s);
-            const uint32_t b = r & mask;
-            if (OP == ADD32) atomicAdd(&lds[b], 1u);
+            a[u] = (a[u] + step[u]) & mask;
+            const uint32_t b = a[u], r = b;
+            if (OP == ADD32 || OP == ADD32_NOCONF || OP == ADD32_PAIRS) atomicAdd(&lds[b], 1u);
             else if (OP == ADD32_RTN) acc += atomicAdd(&lds[b], 1u);
             else if (OP == ADD64) atomicAdd((unsigned long long *)&lds[2 * (b & (mask >> 1))], 1ULL);
+            else if (OP == ADD64_NOCONF) atomicAdd((unsigned long long *)&lds[2 * (b & (mask >> 1))], 1ULL);
             else if (OP == WRITE16) ((uint16_t *)lds)[r & 0x7FFF] = (uint16_t)r;
             else if (OP == WRITE32) lds[b] = r;
-            else if (OP == READ32) acc += lds[b];
+            else if (OP == READ32 || OP == READ32_NOCONF) acc += lds[b];
             else if (OP == ADD32_REP32) atomicAdd(&lds[(b & 511) * 32 + (threadIdx.x & 31)], 1u);
             else if (OP == ADD32_RTN_WRITE16) {
                 const uint32_t slot = atomicAdd(&lds[b & 511], 1u);
@@ -126,9 +146,13 @@ int main()
         run<ADD32_RTN>("ds_add_rtn_u32", block, bpc, 512, dout);
         run<ADD32_RTN>("ds_add_rtn_u32", block, bpc, 32768, dout);
         run<ADD64>("ds_add_u64", block, bpc, 32768, dout);
+        run<ADD32_NOCONF>("ds_add_u32 lane=bank", block, bpc, 32768, dout);
+        run<ADD32_PAIRS>("ds_add_u32 lane pairs", block, bpc, 32768, dout);
+        run<ADD64_NOCONF>("ds_add_u64 lane=bank", block, bpc, 32768, dout);
         run<WRITE16>("ds_write_b16", block, bpc, 32768, dout);
         run<WRITE32>("ds_write_b32", block, bpc, 32768, dout);
         run<READ32>("ds_read_b32", block, bpc, 32768, dout);
+        run<READ32_NOCONF>("ds_read_b32 lane=bank", block, bpc, 32768, dout);
         run<ADD32_RTN_WRITE16>("add_rtn+write16", block, bpc, 512, dout);
     }
     // two 512-thread blocks per CU (the scatter kernel's shape)
