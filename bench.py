@@ -844,6 +844,13 @@ def multi_gpu_worker(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU (no CPU fallback for the hot path)')
+    # KPAL_BENCH_SHARED_GPU=1 (tests on a one-GPU box): every rank works on device 0 and the workers' process group is gloo -- RCCL
+    # refuses two ranks on one device, so only the torch.distributed reducer is measured; what this mode is for is the N > 1 code
+    # around it (supervisors with real GPU workers, shards, the per-bin check of the merged table) running with real counting
+    shared_gpu = os.environ.get('KPAL_BENCH_SHARED_GPU', '') == '1'
+    if shared_gpu:
+        local_rank = 0
+    backend = 'gloo' if shared_gpu else 'nccl'
     torch.cuda.set_device(local_rank)
     ctx = _native.Context(local_rank)
     # what RCCL chose (rings / trees, channels, transports, protocol per collective) goes to one file per rank; rank 0 condenses
@@ -856,10 +863,11 @@ def multi_gpu_worker(args):
         os.environ.setdefault('NCCL_DEBUG_FILE', nccl_log)
     if args.worker:
         set_flag(args.attempt, 'started', rank)
-        join_process_group('nccl', rank, world, args.attempt, device_id=torch.device('cuda', local_rank))
+        join_process_group(backend, rank, world, args.attempt, device_id=None if shared_gpu else torch.device('cuda', local_rank))
     else:   # a rank started without the supervisor (KPAL_BENCH_NO_SUPERVISOR=1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        kw = {} if shared_gpu else {'device_id': torch.device('cuda', local_rank)}
+        td.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     k, L = args.k, args.read_len
     seed = 3
@@ -879,6 +887,9 @@ def multi_gpu_worker(args):
     # ---- which reduce modes ------------------------------------------------------------------------------------------
     library_error = None
     library = args.reduce_via == 'library'
+    if shared_gpu and library:
+        library = False
+        library_error = 'KPAL_BENCH_SHARED_GPU=1: the ranks share one device, which RCCL refuses'
     if library:
         # Every rank first proves that it can bind RCCL -- rank 0 by creating the id, the others by loading the library alone
         # (no id, no bootstrap listener): ncclCommInitRank is a collective, a rank that failed before it would leave the
@@ -1042,6 +1053,9 @@ def multi_gpu_worker(args):
                           'kernels_ms_per_step': {n: v[0] / steps for n, v in sorted(o['prof'].items())}}
             line['config'][key + '_ms_per_step'] = extra[key]['ms_per_step']       # (scalars: the driver's record keeps them)
         line['extra'] = extra
+        if shared_gpu:
+            line['config']['shared_gpu'] = True
+            line['rccl_ranks'] = 0
         if nccl_log:
             line['config']['rccl_info'] = rccl_info(nccl_log)
         if cpu[0] is not None:

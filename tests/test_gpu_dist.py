@@ -87,3 +87,26 @@ def test_bench_multi_gpu_code_path_on_one_gpu():
     # the N > 1 line carries the CPU baseline too (rank 0's host cores, the N = 1 sample)
     assert 'cpu_baseline' in line and line['cpu_baseline']['value'] > 0 and line['cpu_baseline']['kind'] == 'port'
     assert isinstance(line['config'].get('rccl_info'), str)       # (what RCCL said it chose: rank 0's NCCL_DEBUG=INFO log, condensed)
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """TWO ranks with real GPU workers, started as the driver starts the scaling runs.  This box has one GPU and RCCL refuses two ranks on
+    one device, so the ranks share device 0 and talk over gloo (KPAL_BENCH_SHARED_GPU=1): what runs is everything of the N > 1 path
+    but the RCCL collectives themselves -- two supervisors, two workers, the shards of a world of two (rank 1 counts reads
+    [R, 2R)), torch.distributed's reduce of the two tables to rank 0 + balance, the max-over-ranks timing, and the per-bin comparison
+    of the merged table with the single-stream count of both shards."""
+    import json
+    env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29641', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--reads', '1500000',
+                        '--no-cpu'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['attempt'] == 1 and line['config']['shared_gpu'] is True
+    assert line['reduce_mode'] == 'torch_serial' and line['reduce_via'] == 'torch'
+    assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
+    assert line['config']['reads_per_gpu'] == 1500000 and line['value'] > 0
+    assert 'KPAL_BENCH_SHARED_GPU' in line['library_rccl_error']
