@@ -887,7 +887,8 @@ def multi_gpu_worker(args):
     # ---- which reduce modes ------------------------------------------------------------------------------------------
     library_error = None
     library = args.reduce_via == 'library'
-    if shared_gpu and library:
+    if shared_gpu and library and not os.environ.get('KPAL_RCCL_LIBRARY'):
+        # (with KPAL_RCCL_LIBRARY the tests put a stand-in behind the library's communicator: tests/native/fake_rccl.cpp)
         library = False
         library_error = 'KPAL_BENCH_SHARED_GPU=1: the ranks share one device, which RCCL refuses'
     if library:

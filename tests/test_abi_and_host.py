@@ -644,3 +644,17 @@ def test_bench_traffic_comes_from_the_committed_profiles():
             assert per['quad_hist'] < 1.1 * nbytes                               # the records read once, 64 MiB of staged forms written
         assert info['traffic_step'] == pytest.approx(sum(per.values()))
         assert 2.5 * nbytes < info['traffic_step'] < 7 * nbytes
+
+
+def test_fake_rccl_stand_in_covers_what_the_library_binds(tmp_path):
+    """tests/native/fake_rccl.cpp (the transport of the multi-process GPU tests of the kpal_comm_* protocol) builds here, and
+    exports every RCCL entry point kpal_multi.hip looks up -- a symbol the library starts to bind must get a stand-in too."""
+    src = open(os.path.join(ROOT, 'kpal_amd', 'csrc', 'kpal_multi.hip')).read()
+    bound = set(re.findall(r'"(nccl[A-Za-z]+)"', src))
+    assert {'ncclCommInitRank', 'ncclReduce', 'ncclReduceScatter', 'ncclSend', 'ncclRecv', 'ncclGroupEnd'} <= bound
+    lib = str(tmp_path / 'libfake_rccl.so')
+    subprocess.run([os.environ.get('HIPCC', 'hipcc'), '-O2', '-shared', '-fPIC', '-Wall', '-Werror', '-o', lib,
+                    os.path.join(ROOT, 'tests', 'native', 'fake_rccl.cpp')], check=True, timeout=600)
+    out = subprocess.run(['nm', '-D', '--defined-only', lib], check=True, stdout=subprocess.PIPE).stdout.decode()
+    exported = set(re.findall(r' T (nccl[A-Za-z]+)', out))
+    assert bound <= exported, bound - exported

@@ -110,3 +110,68 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
     assert line['config']['reads_per_gpu'] == 1500000 and line['value'] > 0
     assert 'KPAL_BENCH_SHARED_GPU' in line['library_rccl_error']
+
+
+def _build_fake_rccl(tmp_path):
+    lib = str(tmp_path / 'libfake_rccl.so')
+    subprocess.run([os.environ.get('HIPCC', 'hipcc'), '-O2', '-shared', '-fPIC', '-o', lib, os.path.join(ROOT, 'tests', 'native', 'fake_rccl.cpp')],
+                   check=True, timeout=600)
+    return lib
+
+
+def _run_world(tmp_path, world, **extra_env):
+    env = dict(os.environ, KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), KPAL_FAKE_RCCL_TIMEOUT_S='240', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra_env)
+    id_file = str(tmp_path / 'comm_id')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_world_rank.py'), str(r), str(world), id_file], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=1200)[0].decode(errors='replace'))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+@pytest.mark.parametrize('fault', ['reduce', 'recv'])
+def test_fake_rccl_world_test_has_teeth(tmp_path, fault):
+    """The test below must notice a transport that loses a rank's contribution to a reduce, or delivers the wrong block of the
+    mirrored-range exchange: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
+    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='30')
+    assert any(p.returncode != 0 for p in procs), outs
+    assert any('AssertionError' in out for out in outs), outs
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_library_comm_world_over_fake_rccl(tmp_path, world):
+    """The library's kpal_comm_* protocol between W real processes on the one GPU of this box: RCCL refuses two ranks on one device,
+    so KPAL_RCCL_LIBRARY points at a stand-in for the dozen entry points the library binds (tests/native/fake_rccl.cpp: shared
+    memory between the processes, bounded waits).  Contexts, streams, events, kernels, offsets, the order of the collectives:
+    all real (tests/rccl_world_rank.py says what is compared with the oracle)."""
+    procs, outs = _run_world(tmp_path, world)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'RCCL_WORLD_OK rank %d of %d' % (r, world) in out, 'rank %d:\n%s' % (r, out[-3000:])
+
+
+def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path):
+    """bench.py's N > 1 path with TWO real ranks AND the library's reduce modes: as test_bench_two_ranks_sharing_one_gpu, with the
+    stand-in of tests/native/fake_rccl.cpp behind the library's communicator -- pipelined and serial in-library reduce, the torch
+    reduce and the bin-range merge are each measured and each merged table is compared bin for bin with the single-stream count."""
+    import json
+    env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29647', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--reads', '1500000',
+                        '--no-cpu'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['attempt'] == 1 and line['config']['shared_gpu'] is True
+    assert line['reduce_mode'] == 'library_pipelined' and line['reduce_via'] == 'library' and 'library_rccl_error' not in line
+    assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
+    for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce', 'range_merge'):
+        assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['checksum_ok'] is True, mode
