@@ -476,6 +476,10 @@ def main(argv=None):
     c = sub.add_parser('count', help='count the k-mers of FASTA files, sharded over the ranks')
     c.add_argument('-k', dest='size', type=int, default=9, help='k-mer size (default: %(default)s)')      # kmer.py:789
     c.add_argument('--name', default=None, help='profile name (default: the first file\'s base name)')
+    c.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                   help='torch.distributed backend of the merge (default: %(default)s = RCCL; gloo moves the tables through host memory)')
+    c.add_argument('--device', type=int, default=None,
+                   help='GPU of this rank (default: LOCAL_RANK; several ranks may share one GPU with --backend gloo -- RCCL refuses that)')
     c.add_argument('inputs', nargs='+', metavar='INPUT', help='FASTA files')
     c.add_argument('output', metavar='OUTPUT', help='k-mer profile file (HDF5)')
     args = ap.parse_args(argv)
@@ -483,10 +487,15 @@ def main(argv=None):
     if grouped:
         import torch
         import torch.distributed as td
-        local = int(os.environ.get('LOCAL_RANK', '0'))
+        local = args.device if args.device is not None else int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(local)
+        if args.device is not None:
+            os.environ['KPAL_DEVICE'] = str(local)   # the library's default context of this process: the same device
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        td.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            td.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            td.init_process_group('gloo')
     name = args.name or os.path.splitext(os.path.basename(args.inputs[0]))[0]
     profile = profile_from_fasta_sharded(args.inputs, args.size, name=name)
     if profile is not None:

@@ -462,6 +462,38 @@ def test_sharded_fasta_count_through_rccl_world_1(tmp_path, tutorial_dir):
     assert p.returncode == 0 and 'DIST_COUNT_OK' in out, out[-3000:]
 
 
+def test_sharded_fasta_count_three_ranks_on_one_gpu(tmp_path, tutorial_dir):
+    """The same entry with THREE ranks: they share the one GPU of this box (--device 0) and merge over gloo (--backend gloo; RCCL
+    refuses several ranks on one device).  Every rank counts its byte range of the two files (cuts inside records, k - 1-base halo),
+    rank 0 writes the one profile: equal to the merge of the per-file profiles."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a1, a2 = os.path.join(tutorial_dir, 'a_1.fa'), os.path.join(tutorial_dir, 'a_2.fa')
+    code = ('import sys, os, io\n'
+            'sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))\n'
+            'import numpy as np, memh5\n'
+            'from kpal_amd import files, dist, klib\n'
+            'store = memh5.Store(); files.open_profile_file = store.open\n'
+            'out = %r\n'
+            'rc = dist.main(["count", "-k", "8", "--backend", "gloo", "--device", "0", %r, %r, out])\n'
+            'assert rc == 0\n'
+            'if os.environ["RANK"] == "0":\n'
+            '    got = klib.Profile.from_file(store.open(out, "r"))\n'
+            '    a = klib.Profile.from_fasta(open(%r), 8); b = klib.Profile.from_fasta(open(%r), 8); a.merge(b)\n'
+            '    assert got.name == "a_1" and np.array_equal(got.counts, a.counts) and int(got.total) == int(a.total)\n'
+            '    print("DIST_COUNT_OK", int(got.total))\n'
+            'else:\n'
+            '    assert not store.files\n') % (root, root, str(tmp_path / 'out3.k8'), a1, a2, a1, a2)
+    script = tmp_path / 'dist_count3.py'
+    script.write_text(code)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+                        '--master-port', '29613', str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and 'DIST_COUNT_OK' in out, out[-3000:]
+
+
 @pytest.mark.parametrize('env', [{'KPAL_READ_THREADS': '1'}, {'KPAL_READ_PIN': '0', 'KPAL_READ_THREADS': '3'}])
 def test_ingest_with_other_pool_settings(tmp_path, env):
     """The host copy pool (csrc/host_pool.hpp) is sized and bound when it is first used, once per process: a child process per
