@@ -9,11 +9,16 @@
 // library code; only the transport differs.
 //
 // Semantics kept: every call is a collective in program order; data is read from the device buffer after everything queued
-// on `stream` before the call has completed (hipStreamSynchronize) and the result is in place when the call returns -- a
-// legal, maximally synchronous execution of the stream semantics.  ncclSend / ncclRecv are only valid inside a group and run
+// on `stream` before the call has completed and the result is in place before anything queued on `stream` after it starts.
+// Two modes.  Default: the call itself waits for the stream (hipStreamSynchronize), moves the data and returns -- a legal,
+// maximally synchronous execution.  KPAL_FAKE_RCCL_ASYNC=1: the call returns at once, as RCCL's do -- it records an event on
+// the stream, queues a host function there that holds the stream until the operation is done, and hands the operation to the
+// communicator's worker thread, which waits for the event, moves the data on a private stream (KPAL_FAKE_RCCL_DELAY_MS:
+// after sleeping (rank + 1) x that long, so that the collective is in flight while the caller races ahead) and releases the
+// stream.  A missing event between the caller's streams around a collective then shows as wrong data, as it would with RCCL.  ncclSend / ncclRecv are only valid inside a group and run
 // at ncclGroupEnd (one send and one receive per peer and group).  Every wait is bounded (KPAL_FAKE_RCCL_TIMEOUT_S, default
-// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv makes
-// the stand-in lose a contribution / deliver the wrong block: the tests that use it must then FAIL (they are run that way once).
+// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv | early makes
+// the stand-in lose a contribution / deliver the wrong block / (async) release the stream before the data has moved: the tests that use it must then FAIL (they are run that way once).
 //
 //   hipcc -O2 -shared -fPIC -o libfake_rccl.so tests/native/fake_rccl.cpp
 #include <hip/hip_runtime.h>
@@ -26,7 +31,13 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +70,12 @@ double timeout_s()
 
 }  // namespace
 
+struct AsyncOp {
+    std::vector<hipEvent_t> events;            // recorded on the caller's streams at the call
+    std::function<ncclResult_t()> body;
+    uint64_t seq = 0;
+};
+
 struct ncclComm {
     int rank = 0, world = 1;
     Shared *sh = nullptr;
@@ -66,6 +83,18 @@ struct ncclComm {
     size_t slot_bytes = 0, map_bytes = 0;
     char name[64] = {0};
     uint8_t *slot(int r) const { return slots + (size_t)r * slot_bytes; }
+    // KPAL_FAKE_RCCL_ASYNC=1
+    bool async = false;
+    int device = 0;
+    long delay_ms = 0;
+    hipStream_t priv = nullptr;    // the worker's copies (non-blocking: never ordered against the caller's streams)
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    std::deque<AsyncOp> q;
+    bool stop = false;
+    uint64_t issued = 0, done = 0;
+    ncclResult_t async_error = ncclSuccess;
 };
 
 namespace {
@@ -139,6 +168,14 @@ bool combine_any(void *acc, const void *x, size_t n, ncclDataType_t t, ncclRedOp
     }
 }
 
+// device <-> shared memory: the caller's thread (synchronous mode) or the worker on its private stream
+hipError_t dev_copy(ncclComm *c, void *dst, const void *src, size_t n, hipMemcpyKind kind)
+{
+    if (!c->priv) return hipMemcpy(dst, src, n, kind);
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, c->priv);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->priv);
+}
+
 #define HIPOK(expr)                                                                          \
     do {                                                                                     \
         if ((expr) != hipSuccess) {                                                          \
@@ -148,16 +185,14 @@ bool combine_any(void *acc, const void *x, size_t n, ncclDataType_t t, ncclRedOp
     } while (0)
 
 // every rank's `count` elements at send -> their reduction over the ranks at recv of rank `root` (root < 0: of every rank)
-ncclResult_t reduce_impl(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, int root, ncclComm *c, hipStream_t stream)
+ncclResult_t reduce_impl(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, int root, ncclComm *c)
 {
     const size_t es = dtype_size(t);
-    if (!es) return ncclInvalidArgument;
-    HIPOK(hipStreamSynchronize(stream));
     const size_t per = c->slot_bytes / es;
     std::vector<uint8_t> acc;
     for (size_t off = 0; off < count; off += per) {
         const size_t n = count - off < per ? count - off : per;
-        if (n) HIPOK(hipMemcpy(c->slot(c->rank), (const uint8_t *)send + off * es, n * es, hipMemcpyDeviceToHost));
+        if (n) HIPOK(dev_copy(c, c->slot(c->rank), (const uint8_t *)send + off * es, n * es, hipMemcpyDeviceToHost));
         if (!barrier(c)) return ncclSystemError;
         if (n && (root < 0 || root == c->rank)) {
             // (KPAL_FAKE_RCCL_FAULT=reduce: the last rank's contribution is dropped)
@@ -165,10 +200,166 @@ ncclResult_t reduce_impl(const void *send, void *recv, size_t count, ncclDataTyp
             acc.assign(c->slot(0), c->slot(0) + n * es);
             for (int r = 1; r < c->world - (fault ? 1 : 0); ++r)
                 if (!combine_any(acc.data(), c->slot(r), n, t, op)) return ncclInvalidArgument;
-            HIPOK(hipMemcpy((uint8_t *)recv + off * es, acc.data(), n * es, hipMemcpyHostToDevice));
+            HIPOK(dev_copy(c, (uint8_t *)recv + off * es, acc.data(), n * es, hipMemcpyHostToDevice));
         }
         if (!barrier(c)) return ncclSystemError;
     }
+    return ncclSuccess;
+}
+
+ncclResult_t reduce_scatter_impl(const void *send, void *recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t op, ncclComm *c)
+{
+    const size_t es = dtype_size(t);
+    const size_t per = c->slot_bytes / es / (size_t)c->world;      // elements per destination and pass
+    std::vector<uint8_t> acc;
+    for (size_t off = 0; off < recvcount; off += per) {
+        const size_t n = recvcount - off < per ? recvcount - off : per;
+        for (int d = 0; d < c->world; ++d)
+            HIPOK(dev_copy(c, c->slot(c->rank) + (size_t)d * per * es, (const uint8_t *)send + ((size_t)d * recvcount + off) * es, n * es, hipMemcpyDeviceToHost));
+        if (!barrier(c)) return ncclSystemError;
+        const size_t mine = (size_t)c->rank * per * es;
+        acc.assign(c->slot(0) + mine, c->slot(0) + mine + n * es);
+        for (int r = 1; r < c->world; ++r)
+            if (!combine_any(acc.data(), c->slot(r) + mine, n, t, op)) return ncclInvalidArgument;
+        HIPOK(dev_copy(c, (uint8_t *)recv + off * es, acc.data(), n * es, hipMemcpyHostToDevice));
+        if (!barrier(c)) return ncclSystemError;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t all_gather_impl(const void *send, void *recv, size_t sendcount, ncclDataType_t t, ncclComm *c)
+{
+    const size_t es = dtype_size(t);
+    const size_t per = c->slot_bytes / es;
+    for (size_t off = 0; off < sendcount; off += per) {
+        const size_t n = sendcount - off < per ? sendcount - off : per;
+        HIPOK(dev_copy(c, c->slot(c->rank), (const uint8_t *)send + off * es, n * es, hipMemcpyDeviceToHost));
+        if (!barrier(c)) return ncclSystemError;
+        for (int r = 0; r < c->world; ++r)
+            HIPOK(dev_copy(c, (uint8_t *)recv + ((size_t)r * sendcount + off) * es, c->slot(r), n * es, hipMemcpyHostToDevice));
+        if (!barrier(c)) return ncclSystemError;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t group_impl(const std::vector<P2P> &ops, ncclComm *c)
+{
+    // a rank's slot is cut into one region per destination; the passes go on until the longest message of ANY rank is through
+    const size_t region = c->slot_bytes / (size_t)c->world;
+    uint64_t rounds = 0;
+    for (const P2P &o : ops) rounds = std::max<uint64_t>(rounds, (o.bytes + region - 1) / region);
+    c->sh->rounds[c->rank] = rounds;
+    if (!barrier(c)) return ncclSystemError;
+    for (int r = 0; r < c->world; ++r) rounds = std::max<uint64_t>(rounds, c->sh->rounds[r]);
+    if (!barrier(c)) return ncclSystemError;
+    for (uint64_t p = 0; p < rounds; ++p) {
+        for (const P2P &o : ops) {
+            const size_t off = (size_t)p * region;
+            if (!o.send || off >= o.bytes) continue;
+            const size_t n = o.bytes - off < region ? o.bytes - off : region;
+            HIPOK(dev_copy(c, c->slot(c->rank) + (size_t)o.peer * region, (const uint8_t *)o.buf + off, n, hipMemcpyDeviceToHost));
+        }
+        if (!barrier(c)) return ncclSystemError;
+        for (const P2P &o : ops) {
+            const size_t off = (size_t)p * region;
+            if (o.send || off >= o.bytes) continue;
+            const size_t n = o.bytes - off < region ? o.bytes - off : region;
+            // (KPAL_FAKE_RCCL_FAULT=recv: the data of the wrong region arrives -- the test of the tests, see test_gpu_dist.py)
+            static const bool fault = getenv("KPAL_FAKE_RCCL_FAULT") && !strcmp(getenv("KPAL_FAKE_RCCL_FAULT"), "recv");
+            const int from_region = fault ? (c->rank + 1) % c->world : c->rank;
+            HIPOK(dev_copy(c, (uint8_t *)o.buf + off, c->slot(o.peer) + (size_t)from_region * region, n, hipMemcpyHostToDevice));
+        }
+        if (!barrier(c)) return ncclSystemError;
+    }
+    return ncclSuccess;
+}
+
+// ---- when an operation runs
+struct WaitArg {
+    ncclComm *c;
+    uint64_t seq;
+};
+
+void hold_stream(void *p)      // host function on the caller's stream: returns when operation `seq` is done (no HIP call in here)
+{
+    WaitArg *a = (WaitArg *)p;
+    {
+        std::unique_lock<std::mutex> l(a->c->m);
+        a->c->cv_done.wait(l, [&] { return a->c->done >= a->seq; });
+    }
+    delete a;
+}
+
+void worker_main(ncclComm *c)
+{
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        AsyncOp op;
+        {
+            std::unique_lock<std::mutex> l(c->m);
+            c->cv.wait(l, [&] { return c->stop || !c->q.empty(); });
+            if (c->q.empty()) return;
+            op = std::move(c->q.front());
+            c->q.pop_front();
+        }
+        ncclResult_t r = ncclSuccess;
+        for (hipEvent_t e : op.events) {
+            if (hipEventSynchronize(e) != hipSuccess) r = ncclUnhandledCudaError;
+            (void)hipEventDestroy(e);
+        }
+        if (c->delay_ms > 0) usleep((useconds_t)(c->delay_ms * 1000 * (c->rank + 1)));
+        {
+            std::unique_lock<std::mutex> l(c->m);
+            if (r == ncclSuccess) r = c->async_error;
+        }
+        // (KPAL_FAKE_RCCL_FAULT=early: the stream is released BEFORE the data has moved -- what a missing stream dependency looks like)
+        static const bool early = getenv("KPAL_FAKE_RCCL_FAULT") && !strcmp(getenv("KPAL_FAKE_RCCL_FAULT"), "early");
+        if (early) {
+            {
+                std::unique_lock<std::mutex> l(c->m);
+                c->done = op.seq;
+            }
+            c->cv_done.notify_all();
+        }
+        if (r == ncclSuccess) r = op.body();
+        {
+            std::unique_lock<std::mutex> l(c->m);
+            if (r != ncclSuccess && c->async_error == ncclSuccess) {
+                c->async_error = r;
+                c->sh->failed.store(1);             // the other ranks must not wait for this one
+                fprintf(stderr, "fake_rccl: rank %d: operation %llu failed (%d)\n", c->rank, (unsigned long long)op.seq, (int)r);
+            }
+            c->done = op.seq;
+        }
+        c->cv_done.notify_all();
+    }
+}
+
+ncclResult_t submit(ncclComm *c, const std::vector<hipStream_t> &streams, std::function<ncclResult_t()> body)
+{
+    if (!c->async) {
+        for (hipStream_t s : streams) HIPOK(hipStreamSynchronize(s));
+        return body();
+    }
+    AsyncOp op;
+    op.body = std::move(body);
+    {
+        std::unique_lock<std::mutex> l(c->m);
+        if (c->async_error != ncclSuccess) return c->async_error;     // (what ncclCommGetAsyncError would report)
+        op.seq = ++c->issued;
+    }
+    for (hipStream_t s : streams) {
+        hipEvent_t e;
+        HIPOK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPOK(hipEventRecord(e, s));
+        op.events.push_back(e);
+        HIPOK(hipLaunchHostFunc(s, hold_stream, new WaitArg{c, op.seq}));
+    }
+    {
+        std::unique_lock<std::mutex> l(c->m);
+        c->q.push_back(std::move(op));
+    }
+    c->cv.notify_one();
     return ncclSuccess;
 }
 
@@ -225,6 +416,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     }
     if (!barrier(c)) return ncclSystemError;
     if (rank == 0) shm_unlink(c->name);        // everybody has it mapped: the name can go
+    const char *as = getenv("KPAL_FAKE_RCCL_ASYNC");
+    if (as && *as == '1') {
+        const char *dl = getenv("KPAL_FAKE_RCCL_DELAY_MS");
+        c->delay_ms = dl && *dl ? atol(dl) : 0;
+        if (hipGetDevice(&c->device) != hipSuccess || hipStreamCreateWithFlags(&c->priv, hipStreamNonBlocking) != hipSuccess) return ncclUnhandledCudaError;
+        c->async = true;
+        c->worker = std::thread(worker_main, c);
+    }
     *out = c;
     return ncclSuccess;
 }
@@ -232,9 +431,20 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
 ncclResult_t ncclCommDestroy(ncclComm_t c)
 {
     if (!c) return ncclSuccess;
+    ncclResult_t r = ncclSuccess;
+    if (c->async) {                            // what is queued runs first
+        {
+            std::unique_lock<std::mutex> l(c->m);
+            c->stop = true;
+        }
+        c->cv.notify_one();
+        c->worker.join();
+        (void)hipStreamDestroy(c->priv);
+        r = c->async_error;
+    }
     munmap((void *)c->sh, c->map_bytes);
     delete c;
-    return ncclSuccess;
+    return r;
 }
 
 const char *ncclGetErrorString(ncclResult_t r)
@@ -252,54 +462,29 @@ const char *ncclGetErrorString(ncclResult_t r)
 ncclResult_t ncclReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, int root, ncclComm_t c, hipStream_t stream)
 {
     if (!c || root < 0 || root >= c->world || g_group_depth) return ncclInvalidUsage;
-    return reduce_impl(send, recv, count, t, op, root, c, stream);
+    if (!dtype_size(t)) return ncclInvalidArgument;
+    return submit(c, {stream}, [=] { return reduce_impl(send, recv, count, t, op, root, c); });
 }
 
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t stream)
 {
     if (!c || g_group_depth) return ncclInvalidUsage;
-    return reduce_impl(send, recv, count, t, op, -1, c, stream);
+    if (!dtype_size(t)) return ncclInvalidArgument;
+    return submit(c, {stream}, [=] { return reduce_impl(send, recv, count, t, op, -1, c); });
 }
 
 ncclResult_t ncclReduceScatter(const void *send, void *recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t stream)
 {
     if (!c || g_group_depth) return ncclInvalidUsage;
-    const size_t es = dtype_size(t);
-    if (!es) return ncclInvalidArgument;
-    HIPOK(hipStreamSynchronize(stream));
-    const size_t per = c->slot_bytes / es / (size_t)c->world;      // elements per destination and pass
-    std::vector<uint8_t> acc;
-    for (size_t off = 0; off < recvcount; off += per) {
-        const size_t n = recvcount - off < per ? recvcount - off : per;
-        for (int d = 0; d < c->world; ++d)
-            HIPOK(hipMemcpy(c->slot(c->rank) + (size_t)d * per * es, (const uint8_t *)send + ((size_t)d * recvcount + off) * es, n * es, hipMemcpyDeviceToHost));
-        if (!barrier(c)) return ncclSystemError;
-        const size_t mine = (size_t)c->rank * per * es;
-        acc.assign(c->slot(0) + mine, c->slot(0) + mine + n * es);
-        for (int r = 1; r < c->world; ++r)
-            if (!combine_any(acc.data(), c->slot(r) + mine, n, t, op)) return ncclInvalidArgument;
-        HIPOK(hipMemcpy((uint8_t *)recv + off * es, acc.data(), n * es, hipMemcpyHostToDevice));
-        if (!barrier(c)) return ncclSystemError;
-    }
-    return ncclSuccess;
+    if (!dtype_size(t)) return ncclInvalidArgument;
+    return submit(c, {stream}, [=] { return reduce_scatter_impl(send, recv, recvcount, t, op, c); });
 }
 
 ncclResult_t ncclAllGather(const void *send, void *recv, size_t sendcount, ncclDataType_t t, ncclComm_t c, hipStream_t stream)
 {
     if (!c || g_group_depth) return ncclInvalidUsage;
-    const size_t es = dtype_size(t);
-    if (!es) return ncclInvalidArgument;
-    HIPOK(hipStreamSynchronize(stream));
-    const size_t per = c->slot_bytes / es;
-    for (size_t off = 0; off < sendcount; off += per) {
-        const size_t n = sendcount - off < per ? sendcount - off : per;
-        HIPOK(hipMemcpy(c->slot(c->rank), (const uint8_t *)send + off * es, n * es, hipMemcpyDeviceToHost));
-        if (!barrier(c)) return ncclSystemError;
-        for (int r = 0; r < c->world; ++r)
-            HIPOK(hipMemcpy((uint8_t *)recv + ((size_t)r * sendcount + off) * es, c->slot(r), n * es, hipMemcpyHostToDevice));
-        if (!barrier(c)) return ncclSystemError;
-    }
-    return ncclSuccess;
+    if (!dtype_size(t)) return ncclInvalidArgument;
+    return submit(c, {stream}, [=] { return all_gather_impl(send, recv, sendcount, t, c); });
 }
 
 ncclResult_t ncclGroupStart()
@@ -331,41 +516,15 @@ ncclResult_t ncclGroupEnd()
     if (ops.empty()) return ncclSuccess;
     ncclComm *c = ops[0].comm;
     bool sent[kMaxWorld] = {false}, received[kMaxWorld] = {false};
+    std::vector<hipStream_t> streams;
     for (const P2P &o : ops) {
         if (o.comm != c) return ncclInvalidUsage;
         bool *seen = o.send ? sent : received;
         if (seen[o.peer]) return ncclInvalidUsage;       // (one send and one receive per peer and group)
         seen[o.peer] = true;
-        HIPOK(hipStreamSynchronize(o.stream));
+        if (std::find(streams.begin(), streams.end(), o.stream) == streams.end()) streams.push_back(o.stream);
     }
-    // a rank's slot is cut into one region per destination; the passes go on until the longest message of ANY rank is through
-    const size_t region = c->slot_bytes / (size_t)c->world;
-    uint64_t rounds = 0;
-    for (const P2P &o : ops) rounds = std::max<uint64_t>(rounds, (o.bytes + region - 1) / region);
-    c->sh->rounds[c->rank] = rounds;
-    if (!barrier(c)) return ncclSystemError;
-    for (int r = 0; r < c->world; ++r) rounds = std::max<uint64_t>(rounds, c->sh->rounds[r]);
-    if (!barrier(c)) return ncclSystemError;
-    for (uint64_t p = 0; p < rounds; ++p) {
-        for (const P2P &o : ops) {
-            const size_t off = (size_t)p * region;
-            if (!o.send || off >= o.bytes) continue;
-            const size_t n = o.bytes - off < region ? o.bytes - off : region;
-            HIPOK(hipMemcpy(c->slot(c->rank) + (size_t)o.peer * region, (const uint8_t *)o.buf + off, n, hipMemcpyDeviceToHost));
-        }
-        if (!barrier(c)) return ncclSystemError;
-        for (const P2P &o : ops) {
-            const size_t off = (size_t)p * region;
-            if (o.send || off >= o.bytes) continue;
-            const size_t n = o.bytes - off < region ? o.bytes - off : region;
-            // (KPAL_FAKE_RCCL_FAULT=recv: the data of the wrong region arrives -- the test of the tests, see test_gpu_dist.py)
-            static const bool fault = getenv("KPAL_FAKE_RCCL_FAULT") && !strcmp(getenv("KPAL_FAKE_RCCL_FAULT"), "recv");
-            const int from_region = fault ? (c->rank + 1) % c->world : c->rank;
-            HIPOK(hipMemcpy((uint8_t *)o.buf + off, c->slot(o.peer) + (size_t)from_region * region, n, hipMemcpyHostToDevice));
-        }
-        if (!barrier(c)) return ncclSystemError;
-    }
-    return ncclSuccess;
+    return submit(c, streams, [=] { return group_impl(ops, c); });
 }
 
 }  // extern "C"

@@ -128,7 +128,7 @@ def _run_world(tmp_path, world, **extra_env):
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=1200)[0].decode(errors='replace'))
+            outs.append(p.communicate(timeout=600)[0].decode(errors='replace'))
     finally:
         for p in procs:
             if p.poll() is None:
@@ -136,34 +136,43 @@ def _run_world(tmp_path, world, **extra_env):
     return procs, outs
 
 
-@pytest.mark.parametrize('fault', ['reduce', 'recv'])
+@pytest.mark.parametrize('fault', ['reduce', 'recv', 'early'])
 def test_fake_rccl_world_test_has_teeth(tmp_path, fault):
-    """The test below must notice a transport that loses a rank's contribution to a reduce, or delivers the wrong block of the
-    mirrored-range exchange: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
-    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='30')
+    """The test below must notice a transport that loses a rank's contribution to a reduce, delivers the wrong block of the
+    mirrored-range exchange, or (asynchronous mode) lets the stream go on before the collective's data has arrived -- what a missing
+    dependency between streams amounts to: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
+    extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if fault == 'early' else {}
+    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='30', **extra)
     assert any(p.returncode != 0 for p in procs), outs
     assert any('AssertionError' in out for out in outs), outs
 
 
+@pytest.mark.parametrize('mode', ['sync', 'async'])
 @pytest.mark.parametrize('world', [2, 4])
-def test_library_comm_world_over_fake_rccl(tmp_path, world):
+def test_library_comm_world_over_fake_rccl(tmp_path, world, mode):
     """The library's kpal_comm_* protocol between W real processes on the one GPU of this box: RCCL refuses two ranks on one device,
     so KPAL_RCCL_LIBRARY points at a stand-in for the dozen entry points the library binds (tests/native/fake_rccl.cpp: shared
     memory between the processes, bounded waits).  Contexts, streams, events, kernels, offsets, the order of the collectives:
-    all real (tests/rccl_world_rank.py says what is compared with the oracle)."""
-    procs, outs = _run_world(tmp_path, world)
+    all real (tests/rccl_world_rank.py says what is compared with the oracle).  async: the stand-in's calls return at once, as
+    RCCL's do -- the stream is held by a host function until the communicator's worker thread has moved the data, (rank + 1) x 15 ms
+    late, so every collective is in flight while the caller goes on queueing work (the pipelined reduce: the next count)."""
+    extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if mode == 'async' else {}
+    procs, outs = _run_world(tmp_path, world, **extra)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and 'RCCL_WORLD_OK rank %d of %d' % (r, world) in out, 'rank %d:\n%s' % (r, out[-3000:])
 
 
-def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path):
+@pytest.mark.parametrize('mode', ['sync', 'async'])
+def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path, mode):
     """bench.py's N > 1 path with TWO real ranks AND the library's reduce modes: as test_bench_two_ranks_sharing_one_gpu, with the
     stand-in of tests/native/fake_rccl.cpp behind the library's communicator -- pipelined and serial in-library reduce, the torch
     reduce and the bin-range merge are each measured and each merged table is compared bin for bin with the single-stream count."""
     import json
     env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if mode == 'async':
+        env.update(KPAL_FAKE_RCCL_ASYNC='1', KPAL_FAKE_RCCL_DELAY_MS='10')
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29647', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--reads', '1500000',
+                        '--master-port', '29647' if mode == 'sync' else '29649', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--reads', '1500000',
                         '--no-cpu'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
