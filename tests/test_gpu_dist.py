@@ -142,7 +142,7 @@ def test_fake_rccl_world_test_has_teeth(tmp_path, fault):
     mirrored-range exchange, or (asynchronous mode) lets the stream go on before the collective's data has arrived -- what a missing
     dependency between streams amounts to: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
     extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if fault == 'early' else {}
-    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='30', **extra)
+    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='12', **extra)
     assert any(p.returncode != 0 for p in procs), outs
     assert any('AssertionError' in out for out in outs), outs
 
