@@ -104,6 +104,12 @@ python3 tools/skewdiag.py > "$OUT/skewdiag_k12.log" 2> /dev/null
 python3 tools/skewdiag.py --k 15 > "$OUT/skewdiag_k15.log" 2> /dev/null
 # ---- the hex pipeline (k = 12, six k-mers per three-byte item) next to the quads, same box
 for st in partition_quads partition_hex; do python3 "$B" --steps 10 --warmup 2 --no-extra --no-cpu --strategy $st > "$OUT/bench_k12_$st.json" 2> "$OUT/bench_k12_$st.err"; done
+# ---- LDS primitives (what an LDS atomic costs with and without bank conflicts)
+hipcc -O3 --offload-arch=gfx950 -o /tmp/lds_bench tools/lds_bench.hip 2> /dev/null && timeout 300 /tmp/lds_bench > "$OUT/lds_bench.log" 2>&1
+# ---- the N > 1 path of bench.py with 2, 3, 4 and 8 real ranks on this one GPU over the test stand-in for RCCL, synchronous and
+#      asynchronous calls (correctness only: merged_equals_single_stream of every merge mode)
+mkdir -p gpurun_out/r5x
+{ bash tools/multi_rank_one_gpu.sh; echo "# KPAL_FAKE_RCCL_ASYNC=1 KPAL_FAKE_RCCL_DELAY_MS=5"; KPAL_FAKE_RCCL_ASYNC=1 KPAL_FAKE_RCCL_DELAY_MS=5 bash tools/multi_rank_one_gpu.sh; } > "$OUT/multi_rank_one_gpu.log" 2>&1
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -delete
 ls -la "$OUT"; for f in "$OUT"/bench_k1[25]_n1.json "$OUT"/matrix*_bench.json; do echo "== $f"; head -c 1200 "$f"; echo; done
