@@ -108,7 +108,7 @@ for st in partition_quads partition_hex; do python3 "$B" --steps 10 --warmup 2 -
 hipcc -O3 --offload-arch=gfx950 -o /tmp/lds_bench tools/lds_bench.hip 2> /dev/null && timeout 300 /tmp/lds_bench > "$OUT/lds_bench.log" 2>&1
 # ---- the N > 1 path of bench.py with 2, 3, 4 and 8 real ranks on this one GPU over the test stand-in for RCCL, synchronous and
 #      asynchronous calls (correctness only: merged_equals_single_stream of every merge mode)
-mkdir -p gpurun_out/r5x
+mkdir -p gpurun_out/multi_rank
 { bash tools/multi_rank_one_gpu.sh; echo "# KPAL_FAKE_RCCL_ASYNC=1 KPAL_FAKE_RCCL_DELAY_MS=5"; KPAL_FAKE_RCCL_ASYNC=1 KPAL_FAKE_RCCL_DELAY_MS=5 bash tools/multi_rank_one_gpu.sh; } > "$OUT/multi_rank_one_gpu.log" 2>&1
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find "$OUT" -name '*.db' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*counter_collection.csv' -delete
