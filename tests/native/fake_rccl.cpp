@@ -17,8 +17,8 @@
 // after sleeping (rank + 1) x that long, so that the collective is in flight while the caller races ahead) and releases the
 // stream.  A missing event between the caller's streams around a collective then shows as wrong data, as it would with RCCL.  ncclSend / ncclRecv are only valid inside a group and run
 // at ncclGroupEnd (one send and one receive per peer and group).  Every wait is bounded (KPAL_FAKE_RCCL_TIMEOUT_S, default
-// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv | early makes
-// the stand-in lose a contribution / deliver the wrong block / (async) release the stream before the data has moved: the tests that use it must then FAIL (they are run that way once).
+// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv | early | stall
+// makes the stand-in lose a contribution / deliver the wrong block / (async) release the stream before the data has moved / hang: the tests that use it must then FAIL (they are run that way once).
 //
 //   hipcc -O2 -shared -fPIC -o libfake_rccl.so tests/native/fake_rccl.cpp
 #include <hip/hip_runtime.h>
@@ -274,6 +274,16 @@ ncclResult_t group_impl(const std::vector<P2P> &ops, ncclComm *c)
     return ncclSuccess;
 }
 
+// (KPAL_FAKE_RCCL_FAULT=stall: from its fourth operation on the LAST rank never moves again -- a hung collective: the other ranks
+// wait at their barriers (for KPAL_FAKE_RCCL_TIMEOUT_S), the caller's stream of every rank stands still)
+void maybe_stall(ncclComm *c)
+{
+    static const bool stall = getenv("KPAL_FAKE_RCCL_FAULT") && !strcmp(getenv("KPAL_FAKE_RCCL_FAULT"), "stall");
+    static std::atomic<uint32_t> ops{0};
+    if (stall && c->rank == c->world - 1 && ops.fetch_add(1) >= 3)
+        for (;;) pause();
+}
+
 // ---- when an operation runs
 struct WaitArg {
     ncclComm *c;
@@ -321,6 +331,7 @@ void worker_main(ncclComm *c)
             }
             c->cv_done.notify_all();
         }
+        maybe_stall(c);
         if (r == ncclSuccess) r = op.body();
         {
             std::unique_lock<std::mutex> l(c->m);
@@ -339,6 +350,7 @@ ncclResult_t submit(ncclComm *c, const std::vector<hipStream_t> &streams, std::f
 {
     if (!c->async) {
         for (hipStream_t s : streams) HIPOK(hipStreamSynchronize(s));
+        maybe_stall(c);
         return body();
     }
     AsyncOp op;

@@ -184,3 +184,28 @@ def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path, mode):
     assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
     for mode in ('pipelined_reduce', 'serial_reduce', 'torch_reduce', 'range_merge'):
         assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['checksum_ok'] is True, mode
+
+
+@pytest.mark.parametrize('mode', ['sync', 'async'])
+def test_bench_supervisors_restart_after_a_hung_collective(tmp_path, mode):
+    """A collective of the library's communicator that never completes, with REAL GPU workers: the last rank of two stops inside its
+    fourth operation (KPAL_FAKE_RCCL_FAULT=stall; async: its stream stands still behind the operation, sync: its host thread does),
+    the other waits for it.  The supervisors must notice (KPAL_BENCH_RUN_TIMEOUT), end both workers -- one of them with work queued
+    on the GPU that will never run --, start fresh ones in the conservative mode (torch reduce, no library communicator) and rank 0
+    must print ONE verified line that says so."""
+    import json
+    env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0',
+               KPAL_FAKE_RCCL_FAULT='stall', KPAL_FAKE_RCCL_TIMEOUT_S='600', KPAL_BENCH_RUN_TIMEOUT='25')
+    if mode == 'async':
+        env.update(KPAL_FAKE_RCCL_ASYNC='1')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29651' if mode == 'sync' else '29653', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--reads', '1500000', '--no-cpu'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['attempt'] == 2 and line['reduce_mode'] == 'torch_serial' and line['reduce_via'] == 'torch'
+    assert 'did not finish within' in line['fallback_reason'] or 'gave up' in line['fallback_reason'], line['fallback_reason']
+    assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True and line['n_gpus'] == 2
