@@ -17,8 +17,9 @@
 // after sleeping (rank + 1) x that long, so that the collective is in flight while the caller races ahead) and releases the
 // stream.  A missing event between the caller's streams around a collective then shows as wrong data, as it would with RCCL.  ncclSend / ncclRecv are only valid inside a group and run
 // at ncclGroupEnd (one send and one receive per peer and group).  Every wait is bounded (KPAL_FAKE_RCCL_TIMEOUT_S, default
-// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv | early | stall
-// makes the stand-in lose a contribution / deliver the wrong block / (async) release the stream before the data has moved / hang: the tests that use it must then FAIL (they are run that way once).
+// 120): a rank that never arrives turns into ncclSystemError on the others, not a hang.  KPAL_FAKE_RCCL_FAULT = reduce | recv | early | stall | init
+// makes the stand-in lose a contribution / deliver the wrong block / (async) release the stream before the data has moved / hang in a
+// collective / hang in ncclCommInitRank: the tests that use it must then FAIL (they are run that way once).
 //
 //   hipcc -O2 -shared -fPIC -o libfake_rccl.so tests/native/fake_rccl.cpp
 #include <hip/hip_runtime.h>
@@ -390,6 +391,9 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int rank)
 {
     if (!out || nranks < 1 || nranks > kMaxWorld || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    // (KPAL_FAKE_RCCL_FAULT=init: the last rank never joins -- a bootstrap that hangs: the others wait in here for KPAL_FAKE_RCCL_TIMEOUT_S)
+    if (getenv("KPAL_FAKE_RCCL_FAULT") && !strcmp(getenv("KPAL_FAKE_RCCL_FAULT"), "init") && nranks > 1 && rank == nranks - 1)
+        for (;;) pause();
     if (memchr(id.internal, 0, sizeof(id.internal)) == nullptr || strncmp(id.internal, "/kpal_fake_rccl_", 16) != 0) return ncclInvalidArgument;
     ncclComm *c = new ncclComm;
     c->rank = rank;

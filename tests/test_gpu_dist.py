@@ -209,3 +209,23 @@ def test_bench_supervisors_restart_after_a_hung_collective(tmp_path, mode):
     assert line['attempt'] == 2 and line['reduce_mode'] == 'torch_serial' and line['reduce_via'] == 'torch'
     assert 'did not finish within' in line['fallback_reason'] or 'gave up' in line['fallback_reason'], line['fallback_reason']
     assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True and line['n_gpus'] == 2
+
+
+def test_bench_comm_init_that_never_returns(tmp_path):
+    """ncclCommInitRank of the library's communicator hangs on every rank (the last rank never joins: KPAL_FAKE_RCCL_FAULT=init).  It is
+    time-boxed on its own (KPAL_BENCH_COMM_INIT_TIMEOUT): the workers give up with the reason, the supervisors start the
+    conservative attempt, rank 0 prints one verified line."""
+    import json
+    env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0',
+               KPAL_FAKE_RCCL_FAULT='init', KPAL_FAKE_RCCL_TIMEOUT_S='600', KPAL_BENCH_COMM_INIT_TIMEOUT='8')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29659', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--reads', '1500000', '--no-cpu'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['attempt'] == 2 and line['reduce_mode'] == 'torch_serial'
+    assert 'kpal_comm_init' in line['fallback_reason'] or 'gave up' in line['fallback_reason'], line['fallback_reason']
+    assert line['merged_equals_single_stream'] is True and line['checksum_ok'] is True
