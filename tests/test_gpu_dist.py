@@ -186,7 +186,7 @@ def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path, mode):
         assert line['extra'][mode]['merged_equals_single_stream'] is True and line['extra'][mode]['checksum_ok'] is True, mode
 
 
-@pytest.mark.parametrize('mode', ['sync', 'async'])
+@pytest.mark.parametrize('mode', ['async'])      # ('sync' passes too: the host thread hangs inside the call instead of the stream; 30 s more)
 def test_bench_supervisors_restart_after_a_hung_collective(tmp_path, mode):
     """A collective of the library's communicator that never completes, with REAL GPU workers: the last rank of two stops inside its
     fourth operation (KPAL_FAKE_RCCL_FAULT=stall; async: its stream stands still behind the operation, sync: its host thread does),
