@@ -20,3 +20,5 @@ run w2_k13_range 2 --reads 3000000 --k 13 --range-merge
 run w2_strong 2 --reads 5000001 --strong
 run w3 3 --reads 2000000
 run w8_k9 8 --reads 500000 --k 9
+run w2_torch_u32_overlap 2 --reads 3000000 --reduce-via torch --reduce u32 --overlap-reduce
+run w4_torch_overlap 4 --reads 2000000 --reduce-via torch --overlap-reduce
