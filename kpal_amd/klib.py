@@ -29,10 +29,20 @@ import numpy as np
 
 from . import _native, metrics
 
-try:                      # the C gatherer of from_sequences (csrc/kpal_join.c; built by __graft_entry__.build()); without it the
-    from . import _kpal_join   # sequences are joined by the interpreter -- same stream, ~3 x slower for lists of short reads
-except ImportError:       # pragma: no cover
-    _kpal_join = None
+# The C gatherer of from_sequences (built by __graft_entry__.build()); without one the sequences are joined by the interpreter -- same
+# stream, ~3 x slower for lists of short reads.  Two generations with one contract: hostext/kpal_gather.c walks the list's objects
+# on several threads as well as copying them, csrc/kpal_join.c walks them on one (KPAL_GATHERER=join selects it: A/B, cross-check).
+_kpal_join = None
+if os.environ.get('KPAL_GATHERER', 'gather') != 'join':
+    try:
+        from . import _kpal_gather as _kpal_join
+    except ImportError:       # pragma: no cover
+        pass
+if _kpal_join is None:
+    try:
+        from . import _kpal_join
+    except ImportError:       # pragma: no cover
+        _kpal_join = None
 
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
 _GATHER_BYTES = 64 << 20  # page-locked gather buffer of from_sequences

@@ -658,3 +658,49 @@ def test_fake_rccl_stand_in_covers_what_the_library_binds(tmp_path):
     out = subprocess.run(['nm', '-D', '--defined-only', lib], check=True, stdout=subprocess.PIPE).stdout.decode()
     exported = set(re.findall(r' T (nccl[A-Za-z]+)', out))
     assert bound <= exported, bound - exported
+
+
+def test_the_two_gatherers_agree(built):
+    """kpal_amd._kpal_gather (hostext/kpal_gather.c: walk and copies on several threads) against kpal_amd._kpal_join (csrc/kpal_join.c:
+    the walk on one thread), the same calls on random lists and tuples of str / bytes / bytearray -- with latin-1 text, text beyond
+    latin-1, memoryviews (items neither reads), empty items, long items -- at capacities from one byte to everything and 1..16
+    threads: the same (next, nbytes, status) and the same bytes, through the caller's loop to the end of every list."""
+    import random
+    from kpal_amd import _kpal_gather, _kpal_join
+    rnd = random.Random(5)
+
+    def item():
+        r, n = rnd.random(), rnd.choice([0, 1, 2, 5, 31, 150, 150, 150, 151, 400, 5000])
+        body = ''.join(rnd.choice('ACGTNacgt') for _ in range(n))
+        if r < 0.4:
+            return body
+        if r < 0.7:
+            return body.encode()
+        if r < 0.8:
+            return bytearray(body.encode())
+        if r < 0.83:
+            return 'AC\xe9GT'
+        if r < 0.86:
+            return 'ACΔGT'
+        if r < 0.88:
+            return memoryview(body.encode())
+        return body
+    calls = 0
+    for trial in range(30):
+        seq = [item() for _ in range(rnd.choice([0, 1, 3, 50, 700, 5000, 9000]))]
+        if trial & 1:
+            seq = tuple(seq)
+        cap = rnd.choice([1, 10, 200, 4096, 100000, 3000000])
+        threads = rnd.choice([1, 2, 3, 8, 16])
+        a, b = np.full(cap + 8, 7, dtype=np.uint8), np.full(cap + 8, 7, dtype=np.uint8)
+        pos = 0
+        while pos <= len(seq):
+            ra = _kpal_join.gather(seq, pos, a.ctypes.data, cap, threads)
+            rb = _kpal_gather.gather(seq, pos, b.ctypes.data, cap, threads)
+            assert ra == rb and np.array_equal(a, b), (trial, pos, ra, rb)
+            calls += 1
+            nxt, _, status = ra
+            if status == 0:
+                break
+            pos = nxt + 1 if (status == 2 or nxt == pos) else nxt
+    assert calls > 500

@@ -1,0 +1,12 @@
+import sys, time, os
+sys.path.insert(0, '.')
+import numpy as np
+from kpal_amd import klib, _native
+import oracle
+n = 8_000_000
+buf = oracle.synth_reads(2, 0, n, 150)
+flat = bytes(buf)
+t = time.perf_counter(); seqs = [flat[i * 151:i * 151 + 150].decode('ascii') for i in range(n)]; print('built %d str in %.1f s' % (n, time.perf_counter() - t))
+for rep in range(3):
+    t = time.perf_counter(); p = klib.Profile.from_sequences(seqs, 12); dt = time.perf_counter() - t
+    print(os.environ.get('KPAL_GATHERER', 'gather'), 'from_sequences %d str: %.1f ms  %.2f Gbases/s  (total %d)' % (n, dt * 1e3, n * 150 / dt / 1e9, int(p.total)))
