@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Profile.from_sequences on a LIST of 8 million 150-base str objects (k = 12), three calls: what the host-side gatherer costs per read.
+KPAL_GATHERER=join selects the first-generation gatherer (csrc/kpal_join.c) for the A/B (profiles/r5/seqbench.log).  Run on the GPU box."""
 import sys, time, os
 sys.path.insert(0, '.')
 import numpy as np
