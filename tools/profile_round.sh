@@ -96,6 +96,7 @@ python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_vec" "$OUT/pmc_write_vec" 0
 cd "$ROOT"
 python3 tools/clibench.py --gb 8 > "$OUT/clibench.json" 2> "$OUT/clibench.err"
 python3 tools/hostbench.py --reads 20000000 2>&1 | head -8 > "$OUT/hostbench.log"
+for g in join gather; do KPAL_GATHERER=$g python3 tools/seqbench.py 2>&1 | grep -v amdgpu; done > "$OUT/seqbench.log"
 python3 tools/clibench.py --by-record > "$OUT/clibench_by_record.json" 2> "$OUT/clibench_by_record.err"
 # ---- skewed inputs
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
