@@ -4,6 +4,7 @@
 #include "kpal_host.hpp"
 
 #include "vec_kernels.hpp"
+#include "matrix_all_kernels.hpp"
 #include "gram_kernels.hpp"
 #include "option_kernels.hpp"
 #include "stat_kernels.hpp"
@@ -385,8 +386,30 @@ int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, 
     // the register-tile kernel (A/B timing, cross-check)
     static const bool allow_super = [] { const char *e = getenv("KPAL_MATRIX_SUPER"); return !e || atoi(e) != 0; }();
     const bool super = allow_super && P > 8 && tiled;
+    // multiset 'prod' of 17..64 profiles: every profile staged once per bin range (matrix_all_kernels.hpp; KPAL_MATRIX_ALL=0
+    // forces the super-tile kernels)
+    static const bool allow_all = [] { const char *e = getenv("KPAL_MATRIX_ALL"); return !e || atoi(e) != 0; }();
+    static const bool allow_rdiff_all = [] { const char *e = getenv("KPAL_MATRIX_RDIFF"); return !e || atoi(e) != 0; }();
     unsigned gx;
-    if (super) {
+    bool all_done = false;
+    if (super && allow_all && allow_rdiff_all && metric == 0 && P > 16 && P <= 64) {
+        const bool wide = P > 32;
+        gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / kSuperBins, (uint64_t)ctx->num_cu * (wide ? 1 : 4)));
+        CHK(ensure(ctx, ctx->scratch[3], 16));
+        CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
+        Partial *pp = (Partial *)ctx->partials.p;
+        uint32_t *big = (uint32_t *)ctx->scratch[3].p;
+        HIPCHK(hipMemsetAsync(big, 0, sizeof(uint32_t), ctx->stream));
+        HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));   // (.s / .m of a slot come from different threads)
+        if (wide) LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<16>), dim3(gx), dim3(1024), prof, P, n, pp, big);
+        else LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<8>), dim3(gx), dim3(256), prof, P, n, pp, big);
+        uint32_t saw_big = 0;
+        HIPCHK(hipMemcpyAsync(&saw_big, big, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        all_done = saw_big == 0;
+    }
+    if (all_done) {
+    } else if (super) {
         const int sside = (P + 15) / 16;
         std::vector<int2> supers;
         for (int si = 0; si < sside; ++si)
