@@ -392,21 +392,33 @@ int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, 
     static const bool allow_rdiff_all = [] { const char *e = getenv("KPAL_MATRIX_RDIFF"); return !e || atoi(e) != 0; }();
     unsigned gx;
     bool all_done = false;
-    if (super && allow_all && allow_rdiff_all && metric == 0 && P > 16 && P <= 64) {
+    if (super && allow_all && allow_rdiff_all && metric <= 1 && P > 16 && P <= 64) {
         const bool wide = P > 32;
-        gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / kSuperBins, (uint64_t)ctx->num_cu * (wide ? 1 : 4)));
-        CHK(ensure(ctx, ctx->scratch[3], 16));
+        gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n / 128, (uint64_t)ctx->num_cu * (wide ? 1 : 4)));
+        CHK(ensure(ctx, ctx->scratch[3], 32));
         CHK(ensure(ctx, ctx->partials, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial)));
         Partial *pp = (Partial *)ctx->partials.p;
         uint32_t *big = (uint32_t *)ctx->scratch[3].p;
-        HIPCHK(hipMemsetAsync(big, 0, sizeof(uint32_t), ctx->stream));
+        HIPCHK(hipMemsetAsync(big, 0, 32, ctx->stream));
         HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));   // (.s / .m of a slot come from different threads)
-        if (wide) LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<16>), dim3(gx), dim3(1024), prof, P, n, pp, big);
-        else LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<8>), dim3(gx), dim3(256), prof, P, n, pp, big);
+        if (metric == 0) {
+            if (wide) LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<16, kMatrixAllBins, kMatrixAllUnits>), dim3(gx), dim3(1024 / kMatrixAllUnits), prof, P, n, pp, big);
+            else LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<8, 64, 1>), dim3(gx), dim3(256), prof, P, n, pp, big);
+        } else {
+            if (wide) LAUNCH(ctx, "matrix_rsum_all", (matrix_rsum_all_kernel<16, 64>), dim3(gx), dim3(1024), prof, P, n, pp, big);
+            else LAUNCH(ctx, "matrix_rsum_all", (matrix_rsum_all_kernel<8, 64>), dim3(gx), dim3(256), prof, P, n, pp, big);
+        }
         uint32_t saw_big = 0;
         HIPCHK(hipMemcpyAsync(&saw_big, big, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         all_done = saw_big == 0;
+#if defined(KPAL_MALL_CLOCK)
+        {
+            unsigned long long clk[4] = {0, 0, 0, 0};
+            HIPCHK(hipMemcpy(clk, big, sizeof(clk), hipMemcpyDeviceToHost));
+            fprintf(stderr, "matrix_all: %llu shader cycles in %.1f us = %.0f MHz\n", clk[1], (double)clk[2] / 100.0, 100.0 * (double)clk[1] / (double)clk[2]);
+        }
+#endif
     }
     if (all_done) {
     } else if (super) {

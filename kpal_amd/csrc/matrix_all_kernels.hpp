@@ -21,21 +21,34 @@
 
 namespace kpal {
 
-template <int S>
+#if !defined(KPAL_MALL_BINS)
+#define KPAL_MALL_BINS 64
+#endif
+#if !defined(KPAL_MALL_UNITS)
+#define KPAL_MALL_UNITS 1
+#endif
+constexpr int kMatrixAllBins = KPAL_MALL_BINS;        // bins of a stage at 33..64 profiles (64 or 128; A/B builds)
+constexpr int kMatrixAllUnits = KPAL_MALL_UNITS;      // slots a thread works through at 33..64 profiles (1: 1024 threads, 2: 512)
+
+template <int S, int B, int U>
 struct MatrixAllGeometry {
     static constexpr int kRows = 4 * S;                  // staged rows (profiles, clamped to P - 1)
-    static constexpr int kThreads = 4 * S * S;
     static constexpr int kOff = S * (S - 1) / 2;         // off-diagonal 4 x 4 tiles
-    static constexpr int kSlots = kOff + S / 2;
-    static constexpr int kPieces = kRows * 32;           // 16-byte pieces of a stage
-    static constexpr int kLoads = (kPieces + kThreads - 1) / kThreads;
+    static constexpr int kSlots = kOff + S / 2;          // = S^2 / 2
+    static constexpr int kThreads = 8 * kSlots / U;
+    static constexpr int kRowPieces = B / 2;             // 16-byte pieces (two bins) of a staged row
+    static constexpr int kPieces = kRows * kRowPieces;
+    static constexpr int kLoads = kPieces / kThreads;
+    static constexpr int kMaskWords = B / 64;
+    static constexpr int kPairs = kRows * (kRows - 1) / 2;
+    static constexpr int kPairsPerThread = (kPairs + kThreads - 1) / kThreads;
 };
 
 // slot -> blocks (xb, yb): off-diagonal tile (xb > yb) in lexicographic order, then the diagonal slots (xb = 2q, yb = 2q + 1)
 template <int S>
 __device__ __forceinline__ void matrix_all_slot(int slot, int &xb, int &yb, bool &diag)
 {
-    constexpr int OFF = MatrixAllGeometry<S>::kOff;
+    constexpr int OFF = S * (S - 1) / 2;
     diag = slot >= OFF;
     if (diag) {
         xb = 2 * (slot - OFF);
@@ -48,163 +61,437 @@ __device__ __forceinline__ void matrix_all_slot(int slot, int &xb, int &yb, bool
     }
 }
 
-// SUM = false: multiset 'prod' as | 1/(y+1) - 1/(x+1) | (see matrix_rdiff_kernel for the identity and its accuracy bound);
-// the staged values are the reciprocals.  A count >= kRdiffMaxCount (or negative) raises *big: the caller reruns the
-// pair-of-counts kernel.
-// partial layout: that of the super-tile kernels -- [tile t = ti (ti + 1) / 2 + tj][entry a * 4 + b][group], .s from the
-// slot's lane 0, .m (bins seen - bins where both are zero) from thread (i, j).
-template <int S>
-__global__ __launch_bounds__(4 * S * S) void matrix_rdiff_all_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
-                                                                      Partial *__restrict__ partials, uint32_t *__restrict__ big)
+// the terms of one slot and 16 bins: DIAG = false: the 16 pairs x[a] : y[b]; true: the six pairs inside x and the six inside y
+template <bool DIAG>
+__device__ __forceinline__ void matrix_all_terms(double (&s)[4][4], const double2 (&rx)[4], const double2 (&ry)[4])
 {
-    using G = MatrixAllGeometry<S>;
-    constexpr int R = G::kRows, NT = G::kThreads;
-    __shared__ __attribute__((aligned(16))) double rstage[2][R][kSuperBins];
-    __shared__ unsigned long long zmask[2][R];
+    if constexpr (!DIAG) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                s[a][b] += fabs(rx[a].x - ry[b].x);
+                s[a][b] += fabs(rx[a].y - ry[b].y);
+            }
+    } else {
+#pragma unroll
+        for (int a = 1; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < a; ++b) {
+                s[a][b] += fabs(rx[a].x - rx[b].x);
+                s[a][b] += fabs(rx[a].y - rx[b].y);
+                s[b][a] += fabs(ry[a].x - ry[b].x);
+                s[b][a] += fabs(ry[a].y - ry[b].y);
+            }
+    }
+}
+
+// Multiset 'prod' as | 1/(y+1) - 1/(x+1) | (see matrix_rdiff_kernel for the identity and its accuracy bound); the staged
+// values are the reciprocals.  A count >= kRdiffMaxCount (or negative) raises *big: the caller reruns the pair-of-counts kernel.
+// B bins per stage; U slots per thread (thread slot q works through the slots q, q + S^2 / (2 U), ...: U = 2 halves the
+// waves and doubles their registers -- room to have the LDS reads of the next step in flight during the arithmetic of this one).
+// partial layout: that of the super-tile kernels -- [tile t = ti (ti + 1) / 2 + tj][entry a * 4 + b][group]; .s from the
+// slot's lane 0, .m (bins seen - bins where both are zero) from the thread that holds the pair's zero masks.
+template <int S, int B, int U>
+__global__ __launch_bounds__((MatrixAllGeometry<S, B, U>::kThreads), S == 16 ? 4 / U : 3) void matrix_rdiff_all_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                                                                   Partial *__restrict__ partials, uint32_t *__restrict__ big)
+{
+    using G = MatrixAllGeometry<S, B, U>;
+    constexpr int R = G::kRows, NT = G::kThreads, NL = G::kLoads, RP = G::kRowPieces, MW = G::kMaskWords, ZP = G::kPairsPerThread;
+    static_assert(G::kPieces % NT == 0 && (B == 64 || B == 128) && G::kSlots % U == 0, "geometry");
+    __shared__ __attribute__((aligned(16))) double rstage[2][R][B];
+    __shared__ unsigned long long zmask[2][R][MW];
     __shared__ double rtable[kRdiffTable];
     for (int i = threadIdx.x; i < kRdiffTable; i += NT) rtable[i] = rcp_counts((double)i + 1.0);
     const uint32_t group = blockIdx.x, ngroups = gridDim.x;
+    const int tslot = threadIdx.x >> 3, l = threadIdx.x & 7;
+    const int side = (P + 3) / 4;
+    int xb[U], yb[U];
+    bool diag[U];
+    bool mine = false;
+#pragma unroll
+    for (int v = 0; v < U; ++v) {
+        matrix_all_slot<S>(tslot + v * (G::kSlots / U), xb[v], yb[v], diag[v]);
+        mine |= xb[v] < side;
+    }
+    // (mine: one of the thread's slots holds a pair of real profiles; the others work on clamped rows and are never written)
+    const int flip = (tslot >> 1) & 1;
+    double s[U][4][4];
+#pragma unroll
+    for (int v = 0; v < U; ++v)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s[v][a][b] = 0.0;
+    // term counts: thread t holds the pairs number t, t + NT, ... of the lower triangle (pair p = i (i - 1) / 2 + j, j < i)
+    int zi[ZP], zj[ZP];
+    uint32_t both_zero[ZP];
+#pragma unroll
+    for (int h = 0; h < ZP; ++h) {
+        const int p = min((int)threadIdx.x + NT * h, G::kPairs - 1);
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        zi[h] = i;
+        zj[h] = p - i * (i - 1) / 2;
+        both_zero[h] = 0u;
+    }
+    uint32_t hi_seen = 0;                              // OR of the counts' high words and of the low words >= kRdiffMaxCount
+    // loader: piece p = t + NT i is the 16 bytes (two bins) p % RP of staged row p / RP
+    const int64_t *src[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int p = (int)threadIdx.x + NT * i;
+        src[i] = prof + (uint64_t)min(p / RP, P - 1) * n + 2 * (p % RP) + (uint64_t)group * B;
+    }
+    __syncthreads();                                   // the table
+    // Staging a piece = two halves with the table's latency between them: `lookup` (after the piece's global load has landed:
+    // clamp the counts to the table, issue the two reads) and `store` (the reciprocals, the zero masks).  The arithmetic of the
+    // stage's last step runs between the two.  Counts past the table are rare (a wave-uniform test): their reciprocals are computed.
+    auto lookup = [&](const longlong2 &v, double2 &r) {
+        const uint32_t x = (uint32_t)v.x, y = (uint32_t)v.y;
+        r.x = rtable[min(x, (uint32_t)kRdiffTable - 1u)];
+        r.y = rtable[min(y, (uint32_t)kRdiffTable - 1u)];
+    };
+    auto store = [&](int buf, int i, const longlong2 &v, double2 r) {
+        const int p = (int)threadIdx.x + NT * i;
+        const int row = p / RP, col = p % RP;
+        // (a count with a high word, or >= 2^16, makes the launch void -- *big -- so only the low words are looked at)
+        const uint32_t x = (uint32_t)v.x, y = (uint32_t)v.y;
+        hi_seen |= (uint32_t)((unsigned long long)v.x >> 32) | (uint32_t)((unsigned long long)v.y >> 32) | ((x | y) & ~(uint32_t)(kRdiffMaxCount - 1));
+        if (__builtin_amdgcn_ballot_w64((x | y) >= (uint32_t)kRdiffTable) != 0) {   // wave-uniform, rare
+            if (x >= (uint32_t)kRdiffTable) r.x = rcp_counts((double)x + 1.0);
+            if (y >= (uint32_t)kRdiffTable) r.y = rcp_counts((double)y + 1.0);
+        }
+        *reinterpret_cast<double2 *>(&rstage[buf][row][2 * col]) = r;
+        // zero masks: the same permutation of the bins in every row
+        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(x == 0), z1 = __builtin_amdgcn_ballot_w64(y == 0);
+        if constexpr (B == 128) {                      // a wave = one row: word 0 the even bins, word 1 the odd ones
+            if ((threadIdx.x & 63) == 0) {
+                zmask[buf][row][0] = z0;
+                zmask[buf][row][1] = z1;
+            }
+        } else {                                       // a wave = two rows: bit c = bin 2c, bit 32 + c = bin 2c + 1
+            const unsigned long long mlo = (z0 & 0xFFFFFFFFull) | (z1 << 32), mhi = (z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull);
+            if ((threadIdx.x & 31) == 0) zmask[buf][row][0] = (threadIdx.x & 32) ? mhi : mlo;
+        }
+    };
+    const uint64_t chunks = n / B;
+    // (src[] runs ahead of the arithmetic: it always points at the next stage to request)
+    const uint64_t hop = (uint64_t)ngroups * B;
+    uint64_t creq = group;                             // the chunk src[] points at
+    auto request = [&](longlong2 (&dst)[NL]) {
+        if (creq < chunks) {                           // block-uniform
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+#if defined(KPAL_MALL_NOLOAD)   // ablation: everything but the global loads (1: a few repeating values, 2: scattered ones)
+                {
+                    const uint32_t h = ((uint32_t)threadIdx.x * 2654435761u) ^ ((uint32_t)creq * 0x9E3779B1u) ^ (uint32_t)(i * 0x85EBCA6Bu);
+                    dst[i] = KPAL_MALL_NOLOAD == 2 ? longlong2{(long long)((h >> 7) & 31), (long long)((h >> 19) & 31)}
+                                                   : longlong2{(long long)((threadIdx.x + creq) & 15), (long long)(creq & 7)};
+                }
+#else
+                dst[i] = *reinterpret_cast<const longlong2 *>(src[i]);
+#endif
+                src[i] += hop;
+            }
+        }
+        creq += ngroups;
+    };
+    // one step of the arithmetic: 16 bins (a double2 per lane) of the 4 + 4 rows of each of the thread's slots
+    auto step = [&](int cur, int u) {
+#if !defined(KPAL_MALL_NOCOMPUTE)
+        if (!mine) return;
+        const int off = 16 * (u ^ flip);
+#pragma unroll
+        for (int v = 0; v < U; ++v) {
+            const double *xrow = &rstage[cur][4 * xb[v]][2 * l], *yrow = &rstage[cur][4 * yb[v]][2 * l];
+            double2 rx[4], ry[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                rx[a] = *reinterpret_cast<const double2 *>(xrow + a * B + off);
+                ry[a] = *reinterpret_cast<const double2 *>(yrow + a * B + off);
+            }
+            if (!diag[v]) matrix_all_terms<false>(s[v], rx, ry);
+            else matrix_all_terms<true>(s[v], rx, ry);
+        }
+#endif
+    };
+#if defined(KPAL_MALL_CLOCK)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int STEPS = B / 16;
+    longlong2 next[NL];
+    uint64_t c = group;
+    uint64_t stages = 0;
+    request(next);
+    if (c < chunks) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            double2 r;
+            lookup(next[i], r);
+            store(0, i, next[i], r);
+        }
+    }
+    __syncthreads();
+    for (int cur = 0; c < chunks; c += ngroups, ++stages, cur ^= 1) {
+        const bool more = c + ngroups < chunks;        // block-uniform
+        request(next);                                 // the next stage's values: in flight during this stage's arithmetic
+#if !defined(KPAL_MALL_NOCOMPUTE) && !defined(KPAL_MALL_NOZMASK)
+        unsigned long long zr[ZP][MW], zc[ZP][MW];     // (read here, used after the first step: no wait of their own)
+#pragma unroll
+        for (int h = 0; h < ZP; ++h)
+#pragma unroll
+            for (int w = 0; w < MW; ++w) {
+                zr[h][w] = zmask[cur][zi[h]][w];
+                zc[h][w] = zmask[cur][zj[h]][w];
+            }
+#endif
+        step(cur, 0);
+#if !defined(KPAL_MALL_NOCOMPUTE) && !defined(KPAL_MALL_NOZMASK)
+#pragma unroll
+        for (int h = 0; h < ZP; ++h)
+#pragma unroll
+            for (int w = 0; w < MW; ++w) both_zero[h] += (uint32_t)__popcll(zr[h][w] & zc[h][w]);
+#endif
+#pragma unroll
+        for (int u = 1; u < STEPS - 1; ++u) step(cur, u);
+        double2 rnext[NL];
+#if defined(KPAL_MALL_NOPUT)   // ablation: no conversion, no LDS stores (the first stage's values stay)
+        const bool stage_it = more && next[0].x == 0x7fffffffffffffffll;
+#else
+        const bool stage_it = more;
+#endif
+        if (stage_it) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) lookup(next[i], rnext[i]);
+        }
+        step(cur, STEPS - 1);
+        if (stage_it) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) store(cur ^ 1, i, next[i], rnext[i]);
+        }
+        __syncthreads();
+    }
+#if defined(KPAL_MALL_CLOCK)   // diagnostic builds: shader cycles and 100 MHz ticks of workgroup 0's main loop behind *big
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<unsigned long long *>(big)[1] = __builtin_amdgcn_s_memtime() - clk0;
+        reinterpret_cast<unsigned long long *>(big)[2] = __builtin_amdgcn_s_memrealtime() - wall0;
+    }
+#endif
+    if (hi_seen) atomicOr(big, 1u);
+    // sums: reduction over the slot's eight lanes (fixed order), lane 0 writes .s
+#pragma unroll
+    for (int v = 0; v < U; ++v) {
+        const uint64_t tx = (uint64_t)xb[v] * (xb[v] + 1) / 2, ty = (uint64_t)yb[v] * (yb[v] + 1) / 2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double ps = s[v][a][b];
+#pragma unroll
+                for (int d = 4; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 8);
+                if (l != 0 || (diag[v] && a == b)) continue;
+                if (!diag[v]) {
+                    if (xb[v] < side) partials[((tx + yb[v]) * 16 + a * 4 + b) * ngroups + group].s = ps;
+                } else if (a > b) {                    // pair (a, b) of block xb
+                    if (xb[v] < side) partials[((tx + xb[v]) * 16 + a * 4 + b) * ngroups + group].s = ps;
+                } else {                               // s[a][b], a < b: pair (b, a) of block yb
+                    if (yb[v] < side) partials[((ty + yb[v]) * 16 + b * 4 + a) * ngroups + group].s = ps;
+                }
+            }
+    }
+    // term counts
+#pragma unroll
+    for (int h = 0; h < ZP; ++h) {
+        const int i = zi[h], j = zj[h];
+        if ((int)threadIdx.x + NT * h < G::kPairs && i < P) {
+            const int pti = i / 4, ptj = j / 4;
+            const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
+            partials[(t * 16 + (i % 4) * 4 + (j % 4)) * ngroups + group].m = stages * B - both_zero[h];
+        }
+    }
+}
+
+// Multiset 'sum', |x - y| / (x + y + 1), with the reciprocal of the denominator from a table in LDS (see matrix_rsum_kernel:
+// v_sad_u32, the table offset, one ds_read_b64, a conversion and one fused multiply-add per term) over the same slots; the
+// staged values are the counts as 32-bit integers, a lane takes 4 bins of a row per step (one ds_read_b128).  A count >=
+// kRsumTable / 2 anywhere raises *big and the caller reruns matrix_super_kernel<1>.
+template <int S, int B>
+__global__ __launch_bounds__((MatrixAllGeometry<S, B, 1>::kThreads), 4) void matrix_rsum_all_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
+                                                                                                  Partial *__restrict__ partials, uint32_t *__restrict__ big)
+{
+    using G = MatrixAllGeometry<S, B, 1>;
+    constexpr int R = G::kRows, NT = G::kThreads, NL = G::kLoads, RP = G::kRowPieces, MW = G::kMaskWords, ZP = G::kPairsPerThread;
+    static_assert(G::kPieces % NT == 0 && B == 64, "geometry");
+    __shared__ __attribute__((aligned(16))) uint32_t cstage[2][R][B];
+    __shared__ unsigned long long zmask[2][R][MW];
+    // The staged values are the counts TIMES EIGHT -- the byte offset of a table entry is then one v_add_u32 (a half-price
+    // instruction, tools/valu_bench.hip) instead of v_add_lshl_u32 -- and the table holds 1 / (8 (s + 1)): v_sad_u32 of two
+    // staged values is 8 |x - y|, and the power of two cancels exactly.
+    __shared__ double rtable[kRsumTable];
+    for (int i = threadIdx.x; i < kRsumTable; i += NT) rtable[i] = rcp_counts((double)i + 1.0) * 0.125;
+    const uint32_t group = blockIdx.x, ngroups = gridDim.x;
     const int slot = threadIdx.x >> 3, l = threadIdx.x & 7;
+    const int side = (P + 3) / 4;
     int xb, yb;
     bool diag;
     matrix_all_slot<S>(slot, xb, yb, diag);
-    const int side = (P + 3) / 4;
-    const bool mine = xb < side;                        // (yb < xb off the diagonal; a diagonal slot whose second block is past the end computes clamped rows nobody reads)
+    const bool mine = xb < side;
     const int flip = (slot >> 1) & 1;
     double s[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) s[a][b] = 0.0;
-    // term counts: thread t holds the pairs (i, jq + S m), m = 0..3, of row i = t / S
-    const int zi = threadIdx.x / S, zq = threadIdx.x % S;
-    uint32_t both_zero[4] = {0u, 0u, 0u, 0u};
-    bool saw_big = false;
-    // loader: piece p = t + NT i is the 16 bytes (two bins) p & 31 of staged row p >> 5: a wave reads two 512-byte runs
-    const int64_t *src[G::kLoads];
+    int zi[ZP], zj[ZP];
+    uint32_t both_zero[ZP];
 #pragma unroll
-    for (int i = 0; i < G::kLoads; ++i) {
-        const int p = (int)threadIdx.x + NT * i;
-        src[i] = prof + (uint64_t)min(p >> 5, P - 1) * n + 2 * (p & 31);
+    for (int h = 0; h < ZP; ++h) {
+        const int p = min((int)threadIdx.x + NT * h, G::kPairs - 1);
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        zi[h] = i;
+        zj[h] = p - i * (i - 1) / 2;
+        both_zero[h] = 0u;
     }
-    const int lhalf = (threadIdx.x >> 5) & 1, lcol = threadIdx.x & 31;
-    __syncthreads();                                   // the table
-    auto recip = [&](int64_t v, bool all_small) -> double {
-        if (all_small) return rtable[(uint32_t)v];
-        saw_big |= (unsigned long long)v >= kRdiffMaxCount;
-        return (unsigned long long)v < (unsigned long long)kRdiffTable ? rtable[(uint32_t)v & (kRdiffTable - 1)] : rcp_counts((double)(uint32_t)v + 1.0);
-    };
-    auto put = [&](int buf, int i, const longlong2 &v) {
+    uint32_t hi_seen = 0;                              // OR of the counts' high words and of the low words >= kRsumTable / 2
+    const int64_t *src[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
         const int p = (int)threadIdx.x + NT * i;
-        if (G::kPieces % NT != 0 && p >= G::kPieces) return;   // (whole half-waves)
-        const int row = p >> 5;
-        const bool all_small = __all((unsigned long long)v.x < (unsigned long long)kRdiffTable && (unsigned long long)v.y < (unsigned long long)kRdiffTable);
-        double2 r;
-        r.x = recip(v.x, all_small);
-        r.y = recip(v.y, all_small);
-        *reinterpret_cast<double2 *>(&rstage[buf][row][2 * lcol]) = r;
-        // zero masks: bit c = bin 2c, bit 32 + c = bin 2c + 1 (the same permutation of the bins in every row)
-        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(v.x == 0), z1 = __builtin_amdgcn_ballot_w64(v.y == 0);
-        if (lcol == 0) zmask[buf][row] = lhalf ? ((z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull)) : ((z0 & 0xFFFFFFFFull) | (z1 << 32));
+        src[i] = prof + (uint64_t)min(p / RP, P - 1) * n + 2 * (p % RP) + (uint64_t)group * B;
+    }
+    __syncthreads();                                   // the table
+    auto store = [&](int buf, int i, const longlong2 &v) {
+        const int p = (int)threadIdx.x + NT * i;
+        const int row = p / RP, col = p % RP;
+        const uint32_t x = (uint32_t)v.x, y = (uint32_t)v.y;
+        hi_seen |= (uint32_t)((unsigned long long)v.x >> 32) | (uint32_t)((unsigned long long)v.y >> 32) | ((x | y) & ~(uint32_t)(kRsumTable / 2 - 1));
+        // (masked: a larger count only ever costs a rerun, never an out-of-range read)
+        *reinterpret_cast<uint2 *>(&cstage[buf][row][2 * col]) = make_uint2((x & (uint32_t)(kRsumTable / 2 - 1)) << 3, (y & (uint32_t)(kRsumTable / 2 - 1)) << 3);
+        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(x == 0), z1 = __builtin_amdgcn_ballot_w64(y == 0);
+        const unsigned long long mlo = (z0 & 0xFFFFFFFFull) | (z1 << 32), mhi = (z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull);
+        if ((threadIdx.x & 31) == 0) zmask[buf][row][0] = (threadIdx.x & 32) ? mhi : mlo;
     };
-    const uint64_t chunks = n / kSuperBins;
-    auto request = [&](longlong2 (&dst)[G::kLoads], uint64_t chunk) {
-        if (chunk < chunks) {                          // block-uniform
+    const uint64_t chunks = n / B;
+    const uint64_t hop = (uint64_t)ngroups * B;
+    uint64_t creq = group;
+    auto request = [&](longlong2 (&dst)[NL]) {
+        if (creq < chunks) {                           // block-uniform
 #pragma unroll
-            for (int i = 0; i < G::kLoads; ++i) {
-                if (G::kPieces % NT != 0 && (int)threadIdx.x + NT * i >= G::kPieces) continue;
-                dst[i] = *reinterpret_cast<const longlong2 *>(src[i] + chunk * kSuperBins);
+            for (int i = 0; i < NL; ++i) {
+                dst[i] = *reinterpret_cast<const longlong2 *>(src[i]);
+                src[i] += hop;
             }
         }
+        creq += ngroups;
     };
-    auto compute = [&](int cur) {
-        {
-            const unsigned long long zr = zmask[cur][zi];
-            if (zr != 0) {
+    const char *tab = reinterpret_cast<const char *>(rtable);
+    auto term4 = [&](double &acc, const uint4 &x, const uint4 &y) {
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
-                for (int m = 0; m < 4; ++m) both_zero[m] += (uint32_t)__popcll(zr & zmask[cur][zq + S * m]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            uint32_t d;
+            asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(xs[e]), "v"(ys[e]));   // 8 |x - y|
+            const double r = *reinterpret_cast<const double *>(tab + (xs[e] + ys[e]));
+            acc = fma((double)d, r, acc);
         }
+    };
+    // one step: 32 bins (four per lane) of the slot's 4 + 4 rows
+    auto step = [&](int cur, int u) {
         if (!mine) return;
-        const double *xrow = &rstage[cur][4 * xb][2 * l], *yrow = &rstage[cur][4 * yb][2 * l];
+        const uint32_t *xrow = &cstage[cur][4 * xb][4 * l], *yrow = &cstage[cur][4 * yb][4 * l];
+        const int off = 32 * (u ^ flip);
+        uint4 cx[4], cy[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int off = 16 * (u ^ flip);
-            double2 rx[4], ry[4];
+        for (int a = 0; a < 4; ++a) {
+            cx[a] = *reinterpret_cast<const uint4 *>(xrow + a * B + off);
+            cy[a] = *reinterpret_cast<const uint4 *>(yrow + a * B + off);
+        }
+        if (!diag) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                rx[a] = *reinterpret_cast<const double2 *>(xrow + a * kSuperBins + off);
-                ry[a] = *reinterpret_cast<const double2 *>(yrow + a * kSuperBins + off);
-            }
-            if (!diag) {
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    // (one pair at a time: with the offsets of all 64 terms up front the registers run out; the other waves of the SIMD cover the reads)
+                    asm volatile("" : "+v"(cy[b].x), "+v"(cy[b].y), "+v"(cy[b].z), "+v"(cy[b].w));
+                    term4(s[a][b], cx[a], cy[b]);
+                }
+        } else {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        s[a][b] += fabs(rx[a].x - ry[b].x);
-                        s[a][b] += fabs(rx[a].y - ry[b].y);
-                    }
-            } else {
+            for (int a = 1; a < 4; ++a)
 #pragma unroll
-                for (int a = 1; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < a; ++b) {
-                        s[a][b] += fabs(rx[a].x - rx[b].x);
-                        s[a][b] += fabs(rx[a].y - rx[b].y);
-                        s[b][a] += fabs(ry[a].x - ry[b].x);
-                        s[b][a] += fabs(ry[a].y - ry[b].y);
-                    }
-            }
+                for (int b = 0; b < a; ++b) {
+                    asm volatile("" : "+v"(cx[b].x), "+v"(cx[b].y), "+v"(cx[b].z), "+v"(cx[b].w));
+                    term4(s[a][b], cx[a], cx[b]);
+                    asm volatile("" : "+v"(cy[b].x), "+v"(cy[b].y), "+v"(cy[b].z), "+v"(cy[b].w));
+                    term4(s[b][a], cy[a], cy[b]);
+                }
         }
     };
-    longlong2 next[G::kLoads];
+    constexpr int STEPS = B / 32;
+    longlong2 next[NL];
     uint64_t c = group;
     uint64_t stages = 0;
-    request(next, c);
+    request(next);
     if (c < chunks) {
 #pragma unroll
-        for (int i = 0; i < G::kLoads; ++i) put(0, i, next[i]);
+        for (int i = 0; i < NL; ++i) store(0, i, next[i]);
     }
     __syncthreads();
-    int cur = 0;
-    for (; c < chunks; c += ngroups, ++stages) {
+    for (int cur = 0; c < chunks; c += ngroups, ++stages, cur ^= 1) {
         const bool more = c + ngroups < chunks;        // block-uniform
-        request(next, c + ngroups);
-        compute(cur);
+        request(next);
+        unsigned long long zr[ZP][MW], zc[ZP][MW];
+#pragma unroll
+        for (int h = 0; h < ZP; ++h)
+#pragma unroll
+            for (int w = 0; w < MW; ++w) {
+                zr[h][w] = zmask[cur][zi[h]][w];
+                zc[h][w] = zmask[cur][zj[h]][w];
+            }
+        step(cur, 0);
+#pragma unroll
+        for (int h = 0; h < ZP; ++h)
+#pragma unroll
+            for (int w = 0; w < MW; ++w) both_zero[h] += (uint32_t)__popcll(zr[h][w] & zc[h][w]);
+#pragma unroll
+        for (int u = 1; u < STEPS; ++u) step(cur, u);
         if (more) {
 #pragma unroll
-            for (int i = 0; i < G::kLoads; ++i) put(cur ^ 1, i, next[i]);
+            for (int i = 0; i < NL; ++i) store(cur ^ 1, i, next[i]);
         }
         __syncthreads();
-        cur ^= 1;
     }
-    if (saw_big) atomicOr(big, 1u);
-    // sums: reduction over the slot's eight lanes (fixed order), lane 0 writes .s
-    const uint64_t tx = (uint64_t)xb * (xb + 1) / 2, ty = (uint64_t)yb * (yb + 1) / 2;
+    if (hi_seen) atomicOr(big, 1u);
+    {
+        const uint64_t tx = (uint64_t)xb * (xb + 1) / 2, ty = (uint64_t)yb * (yb + 1) / 2;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            double ps = s[a][b];
+            for (int b = 0; b < 4; ++b) {
+                double ps = s[a][b];
 #pragma unroll
-            for (int d = 4; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 8);
-            if (l != 0 || (diag && a == b)) continue;
-            if (!diag) {
-                if (mine) partials[((tx + yb) * 16 + a * 4 + b) * ngroups + group].s = ps;
-            } else if (a > b) {                        // pair (a, b) of block xb
-                if (xb < side) partials[((tx + xb) * 16 + a * 4 + b) * ngroups + group].s = ps;
-            } else {                                   // s[a][b], a < b: pair (b, a) of block yb
-                if (yb < side) partials[((ty + yb) * 16 + b * 4 + a) * ngroups + group].s = ps;
+                for (int d = 4; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 8);
+                if (l != 0 || (diag && a == b)) continue;
+                if (!diag) {
+                    if (xb < side) partials[((tx + yb) * 16 + a * 4 + b) * ngroups + group].s = ps;
+                } else if (a > b) {
+                    if (xb < side) partials[((tx + xb) * 16 + a * 4 + b) * ngroups + group].s = ps;
+                } else {
+                    if (yb < side) partials[((ty + yb) * 16 + b * 4 + a) * ngroups + group].s = ps;
+                }
             }
-        }
-    // term counts
+    }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int i = zi, j = zq + S * m;
-        if (j < i && i < P) {
+    for (int h = 0; h < ZP; ++h) {
+        const int i = zi[h], j = zj[h];
+        if ((int)threadIdx.x + NT * h < G::kPairs && i < P) {
             const int pti = i / 4, ptj = j / 4;
             const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
-            partials[(t * 16 + (i % 4) * 4 + (j % 4)) * ngroups + group].m = stages * kSuperBins - both_zero[m];
+            partials[(t * 16 + (i % 4) * 4 + (j % 4)) * ngroups + group].m = stages * B - both_zero[h];
         }
     }
 }

@@ -241,6 +241,29 @@ def test_matrix_super_tiles(ctx):
         assert close(ctx.distance_matrix(profs, k, 0)[i * (i - 1) // 2 + j], oracle.distance(profs[i], profs[j], k, metric=metric))
 
 
+def test_matrix_all_staged_once(ctx):
+    """The kernels that stage every profile once per bin range (matrix_all_kernels.hpp; 17..64 profiles, multiset prod and
+    sum): every profile count around their geometry's edges -- 17 / 32 (the 256-thread form, a last block of one / four
+    rows), 33 / 48 / 61 / 64 (the 1024-thread form; dead slots; a diagonal slot whose second block is past the end) -- with
+    zero bins (term counts from the zero masks), counts beyond the reciprocal table of 'prod' and up to the last entries of
+    the table of 'sum'; every pair against kpal_pair_distance (IEEE divisions), a sample of pairs against the oracle."""
+    rs = np.random.RandomState(23)
+    for k, P in ((6, 17), (6, 32), (7, 33), (6, 48), (6, 61), (7, 64), (6, 18), (6, 29)):
+        profs = [rs.poisson(rs.choice([0.3, 5.0, 90.0]), 4 ** k).astype(np.int64) for _ in range(P)]
+        profs[P // 2][rs.randint(0, 4 ** k, 50)] = 512 + rs.randint(0, 500, 50)      # past the table of 'prod', inside the table of 'sum'
+        profs[0][5] = profs[1][5] = 1023
+        profs[2][5] = 1022
+        profs[1][::7] = 0
+        profs[P - 1][::3] = 0
+        profs[P - 2][:] = 0                                                           # an empty profile: every bin a both-zero candidate
+        for code, metric in ((0, 'prod'), (1, 'sum')):
+            got = ctx.distance_matrix(profs, k, code)
+            want = np.array([ctx.pair_distance(profs[i], profs[j], code) for i in range(1, P) for j in range(i)])
+            np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+            for i, j in ((1, 0), (P - 1, P - 2), (P - 1, 0), (P // 2, 3), (P - 2, 1)):
+                assert close(got[i * (i - 1) // 2 + j], oracle.distance(profs[i], profs[j], k, metric=metric)), (k, P, metric, i, j)
+
+
 def test_matrix_rdiff_worst_case(ctx):
     """The accuracy bound of multiset 'prod' as a difference of reciprocals (matrix_rdiff_kernel) where it is tightest: EVERY
     count just below the kernel's limit of 2^16 and neighbours differing by 1 or 2 -- each term 1/(y+1) - 1/(x+1) cancels all

@@ -17,7 +17,8 @@ import __graft_entry__ as g
 OUT = os.path.join(ROOT, 'build', 'variants')
 os.makedirs(OUT, exist_ok=True)
 UNITS = sorted(f[:-4] for f in os.listdir(g.CSRC) if f.endswith('.hip'))
-# only the units that include quad_kernels.hpp see the macros; the others are taken from the regular build
+# only these units see the macros (default: the ones that include quad_kernels.hpp; --units=kpal_vec[,...] as the first
+# argument names others); the rest are taken from the regular build
 QUAD_UNITS = ('kpal_quads', 'kpal_quads2')
 
 
@@ -38,6 +39,8 @@ def build(spec):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1].startswith('--units='):
+        QUAD_UNITS = tuple(sys.argv.pop(1)[len('--units='):].split(','))
     g.build()
     with ThreadPoolExecutor(max_workers=4) as pool:
         for lib in pool.map(build, sys.argv[1:]):

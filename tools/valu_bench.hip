@@ -4,8 +4,8 @@
 //   hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_bench tools/valu_bench.hip && /tmp/valu_bench
 // Every kernel runs ITERS x 32 copies of one instruction on eight independent register chains (a chain's next instruction is
 // eight issue slots away), one workgroup per CU of 256 / 512 / 1024 threads = 1 / 2 / 4 waves per SIMD.  Reported: cycles per
-// wave-instruction per SIMD = time x clock / (instructions per wave x waves per SIMD), with the clock read inside the kernel
-// (s_memtime against the 100 MHz s_memrealtime).
+// wave-instruction per SIMD = KERNEL time x clock / (instructions per wave x waves per SIMD), with the clock read inside the
+// kernel (s_memtime against the 100 MHz s_memrealtime).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -158,29 +158,37 @@ __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t seed, u
     if (acc == 0x12345678u && seed == 77u) out[0] = acc;
 }
 
+// (the time is the KERNEL's -- the SIMD issues oldest-first, so the first wave of a workgroup runs as if it were alone whatever
+// the others do; its own cycle count says nothing about the issue rate.  The in-kernel counters only calibrate the clock.)
 template <int OP>
 void run(const char *name, unsigned long long *dout)
 {
     const int iters = 20000;
     printf("%-22s", name);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
     for (int block : {256, 512, 1024}) {
         hipLaunchKernelGGL(bench_kernel<OP>, dim3(256), dim3(block), 0, 0, 100, 3u, dout);
         CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(a));
         hipLaunchKernelGGL(bench_kernel<OP>, dim3(256), dim3(block), 0, 0, iters, 3u, dout);
+        CHECK(hipEventRecord(b));
         CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
         std::vector<unsigned long long> h(512);
         CHECK(hipMemcpy(h.data(), dout, 512 * 8, hipMemcpyDeviceToHost));
-        // per workgroup: shader cycles of its wave 0 for iters x 32 instructions per wave, (block / 256) waves per SIMD
-        double cyc = 0, mhz = 0;
-        for (int b = 0; b < 256; ++b) {
-            cyc += (double)h[2 * b];
-            mhz += 100.0 * (double)h[2 * b] / (double)h[2 * b + 1];
-        }
-        cyc /= 256;
+        double mhz = 0;
+        for (int blk = 0; blk < 256; ++blk) mhz += 100.0 * (double)h[2 * blk] / (double)h[2 * blk + 1];
         mhz /= 256;
-        printf("  %d/SIMD: %5.2f cyc (%4.0f MHz)", block / 256, cyc / ((double)iters * 32 * (block / 256)), mhz);
+        // iters x 32 instructions per wave, (block / 256) waves per SIMD
+        const double cyc = (double)ms * 1e-3 * mhz * 1e6 / ((double)iters * 32 * (block / 256));
+        printf("  %d/SIMD: %5.2f cyc (%4.0f MHz)", block / 256, cyc, mhz);
     }
     printf("\n");
+    CHECK(hipEventDestroy(a));
+    CHECK(hipEventDestroy(b));
 }
 
 int main()
