@@ -339,13 +339,13 @@ def count_roofline(kern, k, n_bytes_step, bins, steps, ms_per_step, fused_balanc
     if not kern:
         return None
     share = {}
-    finalised = 'quad2_finalize' in kern or 'quad2_finalize_balanced' in kern or 'hex_finalize' in kern   # (the histogram stage then stages its forms: the finalisation writes the table)
+    finalised = 'quad2_finalize' in kern or 'quad2_finalize_balanced' in kern   # (the histogram stage then stages its forms: the finalisation writes the table)
     for name in kern:
-        if name in ('quad_scatter', 'hex_scatter') or name in ('chunk_scatter', 'part_scatter', 'coarse_scatter', 'count_lds_direct', 'count_global_atomic'):
+        if name == 'quad_scatter' or name in ('chunk_scatter', 'part_scatter', 'coarse_scatter', 'count_lds_direct', 'count_global_atomic'):
             share[name] = float(n_bytes_step)
-        elif name in ('quad_hist', 'hex_hist', 'chunk_hist', 'part_hist') and k <= 12 and not finalised:
+        elif name in ('quad_hist', 'chunk_hist', 'part_hist') and k <= 12 and not finalised:
             share[name] = 8.0 * bins
-        elif name in ('quad2_finalize', 'quad2_finalize_balanced', 'hex_finalize'):
+        elif name in ('quad2_finalize', 'quad2_finalize_balanced'):
             share[name] = 8.0 * bins
         elif name in ('balance_tiled', 'balance_inplace'):
             share[name] = 16.0 * bins
@@ -945,7 +945,7 @@ def multi_gpu_worker(args):
     # the bin-range merge (ncclReduceScatter + mirrored-range exchange: every rank keeps and balances 1 / W of the table): the
     # merge k >= 13 needs (8 GiB per rank at k = 15); measured at every k as `extra` -- LAST, a collective pattern no run has
     # exercised yet must not stand between the run and its other figures -- the headline only when asked (--range-merge)
-    if library and world & (world - 1) == 0 and 4 ** k >= world * world:
+    if library and kdist.range_merge_supported(k, world):   # (RangeIndex::valid(): stricter than 4^k >= world^2 for odd log2(world))
         if args.range_merge:
             modes.insert(0, 'library_range')
         else:

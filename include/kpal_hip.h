@@ -61,7 +61,6 @@ extern "C" {
 #define KPAL_STRATEGY_PARTITION_CHUNKED 5 /* one-pass partition into chunked bucket lists (no counting pass); 8 <= k <= 12; AUTO */
 #define KPAL_STRATEGY_PARTITION2 4    /* two-level radix partition; 13 <= k <= 16 */
 #define KPAL_STRATEGY_PARTITION2_QUADS 7 /* two-level partition of 4-k-mer items (quad_kernels.hpp); 13 <= k <= 16; AUTO for feeds >= 64 MiB that hold 1/8 byte per table entry (first piece of a count, a whole device buffer) or 3 bytes (any other) */
-#define KPAL_STRATEGY_PARTITION_HEX 8 /* partition of 6-k-mer items of three bytes (hex_kernels.hpp); k = 12 */
 #define KPAL_STRATEGY_PARTITION_QUADS 6 /* partition of 4-k-mer items into aligned records (quad_kernels.hpp); 8 <= k <= 12; AUTO for feeds >= 32 MiB */
 
 typedef struct kpal_ctx kpal_ctx;
@@ -140,6 +139,7 @@ int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, i
  * piece.  Between two _next calls kpal_fasta_records_index / _count serve the current piece. */
 int kpal_fasta_records_file_open(kpal_ctx *ctx, const char *path, uint64_t begin, uint64_t end);
 int kpal_fasta_records_file_next(kpal_ctx *ctx, uint64_t *n_records, uint64_t *flat_bytes, uint64_t *text_offset, int *done);
+int kpal_fasta_records_file_tell(kpal_ctx *ctx, uint64_t *offset);   /* file offset of the first byte no piece has covered yet: where a closed scan is opened again */
 int kpal_fasta_records_file_close(kpal_ctx *ctx);
 int kpal_count_finish(kpal_ctx *ctx, int64_t *host_out /* 4^k, or NULL to keep the result on the device */); /* klib.py:170 */
 /* Profile.balance (klib.py:285-298) on the count table in place, on the device: count + balance is the unit the

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('KPAL_HIP_LIBRARY', os.path.join(_HERE, 'libkpal_hip.s
 KPAL_MAX_K = 16
 PAIRWISE_PROD, PAIRWISE_SUM, EUCLIDEAN, COSINE = 0, 1, 2, 3
 SUMMARY_MIN, SUMMARY_AVERAGE, SUMMARY_MEDIAN = 0, 1, 2
-STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7, 'partition_hex': 8}
+STRATEGY = {'auto': 0, 'global_atomic': 1, 'lds_direct': 2, 'partition': 3, 'partition2': 4, 'partition_chunked': 5, 'partition_quads': 6, 'partition2_quads': 7}
 
 _E_INVALID, _E_NOMEM, _E_HIP, _E_STATE, _E_IO = -1, -2, -3, -4, -5
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     'kpal_fasta_records_index': (ctypes.c_int, [_vp, _vp, _vp]),
     'kpal_fasta_records_file_open': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
     'kpal_fasta_records_file_next': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
+    'kpal_fasta_records_file_tell': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_fasta_records_file_close': (ctypes.c_int, [_vp]),
     'kpal_fasta_records_count': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'kpal_count_finish': (ctypes.c_int, [_vp, _vp]),
@@ -429,6 +430,12 @@ class Context(object):
         self._records = n.value
         self._records_scan = getattr(self, '_records_scan', 0) + 1
         return None if done.value else (n.value, nf.value, off.value)
+
+    def fasta_records_file_tell(self):
+        """File offset of the first byte that no piece has covered yet (where a closed scan is opened again)."""
+        off = ctypes.c_uint64(0)
+        _check(self._L.kpal_fasta_records_file_tell(self._h, ctypes.byref(off)))
+        return off.value
 
     def fasta_records_file_close(self):
         _check(self._L.kpal_fasta_records_file_close(self._h))

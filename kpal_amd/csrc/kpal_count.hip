@@ -43,6 +43,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
     ctx->chunk_error_armed = false;
     ctx->finalize_pending = false;          // (staged forms of an abandoned count)
     ctx->cached_steps1 = ctx->cached_steps2 = 0;
+    ctx->sample_hot_rows = false;           // (the verdict of a sample of THIS count only: kpal_quads2.hip reads it for cached tile sizes)
     ctx->plan_strategy = ctx->plan_steps1 = ctx->plan_steps2 = 0;
     ctx->counting = true;
     return KPAL_OK;
@@ -51,7 +52,7 @@ KPAL_API int kpal_count_begin(kpal_ctx *ctx, int k)
 KPAL_API int kpal_count_set_strategy(kpal_ctx *ctx, int strategy)
 {
     if (!ctx) return set_err(KPAL_E_INVALID, "ctx is NULL");
-    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION_HEX)
+    if (strategy < KPAL_STRATEGY_AUTO || strategy > KPAL_STRATEGY_PARTITION2_QUADS)
         return set_err(KPAL_E_INVALID, "unknown strategy %d", strategy);
     ctx->strategy = strategy;
     return KPAL_OK;
@@ -63,12 +64,9 @@ static int resolve_strategy(kpal_ctx *ctx, int *out)
     const int k = ctx->k;
     if (s == KPAL_STRATEGY_AUTO)
         s = k <= 7 ? KPAL_STRATEGY_LDS_DIRECT : (k <= 12 ? KPAL_STRATEGY_PARTITION_QUADS : KPAL_STRATEGY_PARTITION2_QUADS);
-    static const bool hex_auto = [] { const char *e = getenv("KPAL_K12_HEX"); return e && atoi(e) != 0; }();
-    if (ctx->strategy == KPAL_STRATEGY_AUTO && k == 12 && hex_auto) s = KPAL_STRATEGY_PARTITION_HEX;
     if (s == KPAL_STRATEGY_LDS_DIRECT && k > 7) return set_err(KPAL_E_INVALID, "LDS-direct strategy needs k <= 7 (k=%d)", k);
     if ((s == KPAL_STRATEGY_PARTITION || s == KPAL_STRATEGY_PARTITION_CHUNKED || s == KPAL_STRATEGY_PARTITION_QUADS) && (k < 8 || k > 12))
         return set_err(KPAL_E_INVALID, "partition strategy needs 8 <= k <= 12 (k=%d)", k);
-    if (s == KPAL_STRATEGY_PARTITION_HEX && k != 12) return set_err(KPAL_E_INVALID, "the hex strategy needs k = 12 (k=%d)", k);
     if ((s == KPAL_STRATEGY_PARTITION2 || s == KPAL_STRATEGY_PARTITION2_QUADS) && (k < 13 || k > 16))
         return set_err(KPAL_E_INVALID, "two-level partition strategy needs 13 <= k <= 16 (k=%d)", k);
     *out = s;
@@ -389,7 +387,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
     // 0.1 - 0.5 ms (launches, one merge of the whole table); a quarter million atomics do not
     if (ctx->strategy == KPAL_STRATEGY_AUTO && ctx->k >= 8 && n <= ((size_t)1 << 18)) strat = KPAL_STRATEGY_GLOBAL_ATOMIC;
     // the quad pipeline pays a fixed histogram stage (one 128 KiB workgroup per bucket): medium feeds take the chunked one
-    else if (ctx->strategy == KPAL_STRATEGY_AUTO && (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
+    else if (ctx->strategy == KPAL_STRATEGY_AUTO && strat == KPAL_STRATEGY_PARTITION_QUADS && n < ((size_t)32 << 20)) strat = KPAL_STRATEGY_PARTITION_CHUNKED;
     // The two-level quad pipeline pays per FEED for the whole table -- its forms are staged (4 bytes per entry) and the finalisation
     // reads them and the table and writes the table -- where the round-1 two-level pipeline adds into the table with atomics and
     // pays for the table once per count (memset, Profile.balance).  Measured at the end of round 4 (same box, count + balance,
@@ -421,7 +419,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         const size_t cap = (size_t)(spb_max * G * 1024);
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, cap) : cap;
     }
-    else if (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) {
+    else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
         // the record pool takes 4/3 of the input bytes (up to 8 x that for heavily skewed input, whose tiles are
         // smaller): pieces of up to 16 GiB (KPAL_BATCH_BYTES lowers it)
         piece = ctx->batch_bytes_set ? std::min<size_t>(ctx->batch_bytes, (size_t)16 << 30) : (size_t)16 << 30;
@@ -447,7 +445,7 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
         if (!fresh) CHK(table_ready(ctx));   // zeros materialised; the staged forms of the previous piece added before their buffer is reused
         const size_t h = std::min(km1, halo + off);
         const Span s = make_span(addr + off, len, h);
-        if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS && strat != KPAL_STRATEGY_PARTITION_HEX) {
+        if (strat != KPAL_STRATEGY_PARTITION_QUADS && strat != KPAL_STRATEGY_PARTITION2_QUADS) {
             ctx->plan_strategy = strat;
             ctx->plan_steps1 = ctx->plan_steps2 = 0;
         }
@@ -475,8 +473,8 @@ static int count_device_range(kpal_ctx *ctx, const uint8_t *addr, size_t n, size
                 return rc;
             }
         }
-        else if (strat == KPAL_STRATEGY_PARTITION_QUADS || strat == KPAL_STRATEGY_PARTITION_HEX) {
-            const int rc = strat == KPAL_STRATEGY_PARTITION_HEX ? launch_partition_hex(ctx, s) : launch_partition_quads(ctx, s);
+        else if (strat == KPAL_STRATEGY_PARTITION_QUADS) {
+            const int rc = launch_partition_quads(ctx, s);
             if (rc == KPAL_OK) ++ctx->stat_quad_pieces;
             if (rc == kSplitBatch) ++ctx->stat_split_pieces;
             if (rc == kQuadsUseChunked) {   // (AUTO only) this piece through the chunked pipeline, in its own piece size
@@ -1070,6 +1068,18 @@ KPAL_API int kpal_fasta_records_file_next(kpal_ctx *ctx, uint64_t *n_records, ui
         if (*n_records == 0 && !(ctx->rec_carry.empty() && at_end)) continue;   // (text before the first header only: next piece)
         return KPAL_OK;
     }
+}
+
+// Where the scan stands: the file offset of the first byte that no piece has covered yet (the start of the carried,
+// unfinished record).  A caller that lets other work use the context between two pieces keeps THIS, closes the scan and
+// opens it again there: the scan state of the context -- descriptor, position, carried bytes -- then never outlives a call.
+KPAL_API int kpal_fasta_records_file_tell(kpal_ctx *ctx, uint64_t *offset)
+{
+    CTX_ENTER(ctx);
+    if (!offset) return set_err(KPAL_E_INVALID, "NULL pointer");
+    if (ctx->rec_fd < 0) return set_err(KPAL_E_STATE, "kpal_fasta_records_file_tell without an open scan");
+    *offset = ctx->rec_piece_at;
+    return KPAL_OK;
 }
 
 KPAL_API int kpal_fasta_records_file_close(kpal_ctx *ctx)

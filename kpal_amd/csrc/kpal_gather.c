@@ -1,6 +1,7 @@
 /* kpal_gather.c -- CPython extension `kpal_amd._kpal_gather`: the host side of Profile.from_sequences for LISTS of short sequences
- * (a million 150-base reads as bytes / str objects), second generation: the same contract as csrc/kpal_join.c's gather(), with the
- * walk over the list's objects cut over the threads as well (kpal_gather_core.h says why and how).
+ * (a million 150-base reads as bytes / str objects): gather(sequence, first, address, capacity, threads) -> (next, nbytes, status)
+ * copies the items from `first` on into the page-locked buffer at `address`, each followed by '\n', with the walk over the list's
+ * objects AND the copies cut over the threads (kpal_gather_core.h says why and how).
  *
  * kpal/klib.py:154 walks the sequences in the interpreter; the drop-in hands the GPU one flat byte stream, sequences separated by
  * '\n' (kpal_amd/klib.py).  Items read here: bytes, bytearray, and str whose characters all fit one byte (ASCII / latin-1, whose

@@ -1,21 +1,20 @@
-/* kpal_gather_core.h -- the gatherer of Profile.from_sequences, second generation, free of Python.h: `count` items, each described by
+/* kpal_gather_core.h -- the gatherer of Profile.from_sequences, free of Python.h: `count` items, each described by
  * a callback (data pointer + length, or "not mine"), become one flat byte stream, every item followed by '\n' -- with BOTH phases on
  * several threads.  kpal_gather.c binds it to CPython lists; tests/native/gather_check.c drives it under AddressSanitizer /
  * ThreadSanitizer (pytest -m "not gpu").
  *
- * Why a second generation.  csrc/kpal_join.c walks the list on ONE thread (pointer, length, offset of every item) and only copies on
- * several: for 150-byte reads the walk IS the cost -- every item is its own heap object, one cache miss each, 20-50 ns -- and the
- * copy threads wait for it (the same 60 ns per item with 1 or 8 threads on the development container).  Here the walk is cut over
- * the threads too:
+ * Why both.  The first gatherer (rounds 3-5, csrc/kpal_join.c in the history) walked the list on ONE thread (pointer, length, offset
+ * of every item) and only copied on several: for 150-byte reads the walk IS the cost -- every item is its own heap object, one cache
+ * miss each, 20-50 ns -- and the copy threads waited for it (the same 60 ns per item with 1 or 8 threads on the development
+ * container; 8 M str objects: 157 -> 85.5 ms with the walk on sixteen threads, profiles/r5/seqbench.log).  So the walk is cut over the
+ * threads too:
  *   pass 1 (parallel)  describe(i) -> ptr[i], len[i]; every slice remembers its first item that cannot be described / is too long;
  *   serial             lengths -> offsets (sequential arrays: ~1 ns per item), the cut at the buffer's capacity or the first bad item;
  *   pass 2 (parallel)  the copies (kpal_join_core.h: equal byte shares).
  * The list is taken in windows sized from the first items' mean length, so that a call walks little more than what fits the buffer.
  * The callback must be safe to call from several threads at once for different i (kpal_gather.c: the caller keeps the GIL, the
  * objects are only read).
- *
- * (This directory holds host-side code only and sits outside csrc/: bench.py's source_sha -- the hash that ties the committed
- * counter profiles to the kernel sources -- covers csrc/.) */
+ */
 #ifndef KPAL_GATHER_CORE_H
 #define KPAL_GATHER_CORE_H
 #include <pthread.h>
@@ -23,7 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../csrc/kpal_join_core.h"
+#include "kpal_join_core.h"
 
 /* 1: item i is *len bytes at *ptr; 0: not an item this gatherer reads */
 typedef int (*kpal_describe_fn)(void *ctx, size_t i, const char **ptr, uint64_t *len);

@@ -97,7 +97,6 @@ struct kpal_ctx {
     size_t cached_bytes = 0;
     // two-level quad pipeline: the staged forms of the last piece have not been added to the table yet (quad2_finalize)
     bool finalize_pending = false;
-    bool finalize_hex = false;               // ... of the hex pipeline (k = 12, kpal_hex.hip): six planes in table order
     const void *finalize_stage = nullptr;
     // FRESH mode of that pipeline (kpal_quads2.hip): kpal_count_begin leaves the table of a k >= 13 count UNZEROED
     // (table_zero_pending) -- the first piece, if it is a whole device feed on the two-level quad pipeline, lets its
@@ -289,8 +288,6 @@ inline unsigned stream_grid(kpal_ctx *ctx, uint64_t n_items, unsigned block = 25
 constexpr int kQuadsUseChunked = 2;   // launch_partition*_quads (AUTO): the sample shows a feed for the round-1 pipeline
 constexpr int kSplitBatch = 1;        // launch_partition2 / launch_partition*_quads: the caller halves the piece
 int launch_partition_quads(kpal_ctx *ctx, const Span &s);                 // kpal_quads.hip
-int launch_partition_hex(kpal_ctx *ctx, const Span &s);                   // kpal_hex.hip (k = 12)
-int hex_finalize(kpal_ctx *ctx, bool balance);                            // kpal_hex.hip
 int launch_partition2_quads(kpal_ctx *ctx, const Span &s, bool fresh = false);   // kpal_quads2.hip
 int quad_choose_steps(kpal_ctx *ctx, const Span &s, uint32_t *load, int buckets, int slots, int waves, const int *candidates,
                       size_t n_candidates, int *steps_out, std::vector<double> *fine_per_step = nullptr);   // kpal_quads.hip

@@ -274,7 +274,7 @@ static int comm_range_geometry(kpal_ctx *ctx, RangeIndex &R)
     int w = 0;
     while ((1 << w) < W) ++w;
     R = RangeIndex{ctx->k, w};
-    if (!R.valid()) return set_err(KPAL_E_INVALID, "the bin-range merge needs 4^k >= W^2 (k=%d, %d ranks)", ctx->k, W);
+    if (!R.valid()) return set_err(KPAL_E_INVALID, "the bin-range merge needs 2 ceil(log2(W) / 2) <= k (k=%d, %d ranks)", ctx->k, W);
     return KPAL_OK;
 }
 
@@ -321,17 +321,29 @@ KPAL_API int kpal_comm_reduce_scatter_table(kpal_ctx *ctx, int balance)
     const uint32_t W = (uint32_t)ctx->comm_world, r = (uint32_t)ctx->comm_rank;
     const uint64_t n1 = R.range_bins(), n2 = R.pair_bins();
     unsigned long long *table = (unsigned long long *)ctx->table.p;
+    // Everything of this rank that can fail goes BEFORE the first collective: a rank that returned between the reduce-scatter
+    // and the exchange (an allocation of 8 * 4^k / W bytes twice: 1 GiB each at k = 15, W = 8) would leave its peers waiting in
+    // the Send / Recv group for ever.
+    if (balance) {
+        CHK(ensure(ctx, ctx->xsend, (size_t)n1 * 8));
+        CHK(ensure(ctx, ctx->xrecv, (size_t)n1 * 8));
+    }
     {
         ProfScope ps_(ctx, "rccl_reduce_scatter");
         NCCLCHK(g_rccl.ReduceScatter(table, table + (uint64_t)r * n1, (size_t)n1, ncclInt64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));   // in place
     }
     if (balance) {
-        CHK(ensure(ctx, ctx->xsend, (size_t)n1 * 8));
-        CHK(ensure(ctx, ctx->xrecv, (size_t)n1 * 8));
         unsigned long long *send = (unsigned long long *)ctx->xsend.p, *recv = (unsigned long long *)ctx->xrecv.p;
         const unsigned grid = (unsigned)std::min<uint64_t>((n1 + 255) / 256, (uint64_t)ctx->num_cu * 16);
-        LAUNCH(ctx, "range_pack", range_pack_kernel, dim3(grid), dim3(256), R, r, (const unsigned long long *)table, send);
-        HIPCHK(hipMemcpyAsync(recv + (uint64_t)r * n2, send + (uint64_t)r * n2, (size_t)n2 * 8, hipMemcpyDeviceToDevice, ctx->stream));   // a rank's own block
+        // (a launch or copy that fails here is remembered and reported AFTER the group: the peers' Send / Recv still get their partner)
+        int local_rc = KPAL_OK;
+        {
+            ProfScope ps_(ctx, "range_pack");
+            hipLaunchKernelGGL(range_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, R, r, (const unsigned long long *)table, send);
+        }
+        if (hipGetLastError() != hipSuccess) local_rc = set_err(KPAL_E_HIP, "range_pack did not launch");
+        if (hipMemcpyAsync(recv + (uint64_t)r * n2, send + (uint64_t)r * n2, (size_t)n2 * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)   // a rank's own block
+            local_rc = set_err(KPAL_E_HIP, "the copy of the rank's own block failed");
         if (W > 1) {
             ProfScope ps_(ctx, "rccl_mirror_exchange");
             NCCLCHK(g_rccl.GroupStart());
@@ -345,6 +357,7 @@ KPAL_API int kpal_comm_reduce_scatter_table(kpal_ctx *ctx, int balance)
             const ncclResult_t ge = g_rccl.GroupEnd();      // (always closed: an open group would swallow every later call)
             if (bad != ncclSuccess || ge != ncclSuccess) return set_err(KPAL_E_HIP, "the mirror exchange failed: %s", g_rccl.GetErrorString(bad != ncclSuccess ? bad : ge));
         }
+        if (local_rc != KPAL_OK) return local_rc;
         LAUNCH(ctx, "range_unpack", range_unpack_kernel, dim3(grid), dim3(256), R, r, table, (const unsigned long long *)recv);
     }
     ctx->merged = table + (uint64_t)r * n1;

@@ -227,7 +227,6 @@ int quad2_resolve_fresh(kpal_ctx *ctx)
 int quad2_finalize(kpal_ctx *ctx, bool balance)
 {
     if (!ctx->finalize_pending) return KPAL_OK;
-    if (ctx->finalize_hex) return hex_finalize(ctx, balance);
     CHK(quad2_resolve_fresh(ctx));
     ctx->finalize_pending = false;
     const bool fresh = ctx->finalize_fresh;

@@ -87,13 +87,21 @@ def _revcomp(idx, k):
     return x >> np.uint64(64 - 2 * k)
 
 
+def range_merge_supported(k, world):
+    """RangeIndex::valid() of csrc/range_index.hpp: a power-of-two world of 2^w ranks with 2 ceil(w / 2) <= k -- whole BASES
+    of the reverse complement name the destination rank, so an odd w needs one bit more than 4^k >= world^2 says (k = 3 with 8
+    ranks and k = 5 with 32 are refused)."""
+    w = int(world).bit_length() - 1
+    return world >= 1 and (1 << w) == world and 1 <= k <= 31 and 2 * ((w + 1) // 2) <= k
+
+
 def range_geometry(k, world):
-    """-> (w, bins per rank, bins per pair of ranks) of the bin-range merge; ``world`` must be a power of two with world^2 <= 4^k."""
+    """-> (w, bins per rank, bins per pair of ranks) of the bin-range merge; see range_merge_supported."""
     w = int(world).bit_length() - 1
     if world < 1 or (1 << w) != world:
         raise ValueError('the bin-range merge needs a power-of-two number of ranks (got %d)' % world)
-    if 4 * ((w + 1) // 2) > 2 * k:
-        raise ValueError('the bin-range merge needs 4^k >= world^2 (k=%d, %d ranks)' % (k, world))
+    if not range_merge_supported(k, world):
+        raise ValueError('the bin-range merge needs 2 ceil(log2(ranks) / 2) <= k (k=%d, %d ranks)' % (k, world))
     n1 = 4 ** k >> w
     return w, n1, n1 >> w
 

@@ -29,20 +29,12 @@ import numpy as np
 
 from . import _native, metrics
 
-# The C gatherer of from_sequences (built by __graft_entry__.build()); without one the sequences are joined by the interpreter -- same
-# stream, ~3 x slower for lists of short reads.  Two generations with one contract: hostext/kpal_gather.c walks the list's objects
-# on several threads as well as copying them, csrc/kpal_join.c walks them on one (KPAL_GATHERER=join selects it: A/B, cross-check).
-_kpal_join = None
-if os.environ.get('KPAL_GATHERER', 'gather') != 'join':
-    try:
-        from . import _kpal_gather as _kpal_join
-    except ImportError:       # pragma: no cover
-        pass
-if _kpal_join is None:
-    try:
-        from . import _kpal_join
-    except ImportError:       # pragma: no cover
-        _kpal_join = None
+# The C gatherer of from_sequences (csrc/kpal_gather.c, built by __graft_entry__.build(): walks the list's objects and copies them on
+# several threads); without it the sequences are joined by the interpreter -- same stream, ~3 x slower for lists of short reads.
+try:
+    from . import _kpal_gather
+except ImportError:       # pragma: no cover
+    _kpal_gather = None
 
 _FEED_BYTES = 32 << 20  # host-side join buffer per feed
 _GATHER_BYTES = 64 << 20  # page-locked gather buffer of from_sequences
@@ -200,7 +192,7 @@ def _gather_feed(ctx, sequences):
         block = sequences if it is None else list(itertools.islice(it, 1 << 16))
         pos = 0
         while pos < len(block):
-            pos, nbytes, status = _kpal_join.gather(block, pos, address + fill, cap - fill, _GATHER_THREADS)
+            pos, nbytes, status = _kpal_gather.gather(block, pos, address + fill, cap - fill, _GATHER_THREADS)
             fill += nbytes
             if status == 0:
                 break
@@ -345,32 +337,44 @@ class Profile(object):
             # the names are read from the header lines through a read-only mapping of the file
             import mmap
             encoding = handle.encoding if isinstance(handle, io.TextIOWrapper) else 'ascii'
-            with open(plain[0], 'rb') as raw, mmap.mmap(raw.fileno(), 0, access=mmap.ACCESS_READ) as text:
-                ctx.fasta_records_file_open(plain[0], plain[1], 0)
+            # The reference's generators are independent of each other (zip() of two, nesting, one abandoned half-way), and
+            # this one yields with a piece indexed on the process-wide context.  So nothing of the scan lives in the context
+            # across a yield: the scan is opened at `resume`, asked for ONE piece and closed again; and when another scan has
+            # used the context between two batches of a piece, the piece -- bytes [at, resume) -- is indexed again.
+            def index_piece(begin, end):
+                ctx.fasta_records_file_open(plain[0], begin, end)
                 try:
-                    while True:
-                        piece = ctx.fasta_records_file_next()
-                        if piece is None:
-                            break
-                        n_records, _, at = piece
-                        if n_records == 0:
-                            continue
-                        header_off, _ = ctx.fasta_records_index()
-                        names = []
-                        for h in (header_off + np.uint64(at)).tolist():
-                            words = text[h + 1:_line_end(text, h)].decode(encoding, 'replace').split(None, 1)
-                            index += 1
-                            names.append(prefix + (words[0] if words else str(index)))
-                        scan = ctx._records_scan
-                        for first in range(0, n_records, per_batch):
-                            if ctx._records_scan != scan:
-                                raise RuntimeError('from_fasta_by_record: another by-record scan ran on this context meanwhile')
-                            n = min(per_batch, n_records - first)
-                            tables = ctx.fasta_records_count(length, first, n)
-                            for j in range(n):
-                                yield cls(tables[j], name=names[first + j])
+                    piece = ctx.fasta_records_file_next()
+                    return piece, (ctx.fasta_records_file_tell() if piece is not None else end)
                 finally:
                     ctx.fasta_records_file_close()
+
+            with open(plain[0], 'rb') as raw, mmap.mmap(raw.fileno(), 0, access=mmap.ACCESS_READ) as text:
+                resume = plain[1]
+                while True:
+                    piece, resume = index_piece(resume, 0)
+                    if piece is None:
+                        break
+                    n_records, _, at = piece
+                    if n_records == 0:
+                        continue
+                    scan = ctx._records_scan
+                    header_off, _ = ctx.fasta_records_index()
+                    names = []
+                    for h in (header_off + np.uint64(at)).tolist():
+                        words = text[h + 1:_line_end(text, h)].decode(encoding, 'replace').split(None, 1)
+                        index += 1
+                        names.append(prefix + (words[0] if words else str(index)))
+                    for first in range(0, n_records, per_batch):
+                        if ctx._records_scan != scan:
+                            again, _ = index_piece(at, resume)
+                            if again is None or again[0] != n_records:
+                                raise RuntimeError('from_fasta_by_record: bytes %d..%d of %s changed under the scan' % (at, resume, plain[0]))
+                            scan = ctx._records_scan
+                        n = min(per_batch, n_records - first)
+                        tables = ctx.fasta_records_count(length, first, n)
+                        for j in range(n):
+                            yield cls(tables[j], name=names[first + j])
             handle.seek(0, os.SEEK_END)          # the handle has been consumed, as by the reference's SeqIO.parse loop
             return
         for text, text_str, encoding in _whole_record_chunks(handle):
@@ -387,8 +391,9 @@ class Profile(object):
                 names.append(prefix + (words[0] if words else str(index)))
             scan = ctx._records_scan
             for first in range(0, n_records, per_batch):
-                if ctx._records_scan != scan:
-                    raise RuntimeError('from_fasta_by_record: another by-record scan ran on this context meanwhile')
+                if ctx._records_scan != scan:        # another by-record scan used the context since the last batch: this text again
+                    ctx.fasta_records_begin(text)
+                    scan = ctx._records_scan
                 n = min(per_batch, n_records - first)
                 tables = ctx.fasta_records_count(length, first, n)
                 for j in range(n):
@@ -405,7 +410,7 @@ class Profile(object):
             raise ValueError('k-mer length must be in 1..%d (got %d)' % (_native.KPAL_MAX_K, length))
         ctx = _native.context()
         ctx.count_begin(length)
-        if _kpal_join is not None:
+        if _kpal_gather is not None:
             _gather_feed(ctx, sequences)
             return cls(ctx.count_finish(), name=name)
         it = iter(sequences)

@@ -1,4 +1,4 @@
-/* gather_check.c -- AddressSanitizer / ThreadSanitizer harness of kpal_amd/hostext/kpal_gather_core.h (the gatherer behind
+/* gather_check.c -- AddressSanitizer / ThreadSanitizer harness of kpal_amd/csrc/kpal_gather_core.h (the gatherer behind
  * Profile.from_sequences: the walk over the items AND the copies on several threads): item lists with items the gatherer does not
  * read at every position, zero-length items, one giant item, buffers of every size around the stream (each run's output buffer is
  * exactly `capacity` bytes: a byte written past it is an ASan finding), windows that end inside the list, more threads than items.
@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "../../kpal_amd/hostext/kpal_gather_core.h"
+#include "../../kpal_amd/csrc/kpal_gather_core.h"
 
 static uint64_t rng_state = 0xD1B54A32D192ED03ull;
 static uint64_t rnd(void)

@@ -36,8 +36,6 @@ while time.time() < t_end:
     strategies = ['auto']
     if 8 <= k <= 12:
         strategies += ['partition', 'partition_chunked', 'partition_quads']
-        if k == 12:
-            strategies.append('partition_hex')
     if k >= 13:
         strategies += ['partition2', 'partition2_quads']
     for strat in strategies:

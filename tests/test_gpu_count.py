@@ -38,8 +38,6 @@ def strategies(k):
             s.append('partition')
         s.append('partition_chunked')
         s.append('partition_quads')
-        if k == 12:
-            s.append('partition_hex')
     if 13 <= k <= 16:
         s.append('partition2')
         s.append('partition2_quads')
@@ -874,11 +872,11 @@ def test_k16_two_level_on_device(ctx):
 
 def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
     """Profile.from_sequences on lists / tuples / generators of bytes, str, bytearray, memoryview and str with characters
-    beyond latin-1 (separators, like every non-nucleotide: klib.py:152) goes through the C gatherer (kpal_amd/hostext/kpal_gather.c,
-    and its first generation kpal_amd/csrc/kpal_join.c) and kpal_count_feed_pinned: with the usual 64 MiB buffer and with a 4 KiB one (buffer full in the middle of the list, a
+    beyond latin-1 (separators, like every non-nucleotide: klib.py:152) goes through the C gatherer (kpal_amd/csrc/kpal_gather.c)
+    and kpal_count_feed_pinned: with the usual 64 MiB buffer and with a 4 KiB one (buffer full in the middle of the list, a
     sequence longer than the buffer, foreign items at a buffer's end), against the oracle and against the interpreter's join."""
     from kpal_amd import klib
-    assert klib._kpal_join is not None, 'the gatherer extension was not built'
+    assert klib._kpal_gather is not None, 'the gatherer extension was not built'
     rs = np.random.RandomState(8)
     reads = oracle.synth_reads(61, 0, 3000, 150, noisy=True).reshape(-1, 151)[:, :150]
     items = []
@@ -888,16 +886,11 @@ def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
     items[100] = bytes(np.frombuffer(b'ACGT', dtype=np.uint8)[rs.randint(0, 4, 20000)])       # longer than the small buffer
     items[2000] = ('ACGTTGCA' * 1000) + '中' + 'TTGACCA' * 50                            # foreign AND longer than the small buffer
     as_text = [bytes(x).decode('latin-1') if not isinstance(x, str) else x.encode('latin-1', 'replace').decode('latin-1') for x in items]
-    from kpal_amd import _kpal_gather, _kpal_join
-    assert klib._kpal_join is _kpal_gather, 'the second-generation gatherer is the default'
     for k in (3, 9, 12):
         want = oracle.from_sequences(as_text, k)
         for shape in (list, tuple, iter):
             p = klib.Profile.from_sequences(shape(items), k)
             np.testing.assert_array_equal(p.counts, want, err_msg='k=%d %s' % (k, shape.__name__))
-    with monkeypatch.context() as m:          # the first generation (KPAL_GATHERER=join) behind the same Python code
-        m.setattr(klib, '_kpal_join', _kpal_join)
-        np.testing.assert_array_equal(klib.Profile.from_sequences(items, 9).counts, oracle.from_sequences(as_text, 9))
     small = ctx.host_alloc(4096)
     from kpal_amd import _native
     default = _native.context()
@@ -926,7 +919,7 @@ def test_from_sequences_through_the_gatherer(ctx, monkeypatch):
     with pytest.raises(ValueError):
         ctx.host_free(address)                                                   # not (any more) a buffer of this context
     # the interpreter's join (no extension) gives the same stream
-    monkeypatch.setattr(klib, '_kpal_join', None)
+    monkeypatch.setattr(klib, '_kpal_gather', None)
     np.testing.assert_array_equal(klib.Profile.from_sequences(items, 9).counts, oracle.from_sequences(as_text, 9))
     # empty inputs
     assert klib.Profile.from_sequences([], 5).total == 0 and klib.Profile.from_sequences([b'', ''], 5).total == 0

@@ -221,7 +221,7 @@ def test_from_fasta_by_record_file(tmp_path, monkeypatch):
 def test_fasta_records_c_abi(ctx, tmp_path):
     """kpal_fasta_records_* through the binding: the index (header offsets into the text, record starts in the flattened stream),
     batches of any size at any record (also starting in the middle of a 16-byte chunk of the flattened text), errors, and
-    two scans interleaved on one context (the second invalidates the first: the generator says so instead of counting wrongly)."""
+    two scans interleaved on one context (a generator whose index another scan has overwritten indexes its text again)."""
     from kpal_amd import klib
     text = b'junk\n>a one\nACGTAC\nGT\n>\n\n>c\nTTGACCA\n>d x y\nG\n>e\n' + b'ACGTTGCA' * 300 + b'\n>f\nCC\n'
     n, nf = ctx.fasta_records_begin(text)
@@ -243,24 +243,82 @@ def test_fasta_records_c_abi(ctx, tmp_path):
     assert ctx.fasta_records_index()[0].size == 0           # nothing indexed
     with pytest.raises(RuntimeError):
         ctx.fasta_records_file_next()                       # no file open
-    # interleaved generators on the one default context
+    # interleaved generators on the one default context: the reference's generators are independent of each other
     path = tmp_path / 'two.fa'
     path.write_bytes(b''.join(b'>r%d\nACGTACGT\n' % i for i in range(50)))
     import io
-    a = klib.Profile.from_fasta_by_record(io.BytesIO(path.read_bytes()), 3)
-    first = next(a)
-    assert first.name == 'r0'
-    list(klib.Profile.from_fasta_by_record(io.BytesIO(b'>x\nAC\n'), 3))
     monkey_batch = klib._RECORD_BATCH_BYTES
-    klib._RECORD_BATCH_BYTES = 4 * 8 * 4 ** 3               # four records per batch: the first generator has batches left to fetch
+    klib._RECORD_BATCH_BYTES = 4 * 8 * 4 ** 3               # four records per batch: a generator has batches left to fetch when the other runs
     try:
         b = klib.Profile.from_fasta_by_record(io.BytesIO(path.read_bytes()), 3)
-        next(b)
-        list(klib.Profile.from_fasta_by_record(io.BytesIO(b'>y\nACG\n'), 3))
-        with pytest.raises(RuntimeError):
-            list(b)
+        assert next(b).name == 'r0'
+        assert [p.name for p in klib.Profile.from_fasta_by_record(io.BytesIO(b'>y\nACG\n'), 3)] == ['y']
+        rest = list(b)
+        assert [p.name for p in rest] == ['r%d' % i for i in range(1, 50)]
+        for p in rest:
+            np.testing.assert_array_equal(p.counts, oracle.from_sequences(['ACGTACGT'], 3))
     finally:
         klib._RECORD_BATCH_BYTES = monkey_batch
+
+
+def test_by_record_generators_interleaved_on_files(tmp_path, monkeypatch):
+    """Two (and three) from_fasta_by_record generators over DIFFERENT files advanced in turns -- zip(), one nested in the other,
+    one abandoned half-way -- on the process-wide context, with pieces of 300 bytes (every file is many pieces) and two records
+    per batch: the scan state of a file lives in the generator, a piece another scan has overwritten is indexed again.  Names,
+    order and every table against the tokeniser + the oracle (the reference's generators are independent: klib.py:114-133)."""
+    from kpal_amd import _native, klib
+    rnd = random.Random(5)
+    texts = [random_fasta(rnd, 40, 500), 'junk\n' + random_fasta(rnd, 25, 1200, eol='\r\n'), random_fasta(rnd, 60, 200)]
+    paths = []
+    for t, text in enumerate(texts):
+        path = tmp_path / ('inter%d.fa' % t)
+        path.write_bytes(text.encode('latin-1'))
+        paths.append(str(path))
+    recs = [seqio_records(t) for t in texts]
+    k = 4
+    monkeypatch.setenv('KPAL_FASTA_CHUNK', '300')
+    ctx2 = _native.Context(_native.default_device())
+    monkeypatch.delenv('KPAL_FASTA_CHUNK')
+    monkeypatch.setattr(_native, 'context', lambda: ctx2)
+    monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', 2 * 8 * 4 ** k)
+
+    def check(profile, t, i):
+        name, seq = recs[t][i]
+        assert profile.name == (name or str(i + 1)), (t, i)
+        np.testing.assert_array_equal(profile.counts, oracle.from_sequences([seq], k), err_msg='file %d record %d' % (t, i))
+
+    try:
+        handles = [open(p_, 'rb') for p_ in paths]
+        try:
+            gens = [klib.Profile.from_fasta_by_record(h, k) for h in handles]
+            seen = [0, 0, 0]
+            for round_ in range(max(len(r) for r in recs)):
+                for t, g in enumerate(gens):
+                    if seen[t] < len(recs[t]):
+                        check(next(g), t, seen[t])
+                        seen[t] += 1
+            for g in gens:
+                assert list(g) == []
+            assert seen == [len(r) for r in recs]
+        finally:
+            for h in handles:
+                h.close()
+        # nested: for every fifth record of file 0 a whole scan of file 2; file 1 abandoned after three records
+        with open(paths[0]) as h0, open(paths[1], 'rb') as h1:
+            abandoned = klib.Profile.from_fasta_by_record(h1, k)
+            for i in range(3):
+                check(next(abandoned), 1, i)
+            for i, p0 in enumerate(klib.Profile.from_fasta_by_record(h0, k)):
+                check(p0, 0, i)
+                if i % 5 == 0:
+                    with open(paths[2]) as h2:
+                        for j, p2 in enumerate(klib.Profile.from_fasta_by_record(h2, k)):
+                            check(p2, 2, j)
+                        assert j == len(recs[2]) - 1
+            assert i == len(recs[0]) - 1
+            check(next(abandoned), 1, 3)
+    finally:
+        ctx2.close()
 
 
 def test_chunk_seams_everywhere(tmp_path):

@@ -22,7 +22,7 @@ CASES = [
     ('host_pool_check.cpp', 'g++', ['-std=c++17'], ['1', '2', '16']),
     ('fasta_host_check.cpp', 'g++', ['-std=c++17'], ['1', '5']),
     ('join_check.c', 'gcc', ['-std=c11'], ['']),
-    ('gather_check.c', 'gcc', ['-std=c11'], ['']),      # kpal_amd/hostext/kpal_gather_core.h: walk AND copies on several threads
+    ('gather_check.c', 'gcc', ['-std=c11'], ['']),      # kpal_amd/csrc/kpal_gather_core.h: walk AND copies on several threads
     # the stream / event schedule of the pipelined multi-GPU reduce on a fake runtime: ranks, streams and events as threads
     ('comm_schedule_check.cpp', 'g++', ['-std=c++17'], ['']),
 ]

@@ -43,7 +43,7 @@ def feed_d2h():
     return ctx.count_finish()
 
 
-print('k=%d, %d reads x 150 bp (%.2f GB host buffer); from_sequences gatherer: %s' % (a.k, a.reads, nbytes / 1e9, 'C extension' if klib._kpal_join else 'interpreter join'))
+print('k=%d, %d reads x 150 bp (%.2f GB host buffer); from_sequences gatherer: %s' % (a.k, a.reads, nbytes / 1e9, 'C extension' if klib._kpal_gather else 'interpreter join'))
 timed('kpal_count_feed (host buffer, table stays on GPU)', feed)
 ref = timed('kpal_count_feed + D2H of the 4^k table', feed_d2h)
 reads = [bytes(r) for r in host.reshape(-1, 151)[:min(a.reads, 1_000_000), :150]]

@@ -103,8 +103,6 @@ python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
 python3 tools/skewbench.py --k 15 > "$OUT/skewbench_k15.log" 2>&1
 python3 tools/skewdiag.py > "$OUT/skewdiag_k12.log" 2> /dev/null
 python3 tools/skewdiag.py --k 15 > "$OUT/skewdiag_k15.log" 2> /dev/null
-# ---- the hex pipeline (k = 12, six k-mers per three-byte item) next to the quads, same box
-for st in partition_quads partition_hex; do python3 "$B" --steps 10 --warmup 2 --no-extra --no-cpu --strategy $st > "$OUT/bench_k12_$st.json" 2> "$OUT/bench_k12_$st.err"; done
 # ---- LDS primitives (what an LDS atomic costs with and without bank conflicts)
 hipcc -O3 --offload-arch=gfx950 -o /tmp/lds_bench tools/lds_bench.hip 2> /dev/null && timeout 300 /tmp/lds_bench > "$OUT/lds_bench.log" 2>&1
 # ---- the N > 1 path of bench.py with 2, 3, 4 and 8 real ranks on this one GPU over the test stand-in for RCCL, synchronous and
