@@ -36,7 +36,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 FP64_VALU_PEAK_T = 39.3    # fp64 vector lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (78.6 TFLOP/s with FMA = half the guide's 157.3 TF fp32 vector rate)
 FP64_MFMA_PEAK_T = 78.6    # fp64 matrix TFLOP/s (v_mfma_f64_16x16x4_f64: 2048 flop per 64 SIMD-cycles x 1024 SIMDs x 2.4 GHz)
-PROFILE_ROUND = 'r5'
+PROFILE_ROUND = 'r6'
+VALU_CYCLES_PER_INSTRUCTION = 3.44   # measured: the k = 12 scatter's opcode mix priced by tools/price_stream.py (profiles/r6/valu_prices.md)
 PROFILE_DIR = os.path.join(ROOT, 'profiles', PROFILE_ROUND)
 
 
@@ -137,8 +138,17 @@ def pmc_limiter(dom, k):
     if row.get('SQ_LDS_IDX_ACTIVE') and cyc:
         out['lds_busy_share'] = row['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc
         out['lds_bank_conflict_share_of_lds_busy'] = row.get('SQ_LDS_BANK_CONFLICT', 0.0) / row['SQ_LDS_IDX_ACTIVE']
-    busiest = max((('LDS', out.get('lds_busy_share') or 0.0), ('VALU issue (x waves per SIMD)', (out.get('valu_issue_share_of_wave_cycles') or 0.0) * 4.0)),
-                  key=lambda t: t[1])
+    # VALU: SQ_INSTS_VALU wave-instructions over the 1024 SIMDs of the chip, each at the MEASURED average issue cost of this kernel's
+    # opcode mix with four waves on the SIMD (tools/valu_bench.hip + tools/price_stream.py, profiles/r6/valu_prices.md: 3.44 cycles
+    # for the k = 12 scatter -- 2.5 for the plain two-operand integer / logic opcodes, 4.25 for the three-operand ones, shifts left,
+    # permutes, dot products, compares, DPP and lane moves; rounds 4-5 assumed 4.0 for every instruction)
+    if row.get('SQ_INSTS_VALU') and cyc:
+        out['valu_busy_share'] = row['SQ_INSTS_VALU'] / 1024.0 * VALU_CYCLES_PER_INSTRUCTION / cyc
+        out['valu_cycles_per_instruction'] = VALU_CYCLES_PER_INSTRUCTION
+    valu = out.get('valu_busy_share')
+    if valu is None:
+        valu = (out.get('valu_issue_share_of_wave_cycles') or 0.0) * VALU_CYCLES_PER_INSTRUCTION
+    busiest = max((('LDS', out.get('lds_busy_share') or 0.0), ('VALU issue', valu)), key=lambda t: t[1])
     out['busiest_unit'] = busiest[0]
     return out
 
@@ -146,11 +156,13 @@ def pmc_limiter(dom, k):
 # ----------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle port; reported next to the GPU number, never the target)
 # ----------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(k, read_len, budget_reads):
+def cpu_baseline(k, read_len, budget_reads, big=None):
     """CPU figures next to the GPU number (reported baselines, never the target):
     the oracle's C port (kpal/klib.py:149-170 restated) on a bounded sample of the same workload with 1
     thread and with all host cores (a private table per thread or one shared table, whichever is faster), and the pure-Python
-    restatement of the reference's loop on BASELINE config 1 (the reference's own speed class)."""
+    restatement of the reference's loop on BASELINE config 1 (the reference's own speed class).
+    big: a LARGER sample of the same workload (uint8 buffer of whole reads, taken from the device buffer of the run) for the
+    private-table plan, whose fixed cost -- first touch and merge of T tables of 4^k entries -- a small sample cannot amortise."""
     import oracle
     from oracle import pyref
     cores = os.cpu_count() or 1
@@ -176,18 +188,26 @@ def cpu_baseline(k, read_len, budget_reads):
     tn, best_threads, best_mode, tried = None, cores, 'shared', {}
     # (measured on the MI355X host, 4 M-read sample: private x 256 / 128 / 64 threads 8.0 / 4.6 / 2.2 s -- zeroing and merging T tables of
     # 128 MiB costs more than the sample's counting -- against 0.53 s for 16 threads on one shared table: one private plan is kept)
-    plans = [('private', min(most_private, 64))]
-    plans += [('shared', t) for t in sorted(set([min(cores, 64), min(cores, 16)]), reverse=True)]
-    for mode, threads in plans:
-        t0 = time.perf_counter()
-        cn = oracle.count_flat(buf, k, threads=threads, mode=mode)
-        t = time.perf_counter() - t0
-        tried['%s_%d' % (mode, threads)] = t
-        assert int(cn.sum()) == budget_reads * (read_len - k + 1)
-        if tn is None or t < tn:
-            tn, best_threads, best_mode = t, threads, mode
-    assert int(c1.sum()) == budget_reads * (read_len - k + 1)
+    # Round 6: the private plan is timed on `big` when the caller has one (40 M reads of the run's own device buffer: 6 Gbases against
+    # ~2 s of fixed cost), every plan is compared by its RATE on its own sample, and the line says which sample the best one had.
     bases = budget_reads * read_len
+    plans = [('private', min(most_private, 64), big if big is not None else buf)]
+    if big is not None and most_private >= 128:
+        plans.append(('private', 128, big))
+    plans += [('shared', t, buf) for t in sorted(set([min(cores, 64), min(cores, 16)]), reverse=True)]
+    best_rate, best_reads = 0.0, budget_reads
+    for mode, threads, sample in plans:
+        sample_reads = sample.size // (read_len + 1)
+        t0 = time.perf_counter()
+        cn = oracle.count_flat(sample, k, threads=threads, mode=mode)
+        t = time.perf_counter() - t0
+        tried['%s_%d%s' % (mode, threads, '' if sample is buf else '_big')] = t
+        assert int(cn.sum()) == sample_reads * (read_len - k + 1)
+        del cn
+        rate = sample_reads * read_len / t
+        if rate > best_rate:
+            best_rate, tn, best_threads, best_mode, best_reads = rate, t, threads, mode, sample_reads
+    assert int(c1.sum()) == budget_reads * (read_len - k + 1)
     # BASELINE config 1: 10 k reads, k = 9 through the interpreter loop
     reads1 = [bytes(r).decode() for r in oracle.synth_reads(1, 0, 10000, 150).reshape(-1, 151)[:, :150]]
     t0 = time.perf_counter()
@@ -198,14 +218,16 @@ def cpu_baseline(k, read_len, budget_reads):
         'value': bases / t1 / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
         'sample': '%d synthetic %d bp reads, k=%d, oracle/kpal_oracle.c (1 thread: %.2f s)' % (budget_reads, read_len, k, t1),
         # the same figures as scalars (the driver's record keeps scalars only): all host cores, and the reference's own speed class
-        'all_cores_value': bases / tn / 1e9, 'all_cores_threads': best_threads, 'all_cores_tables': best_mode, 'host_cores': cores,
+        'all_cores_value': best_rate / 1e9, 'all_cores_threads': best_threads, 'all_cores_tables': best_mode, 'all_cores_sample_reads': best_reads, 'host_cores': cores,
         'python_loop_value': 1.5e6 / tp / 1e9, 'python_loop_sample': 'BASELINE config 1 (10000 reads, k=9), pure-Python restatement of klib.py:149-170, 1 core',
-        'all_cores': {'value': bases / tn / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn,
-                      'per_thread_efficiency': (bases / tn) / (bases / t1) / best_threads,
+        'all_cores': {'value': best_rate / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn, 'sample_reads': best_reads,
+                      'per_thread_efficiency': best_rate / (bases / t1) / best_threads,
                       'seconds_by_threads': tried,
                       'tables': best_mode,
                       'note': 'oracle/kpal_oracle.c on T threads: a private 4^k table per thread (calloc + merge timed) or one shared table with '
-                              'relaxed atomic adds; best of the (tables, threads) plans tried'},
+                              'relaxed atomic adds; best RATE of the (tables, threads) plans tried, each on its own sample (`_big`: the '
+                              'private plan on %d reads taken from the run\'s device buffer -- first touch and merge of T x 4^k entries are '
+                              'a fixed cost of about two seconds that a 4 M-read sample cannot amortise)' % (big.size // (read_len + 1) if big is not None else 0)},
         'python_reference_loop': {'value': 1.5e6 / tp / 1e9, 'unit': 'Gbases/s', 'cores': 1, 'seconds': tp,
                                   'sample': 'BASELINE config 1 (10000 reads, k=9) through oracle/pyref.py, the statement-by-statement restatement of kpal/klib.py:149-170'},
     }
@@ -273,11 +295,11 @@ def matrix_measure(ctx, k, P, dprof, host, metric_name, balance, steps, warmup, 
                     'memory_frac': mem_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': mem_bytes,
                     'avg_launch_ms': dom_ms}
     else:
-        # fp64 lane operations a multiset term NEEDS.  matrix_rdiff (prod as |1/(y+1) - 1/(x+1)| on staged reciprocals): its own
-        # algebra, a subtraction and an add of the absolute value = 2.  The pair-of-counts kernels (matrix_rsum / matrix_super /
+        # fp64 lane operations a multiset term NEEDS.  matrix_rdiff / matrix_rdiff_all (prod as |1/(y+1) - 1/(x+1)| on staged reciprocals): its own
+        # algebra, a subtraction and an add of the absolute value = 2.  The pair-of-counts kernels (matrix_rsum(_all) / matrix_super /
         # matrix_tile; metrics.py:118-123): |l - r|, the denominator and the division = 3.  The kernels' instruction counts are
         # higher (loader, conversions, term counts) and are not what the fraction is priced on
-        slots = 2.0 if dom == 'matrix_rdiff' else 3.0
+        slots = 2.0 if dom in ('matrix_rdiff', 'matrix_rdiff_all') else 3.0
         roofline = {'bound': 'fp64-valu', 'kernel': dom, 'achieved': terms * slots / (dom_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_T,
                     'unit': 'Tinstr/s (fp64 lane operations; %.0f necessary per term)' % slots,
                     'frac': terms * slots / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_T, 'traffic': None,
@@ -512,10 +534,11 @@ def run_extras(ctx, args, dev_buf, nbytes, headline_ms):
         dprof, host = matrix_profiles(ctx, 12, args.profiles, args.profile_reads, keep_host=0 if args.no_cpu else 8)
         try:
             extra['matrix_prod'] = matrix_measure(ctx, 12, args.profiles, dprof, host, 'prod', False, 3, 1, check=not args.no_cpu)
+            extra['matrix_sum'] = matrix_measure(ctx, 12, args.profiles, dprof, host, 'sum', False, 3, 1, check=not args.no_cpu)
             extra['matrix_euclidean'] = matrix_measure(ctx, 12, args.profiles, dprof, host, 'euclidean', False, 3, 1, check=not args.no_cpu)
         finally:
             ctx.free(dprof)
-        return {'config': 'BASELINE config 5: %d profiles k=12 (%d reads each, seed 100+p) resident in HBM; see matrix_prod / matrix_euclidean' % (args.profiles, args.profile_reads)}
+        return {'config': 'BASELINE config 5: %d profiles k=12 (%d reads each, seed 100+p) resident in HBM; see matrix_prod / matrix_sum / matrix_euclidean' % (args.profiles, args.profile_reads)}
     guarded('matrix', matrices)
 
     def fasta_end_to_end():
@@ -1113,6 +1136,7 @@ def main():
     ap.add_argument('--k', type=int, default=12)
     ap.add_argument('--strategy', default='auto')
     ap.add_argument('--cpu-reads', type=int, default=4_000_000, help='reads in the CPU-baseline sample')
+    ap.add_argument('--cpu-big-reads', type=int, default=40_000_000, help='reads in the sample of the private-table all-cores plan (N = 1; taken from the device buffer)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='N=1: skip BASELINE configs 4 / 5 and the end-to-end figures after the headline')
     ap.add_argument('--strong', action='store_true',
@@ -1183,12 +1207,21 @@ def main():
     }
     ok = r['checksum_ok']
     if not args.no_cpu:
-        line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads)
+        # the private-table plan of the all-cores figure gets a sample that amortises its fixed cost: the first 40 M reads of the
+        # device buffer (what the host's memory allows: the sample + 64..128 tables of 4^k entries)
+        big = None
+        big_reads = min(n_reads, args.cpu_big_reads)
+        if big_reads > args.cpu_reads and k <= 12:
+            big = np.empty(big_reads * (L + 1), dtype=np.uint8)
+            ctx.d2h(big, dev_buf)
+        line['cpu_baseline'] = cpu_baseline(k, L, args.cpu_reads, big=big)
+        del big
     if not args.no_extra and k == 12 and args.strategy == 'auto':
         line['extra'] = ex = run_extras(ctx, args, dev_buf, nbytes, r['ms_per_step'])
         # the other BASELINE configs and the host-resident figures as SCALARS of `config` (the driver's record keeps scalars only)
         for key, src, field in (('config4_k15_ms_per_step', 'k15', 'ms_per_step'), ('config4_k15_Gbases_per_s', 'k15', 'value'),
-                                ('config5_matrix_prod_ms', 'matrix_prod', 'ms_per_step'), ('config5_matrix_euclidean_ms', 'matrix_euclidean', 'ms_per_step'),
+                                ('config5_matrix_prod_ms', 'matrix_prod', 'ms_per_step'), ('config5_matrix_sum_ms', 'matrix_sum', 'ms_per_step'),
+                                ('config5_matrix_euclidean_ms', 'matrix_euclidean', 'ms_per_step'),
                                 ('host_reads_overlapped_Gbases_per_s', 'end_to_end', 'overlapped_Gbases_per_s'),
                                 ('fasta_file_Gbases_per_s', 'fasta_end_to_end', 'Gbases_per_s')):
             if isinstance(ex.get(src), dict) and field in ex[src]:

@@ -133,6 +133,7 @@ int kpal_count_records(kpal_ctx *ctx, int k, const uint8_t *host_flat, size_t nb
 int kpal_fasta_records_begin(kpal_ctx *ctx, const uint8_t *host_text, size_t nbytes, uint64_t *n_records, uint64_t *flat_bytes);
 int kpal_fasta_records_index(kpal_ctx *ctx, uint64_t *header_off, uint64_t *flat_start);
 int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *host_out);
+int kpal_fasta_records_count_device(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *dev_out);   /* the same into n x 4^k int64 of the caller's device memory (kpal_dev_alloc): profiles that stay in HBM */
 /* The same over a FILE the library reads itself (bytes [begin, end) of path; end = 0: to its end): after _open, every _next
  * indexes the next piece of whole records (as kpal_fasta_records_begin does for text) -- *text_offset = the file offset of the
  * piece's first byte (header offsets of kpal_fasta_records_index are relative to it), *done = 1 (and no records) after the last

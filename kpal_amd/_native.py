@@ -74,6 +74,7 @@ SIGNATURES = {
     'kpal_count_records': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
     'kpal_fasta_records_begin': (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'kpal_fasta_records_index': (ctypes.c_int, [_vp, _vp, _vp]),
+    'kpal_fasta_records_count_device': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     'kpal_fasta_records_file_open': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
     'kpal_fasta_records_file_next': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]),
     'kpal_fasta_records_file_tell': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
@@ -455,6 +456,11 @@ class Context(object):
         if n > 0:
             _check(self._L.kpal_fasta_records_count(self._h, int(k), int(first), int(n), out.ctypes.data))
         return out
+
+    def fasta_records_count_device(self, k, first, n, dev_out):
+        """Tables of records [first, first + n) of the indexed text into n * 4**k int64 of device memory at ``dev_out``."""
+        if n > 0:
+            _check(self._L.kpal_fasta_records_count_device(self._h, int(k), int(first), int(n), _vp(dev_out)))
 
     def count_bytes(self, k, buf, strategy='auto'):
         """Count one flat host byte stream -> int64[4**k]."""

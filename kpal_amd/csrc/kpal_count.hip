@@ -1098,21 +1098,18 @@ KPAL_API int kpal_fasta_records_index(kpal_ctx *ctx, uint64_t *header_off, uint6
     return KPAL_OK;
 }
 
-KPAL_API int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *host_out)
+// the tables of records [first, first + n) of the indexed text into n x 4^k int64 of DEVICE memory (queued on the context's stream)
+static int fasta_records_count_into(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, unsigned long long *dev_out)
 {
-    CTX_ENTER(ctx);
     if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
-    if (n == 0) return KPAL_OK;
-    if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
     if (first > ctx->rec_n || n > ctx->rec_n - first) return set_err(KPAL_E_INVALID, "records %llu..%llu of %llu", (unsigned long long)first,
                                                                       (unsigned long long)(first + n), (unsigned long long)ctx->rec_n);
     if (n >= 0xFFFFFFFFull) return set_err(KPAL_E_INVALID, "too many records in one batch");
     const uint64_t bins = 1ULL << (2 * k);
     const size_t out_bytes = (size_t)n * bins * sizeof(int64_t);
     const uint64_t b0 = ctx->rec_starts_host[(size_t)first], b1 = ctx->rec_starts_host[(size_t)(first + n)];
-    CHK(ensure(ctx, ctx->scratch[0], out_bytes));
     CHK(ensure(ctx, ctx->scratch[2], (size_t)(n + 1) * sizeof(uint64_t)));
-    HIPCHK(hipMemsetAsync(ctx->scratch[0].p, 0, out_bytes, ctx->stream));
+    HIPCHK(hipMemsetAsync(dev_out, 0, out_bytes, ctx->stream));
     if (b1 > b0) {
         LAUNCH(ctx, "fa_rebase", fa_rebase_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), (const uint64_t *)ctx->rec_starts.p + first, n + 1, b0,
                (uint64_t *)ctx->scratch[2].p);
@@ -1123,10 +1120,35 @@ KPAL_API int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint
         const uint64_t waves = (steps + spw - 1) / spw;
         const unsigned grid = (unsigned)((waves + 3) / 4);
         DISPATCH_K_1_16(k, LAUNCH(ctx, "count_records", (count_records_kernel<K>), dim3(grid), dim3(256), s, spw,
-                                  (const uint64_t *)ctx->scratch[2].p, (uint32_t)n, (unsigned long long *)ctx->scratch[0].p));
+                                  (const uint64_t *)ctx->scratch[2].p, (uint32_t)n, dev_out));
     }
+    return KPAL_OK;
+}
+
+KPAL_API int kpal_fasta_records_count(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *host_out)
+{
+    CTX_ENTER(ctx);
+    if (n == 0) return KPAL_OK;
+    if (!host_out) return set_err(KPAL_E_INVALID, "host_out is NULL");
+    if (k < 1 || k > KPAL_MAX_K) return set_err(KPAL_E_INVALID, "k=%d out of range 1..%d", k, KPAL_MAX_K);
+    const size_t out_bytes = (size_t)n * ((size_t)1 << (2 * k)) * sizeof(int64_t);
+    CHK(ensure(ctx, ctx->scratch[0], out_bytes));
+    CHK(fasta_records_count_into(ctx, k, first, n, (unsigned long long *)ctx->scratch[0].p));
     HIPCHK(hipMemcpyAsync(host_out, ctx->scratch[0].p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return KPAL_OK;
+}
+
+// ... into the CALLER's device memory (kpal_dev_alloc): the profiles of a by-record scan that stay in HBM until something on the
+// host asks for their counts (kpal_amd/klib.py: Profile.counts is materialised lazily; distances and matrices of such profiles
+// read the device copies)
+KPAL_API int kpal_fasta_records_count_device(kpal_ctx *ctx, int k, uint64_t first, uint64_t n, int64_t *dev_out)
+{
+    CTX_ENTER(ctx);
+    if (n == 0) return KPAL_OK;
+    if (!dev_out) return set_err(KPAL_E_INVALID, "dev_out is NULL");
+    CHK(fasta_records_count_into(ctx, k, first, n, (unsigned long long *)dev_out));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // (the index may be overwritten by the caller's next piece)
     return KPAL_OK;
 }
 

@@ -1271,6 +1271,21 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         constexpr bool GUARD = decltype(guard_tag)::value;
         // bin of k-mer i in its form: the low 6-2i bits of hi6 above the top L-6+2i bits of low -- with the item laid out
         // hi6 | low | mask4 that is ONE bit-field of the item: L bits from bit 10 - 2i
+#if defined(KPAL_AB_HIST_TWO_ADDS)   // A/B timing builds (wrong counts): what a histogram of (k + 1)-mers would issue -- two adds per item
+        if constexpr (!GUARD && !PACKED) {   // (1: the bins as they are; 2: 2^(L + 2) u16 bins per form, two forms: the half-word select as well)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const uint32_t counted = __builtin_amdgcn_ubfe(it, 3 - i, 1) & __builtin_amdgcn_ubfe(it, 2 - i, 1);
+                if (KPAL_AB_HIST_TWO_ADDS == 2) {
+                    const uint32_t local = __builtin_amdgcn_ubfe(it, 8 - 2 * i, L + 2);                  // 15 bits at k = 12
+                    atomicAdd(&hist[(uint32_t)(i / 2) * (uint32_t)(2 * BINS) + (local >> 1)], counted << (16u * (local & 1u)));
+                } else {
+                    atomicAdd(&hist[plane_of(i) + stage_swizzle(i, __builtin_amdgcn_ubfe(it, 10 - 2 * i, L))], counted);
+                }
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t counted = __builtin_amdgcn_ubfe(it, 3 - i, 1);

@@ -108,6 +108,15 @@ class ProfileDistance(object):
         """Distance between two profiles; the inputs are left unmodified
         (kpal/kdistlib.py:126-161, tests/test_kdistlib.py:124-135)."""
         metric = self._native_metric()
+        dev = _device_pair(left, right)
+        if dev is not None:
+            # both tables are still in HBM (klib.Profile.from_fasta_by_record): the same kernels on the device copies, no transfer
+            ctx, dl, dr = dev
+            if self._is_plain() and metric is not None and metric != _native.COSINE:
+                return ctx.pair_distance_device(4 ** left.length, dl, dr, metric, do_balance=self._do_balance, k=left.length)
+            options = self._native_options()
+            if options is not None:
+                return ctx.profile_distance_device(left.length, dl, dr, options)
         integer = (np.asanyarray(left.counts).dtype.kind in 'iub' and np.asanyarray(right.counts).dtype.kind in 'iub'
                    and len(left.counts) == len(right.counts))
         if self._is_plain() and metric is not None and metric != _native.COSINE and integer:
@@ -153,6 +162,10 @@ def distance_matrix(profiles, output, precision, dist):
 
     metric = dist._native_metric()
     same_k = len(set(p.length for p in profiles)) == 1
+    values = _device_matrix(profiles, dist, metric) if same_k else None
+    if values is not None:
+        _write_matrix(output, count, values, precision)
+        return
     integer = all(np.asanyarray(p.counts).dtype.kind in 'iub' for p in profiles)
     options = dist._native_options() if (same_k and integer) else None
     if dist._is_plain() and metric is not None and metric != _native.COSINE and same_k and integer:
@@ -164,9 +177,57 @@ def distance_matrix(profiles, output, precision, dist):
     else:
         values = [dist.distance(profiles[i], profiles[j]) for i in range(1, count) for j in range(i)]
 
+    _write_matrix(output, count, values, precision)
+
+
+def _write_matrix(output, count, values, precision):
     fmt = '{{0:.{0}f}}'.format(precision)
     at = 0
     for i in range(1, count):
         output.write(' '.join(fmt.format(values[at + j]) for j in range(i)))
         output.write('\n')
         at += i
+
+
+def _device_pair(left, right):
+    """(context, device address of left, of right) when both profiles' tables are still in HBM on one context, else None."""
+    a = getattr(left, '_device_counts', None)
+    b = getattr(right, '_device_counts', None)
+    if a is None or b is None or left.length != right.length:
+        return None
+    a, b = a(), b()
+    if not a or not b or a[0] is not b[0]:
+        return None
+    return a[0], a[1], b[1]
+
+
+def _device_matrix(profiles, dist, metric):
+    """The matrix values of profiles whose tables are ALL still in HBM (one context, one k) without a transfer: consecutive
+    tables of one batch are used where they lie, anything else is gathered by device-to-device copies first.  None when a
+    profile has host counts, or when a user-supplied callable keeps the distance in Python."""
+    devs = []
+    for p in profiles:
+        d = getattr(p, '_device_counts', None)
+        d = d() if d is not None else None
+        if not d or (devs and d[0] is not devs[0][0]):
+            return None
+        devs.append(d)
+    plain = dist._is_plain() and metric is not None and metric != _native.COSINE
+    options = None if plain else dist._native_options()
+    if not plain and options is None:
+        return None
+    ctx, k, P = devs[0][0], profiles[0].length, len(profiles)
+    table_bytes = 8 * 4 ** k
+    if not plain:        # the option kernels work pair by pair (balancing, positive, smoothing and scaling depend on the partner)
+        return [ctx.profile_distance_device(k, devs[i][1], devs[j][1], options) for i in range(1, P) for j in range(i)]
+    base, gathered = devs[0][1], None
+    if any(devs[i][1] != base + i * table_bytes for i in range(P)):
+        gathered = base = ctx.alloc(P * table_bytes)
+        for i in range(P):
+            ctx.d2d(base + i * table_bytes, devs[i][1], table_bytes)
+    try:
+        return ctx.distance_matrix_device(P, k, base, metric, do_balance=dist._do_balance)
+    finally:
+        if gathered is not None:
+            ctx.sync()
+            ctx.free(gathered)

@@ -40,7 +40,42 @@ _FEED_BYTES = 32 << 20  # host-side join buffer per feed
 _GATHER_BYTES = 64 << 20  # page-locked gather buffer of from_sequences
 _GATHER_THREADS = max(1, min(64, int(os.environ.get('KPAL_GATHER_THREADS', '16'))))   # threads of the gatherer (walk + copies; 4 / 8 / 16 / 32: 114 / 88 / 80 / 92 ms for 8 M reads)
 _JOIN_BLOCK = 4096       # sequences joined per C-level call
-_RECORD_BATCH_BYTES = 1 << 30   # tables downloaded per from_fasta_by_record batch
+_RECORD_BATCH_BYTES = 1 << 30   # tables counted per from_fasta_by_record batch
+# from_fasta_by_record leaves its tables in HBM (Profile.counts downloads on first access) while no more than this many bytes of
+# them are alive; past it a batch is downloaded at once, as before round 6 (KPAL_DEVICE_PROFILE_BYTES; 0: always download)
+_DEVICE_PROFILE_BYTES = int(os.environ.get('KPAL_DEVICE_PROFILE_BYTES', str(64 << 30)))
+
+
+class _DeviceBatch(object):
+    """The tables of one batch of ``from_fasta_by_record`` in device memory: n x 4^k int64, never written again.  Every
+    profile of the batch that has not been asked for its counts yet holds a reference; the memory goes back when the last
+    one is dropped or materialised."""
+    live_bytes = 0
+
+    def __init__(self, ctx, nbytes, n_tables):
+        self.ctx, self.nbytes, self.n_tables = ctx, int(nbytes), int(n_tables)
+        self.ptr = ctx.alloc(self.nbytes)
+        self.host = None
+        _DeviceBatch.live_bytes += self.nbytes
+
+    def table(self, index):
+        """Table ``index`` on the host.  The first request brings the WHOLE batch over in one copy (a profile at a time cost
+        140 us per 512 KiB table: `kpal count --by-record` asks for every one of them); the rows are views of that array, as
+        the tables of a batch were before round 6."""
+        if self.host is None:
+            host = np.empty((self.n_tables, self.nbytes // (8 * self.n_tables)), dtype=np.int64)
+            self.ctx.d2h(host, self.ptr)
+            self.host = host
+        return self.host[index]
+
+    def __del__(self):
+        try:
+            _DeviceBatch.live_bytes -= self.nbytes
+            if getattr(self.ctx, '_h', None):      # (a context that has been closed took its allocations with it)
+                self.ctx.free(self.ptr)
+        except Exception:       # pragma: no cover  (interpreter shutdown)
+            pass
+
 _FASTA_CHUNK = 64 << 20  # FASTA text read per device feed (cut back to a record boundary)
 _DROPPED = {ord(' '): None, ord('\r'): None}   # removed from the joined record (Biopython's SimpleFastaParser)
 
@@ -239,6 +274,45 @@ class Profile(object):
         self.counts = counts
         self.name = name
 
+    # ---- counts that may still be in HBM -----------------------------------------------------
+    # The reference's ``counts`` is a plain attribute holding a NumPy array that callers read AND write in place
+    # (kpal/klib.py:58-61, kmer.py:137-146).  Here it is a property: a profile made by from_fasta_by_record starts with its table
+    # in device memory only (``_device`` = (batch, index)); the first access downloads it, and from then on the host array is
+    # the one truth -- the device copy is let go at that moment, because whoever holds the array may change it.  Distances,
+    # matrices and the summaries of profiles nobody has looked at read the device copies (kdistlib.py, _device_stats).
+    @classmethod
+    def _from_device(cls, batch, index, length, name, private=False):
+        """private: a copy() of a profile that is still in HBM -- it shares the (never written) device table, but when it is asked
+        for counts it downloads its own array: the row of the batch's host array may be in someone's hands already."""
+        p = cls.__new__(cls)
+        p._counts, p._device = None, (batch, int(index), bool(private))
+        p.length = int(length)
+        p.name = name
+        return p
+
+    @property
+    def counts(self):
+        if self._counts is None and self._device is not None:
+            batch, index, private = self._device
+            if private:
+                out = np.empty(4 ** self.length, dtype=np.int64)
+                batch.ctx.d2h(out, batch.ptr + index * out.nbytes)
+            else:
+                out = batch.table(index)
+            self._counts, self._device = out, None
+        return self._counts
+
+    @counts.setter
+    def counts(self, value):
+        self._counts, self._device = value, None
+
+    def _device_counts(self):
+        """(context, device address) of the int64 table while it lives in HBM only, else None."""
+        if self._counts is None and self._device is not None:
+            batch, index, _ = self._device
+            return batch.ctx, batch.ptr + index * 8 * 4 ** self.length
+        return None
+
     # ---- constructors --------------------------------------------------------------------
     @classmethod
     def from_file(cls, handle, name=None):
@@ -372,9 +446,8 @@ class Profile(object):
                                 raise RuntimeError('from_fasta_by_record: bytes %d..%d of %s changed under the scan' % (at, resume, plain[0]))
                             scan = ctx._records_scan
                         n = min(per_batch, n_records - first)
-                        tables = ctx.fasta_records_count(length, first, n)
-                        for j in range(n):
-                            yield cls(tables[j], name=names[first + j])
+                        for profile in cls._record_batch(ctx, length, first, n, names):
+                            yield profile
             handle.seek(0, os.SEEK_END)          # the handle has been consumed, as by the reference's SeqIO.parse loop
             return
         for text, text_str, encoding in _whole_record_chunks(handle):
@@ -395,9 +468,20 @@ class Profile(object):
                     ctx.fasta_records_begin(text)
                     scan = ctx._records_scan
                 n = min(per_batch, n_records - first)
-                tables = ctx.fasta_records_count(length, first, n)
-                for j in range(n):
-                    yield cls(tables[j], name=names[first + j])
+                for profile in cls._record_batch(ctx, length, first, n, names):
+                    yield profile
+
+    @classmethod
+    def _record_batch(cls, ctx, length, first, n, names):
+        """The profiles of records [first, first + n) of the text the context has indexed.  Their tables stay in HBM (one
+        allocation per batch) while the budget of live device tables allows; else they are downloaded at once."""
+        nbytes = n * 8 * 4 ** length
+        if _DEVICE_PROFILE_BYTES and _DeviceBatch.live_bytes + nbytes <= _DEVICE_PROFILE_BYTES:
+            batch = _DeviceBatch(ctx, nbytes, n)
+            ctx.fasta_records_count_device(length, first, n, batch.ptr)
+            return [cls._from_device(batch, j, length, names[first + j]) for j in range(n)]
+        tables = ctx.fasta_records_count(length, first, n)
+        return [cls(tables[j], name=names[first + j]) for j in range(n)]
 
     @classmethod
     def from_sequences(cls, sequences, length, name=None):
@@ -445,19 +529,24 @@ class Profile(object):
     @property
     def number(self):
         """Number of possible k-mers of this length."""
-        return len(self.counts)
+        return 4 ** self.length if self._counts is None and self._device is not None else len(self.counts)
 
     @property
     def non_zero(self):
-        return np.count_nonzero(self.counts)
+        dev = self._device_counts()
+        return int(dev[0].stats_device(dev[1], self.number).non_zero) if dev else np.count_nonzero(self.counts)
 
     @property
     def total(self):
-        return self.counts.sum()
+        dev = self._device_counts()
+        return np.int64(dev[0].stats_device(dev[1], self.number).total) if dev else self.counts.sum()
 
     def _device_stats(self):
-        """``kpal_stats`` over integer counts (one upload, two streaming passes and a radix select),
-        or None when the counts are not integers (scaled profiles keep NumPy's float formulation)."""
+        """``kpal_stats`` over integer counts (one upload -- none for a table that is still in HBM --, two streaming passes and
+        a radix select), or None when the counts are not integers (scaled profiles keep NumPy's float formulation)."""
+        dev = self._device_counts()
+        if dev:
+            return dev[0].stats_device(dev[1], self.number)
         c = np.asanyarray(self.counts)
         if c.dtype.kind not in 'iub' or c.ndim != 1 or c.size == 0:
             return None
@@ -506,7 +595,10 @@ class Profile(object):
         return name
 
     def copy(self):
-        """Deep copy (kpal/klib.py:258-267)."""
+        """Deep copy (kpal/klib.py:258-267).  (A table that is still in HBM is never written: the copy shares it until either
+        profile is asked for its counts.)"""
+        if self._counts is None and self._device is not None:
+            return type(self)._from_device(self._device[0], self._device[1], self.length, self.name, private=True)
         return type(self)(self.counts.copy(), name=self.name)
 
     def merge(self, profile, merger=metrics.mergers['sum']):

@@ -142,12 +142,12 @@ def test_fake_rccl_world_test_has_teeth(tmp_path, fault):
     mirrored-range exchange, or (asynchronous mode) lets the stream go on before the collective's data has arrived -- what a missing
     dependency between streams amounts to: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
     extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if fault == 'early' else {}
-    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='12', **extra)
+    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='8', **extra)
     assert any(p.returncode != 0 for p in procs), outs
     assert any('AssertionError' in out for out in outs), outs
 
 
-@pytest.mark.parametrize('mode', ['sync', 'async'])
+@pytest.mark.parametrize('mode', ['async'])       # ('sync' -- every collective completed inside the call -- passes too and is the schedule with fewer ways to go wrong: tools/multi_rank_one_gpu.sh runs both)
 @pytest.mark.parametrize('world', [2, 4])
 def test_library_comm_world_over_fake_rccl(tmp_path, world, mode):
     """The library's kpal_comm_* protocol between W real processes on the one GPU of this box: RCCL refuses two ranks on one device,
@@ -162,7 +162,7 @@ def test_library_comm_world_over_fake_rccl(tmp_path, world, mode):
         assert p.returncode == 0 and 'RCCL_WORLD_OK rank %d of %d' % (r, world) in out, 'rank %d:\n%s' % (r, out[-3000:])
 
 
-@pytest.mark.parametrize('mode', ['sync', 'async'])
+@pytest.mark.parametrize('mode', ['async'])       # (as above)
 def test_bench_two_ranks_library_modes_over_fake_rccl(tmp_path, mode):
     """bench.py's N > 1 path with TWO real ranks AND the library's reduce modes: as test_bench_two_ranks_sharing_one_gpu, with the
     stand-in of tests/native/fake_rccl.cpp behind the library's communicator -- pipelined and serial in-library reduce, the torch
@@ -195,7 +195,7 @@ def test_bench_supervisors_restart_after_a_hung_collective(tmp_path, mode):
     must print ONE verified line that says so."""
     import json
     env = dict(os.environ, KPAL_BENCH_SHARED_GPU='1', KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY='0',
-               KPAL_FAKE_RCCL_FAULT='stall', KPAL_FAKE_RCCL_TIMEOUT_S='600', KPAL_BENCH_RUN_TIMEOUT='25')
+               KPAL_FAKE_RCCL_FAULT='stall', KPAL_FAKE_RCCL_TIMEOUT_S='600', KPAL_BENCH_RUN_TIMEOUT='15')
     if mode == 'async':
         env.update(KPAL_FAKE_RCCL_ASYNC='1')
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

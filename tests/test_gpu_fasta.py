@@ -218,6 +218,100 @@ def test_from_fasta_by_record_file(tmp_path, monkeypatch):
             ctx2.close()
 
 
+def test_by_record_profiles_stay_in_hbm(ctx, tmp_path, monkeypatch):
+    """Profiles of from_fasta_by_record keep their tables in HBM until something asks for ``counts`` (kpal/klib.py:114-133 ->
+    kmer.py:683-700 without the tables crossing PCIe twice): name / length / number / total / non_zero / summary and copy()
+    without a download; ProfileDistance.distance (plain, balanced, euclidean, with options) and kdistlib.distance_matrix on the
+    device copies give the SAME bits as on downloaded copies; the first access to ``counts`` downloads and lets the device copy
+    go -- an in-place change of that array is what every later distance sees (the reference's callers mutate counts: SURVEY 7);
+    the budget of live device tables: past it batches are downloaded at once; the memory goes back when the profiles do."""
+    import gc
+    from kpal_amd import kdistlib, klib, metrics
+    rnd = random.Random(31)
+    text = random_fasta(rnd, 23, 3000)
+    recs = seqio_records(text)
+    k = 5
+    monkeypatch.setattr(klib, '_RECORD_BATCH_BYTES', 7 * 8 * 4 ** k)         # seven records per batch: profiles of several batches
+    gc.collect()
+    live0 = klib._DeviceBatch.live_bytes
+    profiles = list(klib.Profile.from_fasta_by_record(io.StringIO(text), k))
+    assert len(profiles) == len(recs) and all(p._device_counts() is not None for p in profiles)
+    assert klib._DeviceBatch.live_bytes - live0 == len(recs) * 8 * 4 ** k
+    want = [oracle.from_sequences([seq], k) for _, seq in recs]
+    for p, w, (name, _) in zip(profiles, want, recs):
+        assert p.length == k and p.number == 4 ** k and int(p.total) == int(w.sum()) and int(p.non_zero) == int(np.count_nonzero(w))
+        s = p.summary()
+        assert int(s['total']) == int(w.sum()) and abs(float(s['mean']) - w.mean()) <= 1e-12 * max(1.0, w.mean()) and float(s['median']) == float(np.median(w))
+    assert all(p._device_counts() is not None for p in profiles)               # nothing above downloaded a table
+    host = [klib.Profile(w.copy(), name=p.name) for p, w in zip(profiles, want)]
+    dists = [kdistlib.ProfileDistance(), kdistlib.ProfileDistance(do_balance=True), kdistlib.ProfileDistance(pairwise=metrics.pairwise['sum']),
+             kdistlib.ProfileDistance(distance_function=metrics.euclidean), kdistlib.ProfileDistance(distance_function=metrics.cosine_similarity),
+             kdistlib.ProfileDistance(do_smooth=True, summary=metrics.summary['average'], threshold=2), kdistlib.ProfileDistance(do_scale=True, down=True),
+             kdistlib.ProfileDistance(do_positive=True, do_balance=True)]
+    def same(a, b):
+        return a == b or (a != a and b != b)              # (an empty record: nan from both)
+
+    for d in dists:
+        for i, j in ((1, 0), (8, 3), (22, 7), (15, 14)):
+            assert same(d.distance(profiles[i], profiles[j]), d.distance(host[i], host[j])), (i, j)
+        a, b = io.StringIO(), io.StringIO()
+        kdistlib.distance_matrix(profiles, a, 10, d)
+        kdistlib.distance_matrix(host, b, 10, d)
+        assert a.getvalue() == b.getvalue()
+    sub = profiles[7:14]                                                       # one whole batch: used where it lies
+    a, b = io.StringIO(), io.StringIO()
+    kdistlib.distance_matrix(sub, a, 10, dists[0])
+    kdistlib.distance_matrix(host[7:14], b, 10, dists[0])
+    assert a.getvalue() == b.getvalue()
+    assert all(p._device_counts() is not None for p in profiles)               # distances and matrices read the device copies
+    # a user-supplied callable: the reference's NumPy path on downloaded counts
+    custom = kdistlib.ProfileDistance(pairwise=lambda x, y: abs(x - y) / (x + y + 2.0))
+    assert same(custom.distance(profiles[2], profiles[1]), custom.distance(host[2], host[1]))
+    assert profiles[2]._device_counts() is None and profiles[1]._device_counts() is None
+    # copy() shares the device table; the first look at counts downloads it and the array is the truth from then on
+    c = profiles[4].copy()
+    assert c._device_counts() is not None and c.name == profiles[4].name
+    arr = profiles[4].counts
+    np.testing.assert_array_equal(arr, want[4])
+    assert profiles[4]._device_counts() is None and c._device_counts() is not None
+    arr[3] += 7
+    changed = klib.Profile(want[4].copy())
+    changed.counts[3] += 7
+    assert same(dists[0].distance(profiles[4], profiles[5]), dists[0].distance(changed, host[5]))
+    assert same(dists[0].distance(c, profiles[5]), dists[0].distance(host[4], host[5]))      # the copy still has the counted table
+    profiles[6].counts = want[6] * 2                                           # the setter drops the device copy as well
+    assert profiles[6]._device_counts() is None and int(profiles[6].total) == 2 * int(want[6].sum())
+    profiles[9].balance()
+    np.testing.assert_array_equal(profiles[9].counts, oracle.balance(want[9], k))
+    # mixed: some on the device, some on the host -> the host path, same text
+    a, b = io.StringIO(), io.StringIO()
+    kdistlib.distance_matrix(profiles[:6], a, 8, dists[0])
+    ref = [klib.Profile(w.copy(), name=p.name) for p, w in zip(profiles[:6], want[:6])]
+    ref[4].counts[3] += 7
+    kdistlib.distance_matrix(ref, b, 8, dists[0])
+    assert a.getvalue() == b.getvalue()
+    # saving (kmer.count --by-record) materialises; the file holds the counted table
+    import memh5
+    h5 = memh5.File()
+    h5.create_group('profiles')
+    profiles[11].name = 'rec11'
+    profiles[11].save(h5)
+    np.testing.assert_array_equal(h5['profiles/rec11'][:], want[11])
+    assert profiles[11]._device_counts() is None
+    # the budget: nothing stays on the device past it
+    del profiles, sub, c, arr
+    gc.collect()
+    assert klib._DeviceBatch.live_bytes == live0
+    monkeypatch.setattr(klib, '_DEVICE_PROFILE_BYTES', 10 * 8 * 4 ** k)
+    mixed = list(klib.Profile.from_fasta_by_record(io.StringIO(text), k))
+    assert [p._device_counts() is not None for p in mixed] == [True] * 7 + [False] * (len(recs) - 7)
+    for p, w in zip(mixed, want):
+        np.testing.assert_array_equal(p.counts, w)
+    del mixed
+    gc.collect()
+    assert klib._DeviceBatch.live_bytes == live0
+
+
 def test_fasta_records_c_abi(ctx, tmp_path):
     """kpal_fasta_records_* through the binding: the index (header offsets into the text, record starts in the flattened stream),
     batches of any size at any record (also starting in the middle of a 16-byte chunk of the flattened text), errors, and

@@ -151,6 +151,13 @@ def test_full_size_skewed_k12(cases):
         ctx.close()
 
 
+# k = 15: the first quarter of every case (256 MiB of whole reads).  The paths at stake -- FRESH lists (first whole-buffer piece of
+# at least max(64 MiB, 4^k / 8 B = 128 MiB)), their overflow and the classic rerun, level-1 / level-2 spill lists and hot-item
+# tables -- are the same from that size on, and eight cases x (three 8 GiB tables + the host oracle over the downloaded bytes) at
+# 1 GiB took three minutes of the GPU suite's time box (round 5: 141 s, round 6: 181 s).  k = 12 stays at 1 GiB.
+NBYTES_K15 = (NBYTES // 4) // L * L
+
+
 def test_full_size_skewed_k15(cases):
     from kpal_amd import _native, dist
     import torch
@@ -170,7 +177,8 @@ def test_full_size_skewed_k15(cases):
     sel_t = torch.as_tensor(sel, device='cuda:0')
     try:
         seen = {}
-        for name, t in cases.items():
+        for name, whole in cases.items():
+            t = whole[:NBYTES_K15]
             before = ctx.count_stats()
             host = t.cpu().numpy()
             torch.cuda.synchronize()
@@ -196,8 +204,9 @@ def test_full_size_skewed_k15(cases):
             # (one hot bin: a shared table with atomic adds serialises the host threads -- few threads there)
             threads = 2 if name == 'homopolymer' else min(32, os.cpu_count() or 1)
             plain, mirror = oracle.count_blocks(host, k, block_bits, sel, threads=threads)
-            np.testing.assert_array_equal(blocks, plain, err_msg='%s plain, plan %r' % (name, plan))
-            np.testing.assert_array_equal(bal_blocks, plain + mirror, err_msg='%s balanced, plan %r' % (name, plan))
+            assert np.array_equal(blocks, plain), '%s plain, plan %r' % (name, plan)
+            mirror += plain
+            assert np.array_equal(bal_blocks, mirror), '%s balanced, plan %r' % (name, plan)
             seen[name] = (plan, total, {key: after[key] - before[key] for key in after})
             if name in ('low_complexity_2pct', 'adapter_prefixed'):
                 # the same feed on the context with tiny bypass lists: FRESH, overflow, run again the classic way -- same table
@@ -215,7 +224,7 @@ def test_full_size_skewed_k15(cases):
         print('k=15 plans, totals and slow-path statistics (two counts per case):', seen)
         assert seen['uniform'][0][0] == 'partition2_quads' and seen['uniform'][2]['fresh_pieces'] == 2
         assert seen['uniform'][2]['spilled_items'] > 0
-        assert seen['homopolymer'][1] == NBYTES // L * L - k + 1
+        assert seen['homopolymer'][1] == NBYTES_K15 - k + 1
         assert seen['homopolymer'][2]['hot_entries'] > 0, seen['homopolymer']
         assert any(seen[n + '/small_lists']['fresh_reruns'] >= 1 for n in ('low_complexity_2pct', 'adapter_prefixed')), seen
     finally:

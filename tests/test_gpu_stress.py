@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('tool,seconds,seed', [('stress_count.py', 35, 4), ('stress_vec.py', 20, 4)])
+# (the long campaigns: tools/stress_campaign.sh, profiles/)
+@pytest.mark.parametrize('tool,seconds,seed', [('stress_count.py', 15, 4), ('stress_vec.py', 10, 4)])
 def test_stress_slice(tool, seconds, seed):
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', tool), '--seconds', str(seconds), '--seed', str(seed)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=480)
     out = p.stdout.decode()
     assert p.returncode == 0 and 'stress ok' in out, out[-3000:]
     cases = int(out.split('stress ok:')[1].split('cases')[0])
-    assert cases >= 5, out[-500:]
+    assert cases >= 3, out[-500:]

@@ -99,7 +99,29 @@ def by_record_bench(ctx, args):
             assert n == nrec and names[:2] == ['chr1', 'chr2'] and names[-1] == 'chr%d' % nrec, (n, names)
             assert total <= int(whole.total) and total >= (nrec - 1) * per_record_kmers, (total, int(whole.total))
             row['by_record'] = {'s': min(times), 'Gbases_per_s': bases / min(times) / 1e9, 'records_per_s': nrec / min(times),
-                                'tables_GBs': nrec * 8 * 4 ** k / min(times) / 1e9}
+                                'tables_GBs': nrec * 8 * 4 ** k / min(times) / 1e9,
+                                'note': 'the profiles are built and dropped; since round 6 their tables stay in HBM until something asks for counts'}
+            # ... and with every table brought to the host (what `kpal count --by-record` needs for the HDF5 file)
+            t = time.perf_counter()
+            with open(path) as fh:
+                got = sum(int(p.counts[0]) >= 0 for p in klib.Profile.from_fasta_by_record(fh, k))
+            dt = time.perf_counter() - t
+            assert got == nrec
+            row['by_record_downloaded'] = {'s': dt, 'Gbases_per_s': bases / dt / 1e9, 'tables_GBs': nrec * 8 * 4 ** k / dt / 1e9}
+            # the library flow the device tables are for: the records' profiles straight into a distance matrix (kmer.py:137-146 ->
+            # 683-700 in one process), first 64 records
+            import io
+            from kpal_amd import kdistlib
+            t = time.perf_counter()
+            with open(path) as fh:
+                gen = klib.Profile.from_fasta_by_record(fh, k)
+                some = [p for _, p in zip(range(64), gen)]
+                gen.close()
+            out_text = io.StringIO()
+            kdistlib.distance_matrix(some, out_text, 3, kdistlib.ProfileDistance())
+            dt = time.perf_counter() - t
+            row['first_64_records_to_matrix'] = {'s': dt, 'on_device': all(p._device_counts() is not None for p in some), 'lines': out_text.getvalue().count('\n')}
+            del some
             t = time.perf_counter()
             with open(path) as fh:
                 m = sum(len(sq) for _, sq in klib._fasta_records(fh))

@@ -23,7 +23,8 @@
 
 enum Op {
     FMA_F32 = 0, ADD_F64, FMA_F64, PERM, DOT4, LSHL_OR, AND_OR, BFE, LSHRREV_B64, MOV_DPP_SHR, READLANE, ADD_U32, LSHLREV, XOR, CNDMASK,
-    BCNT, MBCNT, CMP_EQ, ADD3, MUL_LO, MUL_U24, MAD_U24, SAD, CVT_F64_U32, ALIGNBIT, PK_ADD_F32, ADD_LSHL, MOV, LSHL_ADD, OR3, MIX_SCATTER, NOPS
+    BCNT, MBCNT, CMP_EQ, ADD3, MUL_LO, MUL_U24, MAD_U24, SAD, CVT_F64_U32, ALIGNBIT, PK_ADD_F32, ADD_LSHL, MOV, LSHL_ADD, OR3, MIX_SCATTER, NOPS,
+    BITOP3, LSHRREV, AND, OR, SUB, NOT, CNDMASK_SGPR, CNDMASK_ALT, LSHL_ADD_U64, CMP_GT_U64, WRITELANE, CMP_CNDMASK
 };
 
 #define ONE8(INS)                                                                                                                 \
@@ -64,6 +65,16 @@ enum Op {
 #define I_LSHL_ADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %9\n"
 #define I_OR3(n) "v_or3_b32 %" #n ", %" #n ", %8, %9\n"
 #define I_NOP(n) "s_nop 0\n"
+#define I_BITOP3(n) "v_bitop3_b32 %" #n ", %" #n ", %8, %9 bitop3:0x96\n"
+#define I_LSHRREV(n) "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
+#define I_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define I_OR(n) "v_or_b32 %" #n ", %" #n ", %8\n"
+#define I_SUB(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define I_NOT(n) "v_not_b32 %" #n ", %" #n "\n"
+#define I_CNDMASK_SGPR(n) "v_cndmask_b32 %" #n ", %" #n ", %8, s[42:43]\n"
+#define I_WRITELANE(n) "v_writelane_b32 %" #n ", s44, 7\n"
+#define I_LSHL_ADD_U64(n) "v_lshl_add_u64 %" #n ", %" #n ", 0, %8\n"
+#define I_CMP_GT_U64(n) "v_cmp_gt_u64 vcc, %" #n ", %8\n"
 #define I_ADD_F64(n) "v_add_f64 %" #n ", %" #n ", %8\n"
 #define I_FMA_F64(n) "v_fma_f64 %" #n ", %" #n ", %8, %" #n "\n"
 #define I_LSHRREV_B64(n) "v_lshrrev_b64 %" #n ", 3, %" #n "\n"
@@ -118,6 +129,41 @@ __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t seed, u
             else if constexpr (OP == LSHL_ADD) ONE8(I_LSHL_ADD);
             else if constexpr (OP == OR3) ONE8(I_OR3);
             else if constexpr (OP == NOPS) ONE8(I_NOP);
+            else if constexpr (OP == BITOP3) ONE8(I_BITOP3);
+            else if constexpr (OP == LSHRREV) ONE8(I_LSHRREV);
+            else if constexpr (OP == AND) ONE8(I_AND);
+            else if constexpr (OP == OR) ONE8(I_OR);
+            else if constexpr (OP == SUB) ONE8(I_SUB);
+            else if constexpr (OP == NOT) ONE8(I_NOT);
+            else if constexpr (OP == CNDMASK_SGPR) {
+                asm volatile(I_CNDMASK_SGPR(0) I_CNDMASK_SGPR(1) I_CNDMASK_SGPR(2) I_CNDMASK_SGPR(3) I_CNDMASK_SGPR(4) I_CNDMASK_SGPR(5) I_CNDMASK_SGPR(6) I_CNDMASK_SGPR(7)
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             : "v"(c0)
+                             : "s42", "s43");
+            } else if constexpr (OP == CNDMASK_ALT) {   // every second instruction something else: is it the back-to-back select that is slow?
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_xor_b32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_xor_b32 %3, %3, %8\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\n v_xor_b32 %5, %5, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_xor_b32 %7, %7, %8\n"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             : "v"(c0)
+                             : "vcc");
+            } else if constexpr (OP == CMP_CNDMASK) {   // the usual pair: a compare that writes vcc, the select that reads it
+                asm volatile("v_cmp_gt_u32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_gt_u32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cmp_gt_u32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_gt_u32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             : "v"(c0)
+                             : "vcc");
+            } else if constexpr (OP == WRITELANE) {
+                asm volatile(I_WRITELANE(0) I_WRITELANE(1) I_WRITELANE(2) I_WRITELANE(3) I_WRITELANE(4) I_WRITELANE(5) I_WRITELANE(6) I_WRITELANE(7)
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             :
+                             : "s44");
+            } else if constexpr (OP == LSHL_ADD_U64) ONE8D(I_LSHL_ADD_U64);
+            else if constexpr (OP == CMP_GT_U64) {
+                asm volatile(I_CMP_GT_U64(0) I_CMP_GT_U64(1) I_CMP_GT_U64(2) I_CMP_GT_U64(3) I_CMP_GT_U64(4) I_CMP_GT_U64(5) I_CMP_GT_U64(6) I_CMP_GT_U64(7)
+                             :
+                             : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(dc)
+                             : "vcc");
+            }
             else if constexpr (OP == ADD_F64) ONE8D(I_ADD_F64);
             else if constexpr (OP == FMA_F64) ONE8D(I_FMA_F64);
             else if constexpr (OP == LSHRREV_B64) ONE8D(I_LSHRREV_B64);
@@ -228,5 +274,17 @@ int main()
     run<FMA_F64>("v_fma_f64", dout);
     run<CVT_F64_U32>("v_cvt_f64_u32", dout);
     run<MIX_SCATTER>("mix of 8 (scatter)", dout);
+    run<AND>("v_and_b32", dout);
+    run<OR>("v_or_b32", dout);
+    run<SUB>("v_sub_u32", dout);
+    run<NOT>("v_not_b32", dout);
+    run<LSHRREV>("v_lshrrev_b32", dout);
+    run<BITOP3>("v_bitop3_b32", dout);
+    run<CNDMASK_SGPR>("v_cndmask_b32 (sgpr)", dout);
+    run<CNDMASK_ALT>("v_cndmask + v_xor", dout);
+    run<CMP_CNDMASK>("v_cmp + v_cndmask", dout);
+    run<WRITELANE>("v_writelane_b32", dout);
+    run<LSHL_ADD_U64>("v_lshl_add_u64", dout);
+    run<CMP_GT_U64>("v_cmp_gt_u64 -> vcc", dout);
     return 0;
 }
