@@ -402,9 +402,7 @@ int distance_matrix_core(kpal_ctx *ctx, int P, uint64_t n, const int64_t *prof, 
         HIPCHK(hipMemsetAsync(big, 0, 32, ctx->stream));
         HIPCHK(hipMemsetAsync(pp, 0, (size_t)ntiles * TILE * TILE * gx * sizeof(Partial), ctx->stream));   // (.s / .m of a slot come from different threads)
         if (metric == 0) {
-            static const bool pipe = [] { const char *e = getenv("KPAL_MATRIX_PIPE"); return e && atoi(e) != 0; }();
-            if (wide && pipe) LAUNCH(ctx, "matrix_rdiff_pipe", matrix_rdiff_pipe_kernel, dim3(gx), dim3(512), prof, P, n, pp, big);
-            else if (wide) LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<16, kMatrixAllBins, kMatrixAllUnits>), dim3(gx), dim3(1024 / kMatrixAllUnits), prof, P, n, pp, big);
+            if (wide) LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<16, kMatrixAllBins, kMatrixAllUnits>), dim3(gx), dim3(1024 / kMatrixAllUnits), prof, P, n, pp, big);
             else LAUNCH(ctx, "matrix_rdiff_all", (matrix_rdiff_all_kernel<8, 64, 1>), dim3(gx), dim3(256), prof, P, n, pp, big);
         } else {
             if (wide) LAUNCH(ctx, "matrix_rsum_all", (matrix_rsum_all_kernel<16, 64>), dim3(gx), dim3(1024), prof, P, n, pp, big);

@@ -496,193 +496,4 @@ __global__ __launch_bounds__((MatrixAllGeometry<S, B, 1>::kThreads), 4) void mat
     }
 }
 
-// matrix_rdiff_all_kernel<16, 64, 1> runs 6.7 M shader cycles for 64 profiles at k = 12 against 4.46 M of fp64 issue (2016 pairs x
-// 4^12 bins x 2 instructions x 4.25 cycles / 1024 SIMDs; profiles/r6/ab_mall_*.log): a wave issues its eight LDS reads, WAITS for
-// them, then runs 64 fp64 instructions -- with 128 registers per thread there is no room to have the next step's operands in
-// flight, and the three other waves of the SIMD do not fill the gap (a wave alone issues one instruction per 5.4 cycles).  This
-// form has 512 threads -- thread slot q works through slots q and q + 64, waves 0..6 two off-diagonal tiles, wave 7 an
-// off-diagonal tile and a diagonal slot -- and 256 registers: the reads of phase p + 1 (a phase = one slot x 16 bins) are issued
-// before the arithmetic of phase p, into a second set of registers.
-__global__ __launch_bounds__(512, 2) void matrix_rdiff_pipe_kernel(const int64_t *__restrict__ prof, int P, uint64_t n,
-                                                                     Partial *__restrict__ partials, uint32_t *__restrict__ big)
-{
-    constexpr int S = 16, B = 64, U = 2;
-    using G = MatrixAllGeometry<S, B, U>;
-    constexpr int R = G::kRows, NT = G::kThreads, NL = G::kLoads, RP = G::kRowPieces, ZP = G::kPairsPerThread;
-    static_assert(NT == 512 && NL == 4 && ZP == 4, "geometry");
-    __shared__ __attribute__((aligned(16))) double rstage[2][R][B];
-    __shared__ unsigned long long zmask[2][R];
-    __shared__ double rtable[kRdiffTable];
-    for (int i = threadIdx.x; i < kRdiffTable; i += NT) rtable[i] = rcp_counts((double)i + 1.0);
-    const uint32_t group = blockIdx.x, ngroups = gridDim.x;
-    const int tslot = threadIdx.x >> 3, l = threadIdx.x & 7;
-    const int side = (P + 3) / 4;
-    int xb[U], yb[U];
-    bool diag[U];
-#pragma unroll
-    for (int v = 0; v < U; ++v) matrix_all_slot<S>(tslot + v * (G::kSlots / U), xb[v], yb[v], diag[v]);
-    const bool wdiag = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 7;   // the wave's second slots are the diagonal ones
-    const int flipoff = 16 * ((tslot >> 1) & 1);       // doubles: the order in which the slot walks its rows' 128-byte pieces
-    double s[U][4][4];
-#pragma unroll
-    for (int v = 0; v < U; ++v)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) s[v][a][b] = 0.0;
-    int zi[ZP], zj[ZP];
-    uint32_t both_zero[ZP];
-#pragma unroll
-    for (int h = 0; h < ZP; ++h) {
-        const int p = min((int)threadIdx.x + NT * h, G::kPairs - 1);
-        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-        while (i * (i - 1) / 2 > p) --i;
-        while ((i + 1) * i / 2 <= p) ++i;
-        zi[h] = i;
-        zj[h] = p - i * (i - 1) / 2;
-        both_zero[h] = 0u;
-    }
-    uint32_t hi_seen = 0;
-    const int64_t *src[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int p = (int)threadIdx.x + NT * i;
-        src[i] = prof + (uint64_t)min(p / RP, P - 1) * n + 2 * (p % RP) + (uint64_t)group * B;
-    }
-    __syncthreads();                                   // the table
-    auto lookup = [&](const longlong2 &v, double2 &r) {
-        r.x = rtable[min((uint32_t)v.x, (uint32_t)kRdiffTable - 1u)];
-        r.y = rtable[min((uint32_t)v.y, (uint32_t)kRdiffTable - 1u)];
-    };
-    auto store = [&](int buf, int i, const longlong2 &v, double2 r) {
-        const int p = (int)threadIdx.x + NT * i;
-        const int row = p / RP, col = p % RP;
-        const uint32_t x = (uint32_t)v.x, y = (uint32_t)v.y;
-        hi_seen |= (uint32_t)((unsigned long long)v.x >> 32) | (uint32_t)((unsigned long long)v.y >> 32) | ((x | y) & ~(uint32_t)(kRdiffMaxCount - 1));
-        if (__builtin_amdgcn_ballot_w64((x | y) >= (uint32_t)kRdiffTable) != 0) {   // wave-uniform, rare
-            if (x >= (uint32_t)kRdiffTable) r.x = rcp_counts((double)x + 1.0);
-            if (y >= (uint32_t)kRdiffTable) r.y = rcp_counts((double)y + 1.0);
-        }
-        *reinterpret_cast<double2 *>(&rstage[buf][row][2 * col]) = r;
-        const unsigned long long z0 = __builtin_amdgcn_ballot_w64(x == 0), z1 = __builtin_amdgcn_ballot_w64(y == 0);
-        const unsigned long long mlo = (z0 & 0xFFFFFFFFull) | (z1 << 32), mhi = (z0 >> 32) | (z1 & 0xFFFFFFFF00000000ull);
-        if ((threadIdx.x & 31) == 0) zmask[buf][row] = (threadIdx.x & 32) ? mhi : mlo;
-    };
-    const uint64_t chunks = n / B;
-    const uint64_t hop = (uint64_t)ngroups * B;
-    uint64_t creq = group;
-    auto request = [&](longlong2 (&dst)[NL]) {
-        if (creq < chunks) {                           // block-uniform
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                dst[i] = *reinterpret_cast<const longlong2 *>(src[i]);
-                src[i] += hop;
-            }
-        }
-        creq += ngroups;
-    };
-    // phase ph of a stage: slot v = ph & 1, bins 16 (ph >> 1) .. + 15 (in the slot's own order)
-    const double *xbase[U], *ybase[U];
-#pragma unroll
-    for (int v = 0; v < U; ++v) {
-        xbase[v] = &rstage[0][4 * xb[v]][2 * l];
-        ybase[v] = &rstage[0][4 * yb[v]][2 * l];
-    }
-    auto load = [&](double2 (&rx)[4], double2 (&ry)[4], int cur, int ph) {
-        const int v = ph & 1, off = (16 * (ph >> 1)) ^ flipoff;
-        const double *xr = xbase[v] + cur * (R * B) + off, *yr = ybase[v] + cur * (R * B) + off;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            rx[a] = *reinterpret_cast<const double2 *>(xr + a * B);
-            ry[a] = *reinterpret_cast<const double2 *>(yr + a * B);
-        }
-    };
-#if defined(KPAL_MALL_CLOCK)
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    longlong2 next[NL];
-    uint64_t c = group;
-    uint64_t stages = 0;
-    request(next);
-    if (c < chunks) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            double2 r;
-            lookup(next[i], r);
-            store(0, i, next[i], r);
-        }
-    }
-    __syncthreads();
-    double2 bx[2][4], by[2][4];
-    for (int cur = 0; c < chunks; c += ngroups, ++stages, cur ^= 1) {
-        const bool more = c + ngroups < chunks;        // block-uniform
-        request(next);
-        unsigned long long zr[ZP], zc[ZP];
-#pragma unroll
-        for (int h = 0; h < ZP; ++h) {
-            zr[h] = zmask[cur][zi[h]];
-            zc[h] = zmask[cur][zj[h]];
-        }
-        load(bx[0], by[0], cur, 0);
-        double2 rnext[NL];
-#pragma unroll
-        for (int ph = 0; ph < 8; ++ph) {
-            if (ph + 1 < 8) load(bx[(ph + 1) & 1], by[(ph + 1) & 1], cur, ph + 1);
-            if (ph == 5 && more) {
-#pragma unroll
-                for (int i = 0; i < NL; ++i) lookup(next[i], rnext[i]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if ((ph & 1) && wdiag) matrix_all_terms<true>(s[ph & 1], bx[ph & 1], by[ph & 1]);
-            else matrix_all_terms<false>(s[ph & 1], bx[ph & 1], by[ph & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ph == 0) {
-#pragma unroll
-                for (int h = 0; h < ZP; ++h) both_zero[h] += (uint32_t)__popcll(zr[h] & zc[h]);
-            }
-            if (ph == 6 && more) {
-#pragma unroll
-                for (int i = 0; i < NL; ++i) store(cur ^ 1, i, next[i], rnext[i]);
-            }
-        }
-        __syncthreads();
-    }
-#if defined(KPAL_MALL_CLOCK)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        reinterpret_cast<unsigned long long *>(big)[1] = __builtin_amdgcn_s_memtime() - clk0;
-        reinterpret_cast<unsigned long long *>(big)[2] = __builtin_amdgcn_s_memrealtime() - wall0;
-    }
-#endif
-    if (hi_seen) atomicOr(big, 1u);
-#pragma unroll
-    for (int v = 0; v < U; ++v) {
-        const uint64_t tx = (uint64_t)xb[v] * (xb[v] + 1) / 2, ty = (uint64_t)yb[v] * (yb[v] + 1) / 2;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                double ps = s[v][a][b];
-#pragma unroll
-                for (int d = 4; d >= 1; d >>= 1) ps += __shfl_down(ps, d, 8);
-                if (l != 0 || (diag[v] && a == b)) continue;
-                if (!diag[v]) {
-                    if (xb[v] < side) partials[((tx + yb[v]) * 16 + a * 4 + b) * ngroups + group].s = ps;
-                } else if (a > b) {
-                    if (xb[v] < side) partials[((tx + xb[v]) * 16 + a * 4 + b) * ngroups + group].s = ps;
-                } else {
-                    if (yb[v] < side) partials[((ty + yb[v]) * 16 + b * 4 + a) * ngroups + group].s = ps;
-                }
-            }
-    }
-#pragma unroll
-    for (int h = 0; h < ZP; ++h) {
-        const int i = zi[h], j = zj[h];
-        if ((int)threadIdx.x + NT * h < G::kPairs && i < P) {
-            const int pti = i / 4, ptj = j / 4;
-            const uint64_t t = (uint64_t)pti * (pti + 1) / 2 + ptj;
-            partials[(t * 16 + (i % 4) * 4 + (j % 4)) * ngroups + group].m = stages * B - both_zero[h];
-        }
-    }
-}
-
 }  // namespace kpal

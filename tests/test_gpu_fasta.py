@@ -299,15 +299,16 @@ def test_by_record_profiles_stay_in_hbm(ctx, tmp_path, monkeypatch):
     np.testing.assert_array_equal(h5['profiles/rec11'][:], want[11])
     assert profiles[11]._device_counts() is None
     # the budget: nothing stays on the device past it
-    del profiles, sub, c, arr
+    del profiles, sub, c, arr, p                                               # (p: the loop variable above still holds the last profile)
     gc.collect()
     assert klib._DeviceBatch.live_bytes == live0
     monkeypatch.setattr(klib, '_DEVICE_PROFILE_BYTES', 10 * 8 * 4 ** k)
     mixed = list(klib.Profile.from_fasta_by_record(io.StringIO(text), k))
-    assert [p._device_counts() is not None for p in mixed] == [True] * 7 + [False] * (len(recs) - 7)
-    for p, w in zip(mixed, want):
-        np.testing.assert_array_equal(p.counts, w)
-    del mixed
+    on_device = [m._device_counts() is not None for m in mixed]
+    assert on_device[:7] == [True] * 7 and on_device[7:14] == [False] * 7 and sum(on_device) <= 10       # (a batch is all or nothing)
+    for q, w in zip(mixed, want):
+        np.testing.assert_array_equal(q.counts, w)
+    del mixed, q
     gc.collect()
     assert klib._DeviceBatch.live_bytes == live0
 
