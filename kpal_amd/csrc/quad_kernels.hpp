@@ -751,6 +751,9 @@ __global__ __launch_bounds__(WAVES * 64) void quad_scatter_kernel(Span s, uint64
     const uint64_t row_bytes = (uint64_t)gridDim.x * rounds_cap * (uint64_t)(S * 4 * PAIR);
     const uint32_t thread_off = (uint32_t)((uint64_t)(threadIdx.x / (LPR * PAIR)) * row_bytes) + (threadIdx.x % (LPR * PAIR)) * 16u;
     auto store_rec = [&](int i) {
+#if defined(KPAL_AB_POOL_FILL)   // A/B timing builds (wrong counts): what records filled to 0.86 instead of 0.74 would store -- six of seven vectors
+        if (i % 7 == 6) return;
+#endif
         uint32_t o = thread_off;
         asm volatile("" : "+v"(o));             // (no FI hoisted 64-bit addresses)
         const uint64_t sc = (uint64_t)(i * (THREADS / (LPR * PAIR))) * row_bytes + ((uint64_t)blockIdx.x * rounds_cap + (round - 1u)) * (uint64_t)(S * 4 * PAIR);
@@ -1373,7 +1376,11 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             }
         }
 #endif
+#if defined(KPAL_AB_POOL_FILL)   // (... and read: six sevenths of the vectors, i.e. fewer null items to test AND fewer real ones: an upper bound of the gain)
+        const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4) / 7u * 6u;
+#else
         const uint32_t nvec = nrounds[g] * (uint32_t)(S / 4);
+#endif
         if (nvec == 0u) continue;                  // wave-uniform: this scatter workgroup wrote nothing
         // four 16-byte loads per lane in flight; the next four are requested before these are counted.  The loads are
         // UNCONDITIONAL (index clamped, value zeroed afterwards): predicated ones sit in basic blocks of their own, the
