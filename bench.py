@@ -192,7 +192,7 @@ def cpu_baseline(k, read_len, budget_reads, big=None):
     # ~2 s of fixed cost), every plan is compared by its RATE on its own sample, and the line says which sample the best one had.
     bases = budget_reads * read_len
     plans = [('private', min(most_private, 64), big if big is not None else buf)]
-    if big is not None and most_private >= 128:
+    if big is not None and most_private >= 128 and big.size >= 20_000_000 * (read_len + 1):   # (a second private plan only where its fixed cost amortises)
         plans.append(('private', 128, big))
     plans += [('shared', t, buf) for t in sorted(set([min(cores, 64), min(cores, 16)]), reverse=True)]
     best_rate, best_reads = 0.0, budget_reads

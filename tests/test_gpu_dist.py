@@ -24,7 +24,7 @@ def test_bench_single_gpu_small():
     """bench.py contract on a small workload: one JSON line with roofline and a true checksum."""
     import json
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
-                        '--reads', '2000000', '--cpu-reads', '200000', '--profile-reads', '100000'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        '--reads', '2000000', '--cpu-reads', '200000', '--cpu-big-reads', '1000000', '--profile-reads', '100000'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
@@ -119,12 +119,14 @@ def _build_fake_rccl(tmp_path):
     return lib
 
 
-def _run_world(tmp_path, world, **extra_env):
-    env = dict(os.environ, KPAL_RCCL_LIBRARY=_build_fake_rccl(tmp_path), KPAL_FAKE_RCCL_TIMEOUT_S='240', HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _start_world(lib, id_file, world, **extra_env):
+    env = dict(os.environ, KPAL_RCCL_LIBRARY=lib, KPAL_FAKE_RCCL_TIMEOUT_S='240', HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.update(extra_env)
-    id_file = str(tmp_path / 'comm_id')
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_world_rank.py'), str(r), str(world), id_file], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    return [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_world_rank.py'), str(r), str(world), id_file], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+
+
+def _finish_world(procs):
     outs = []
     try:
         for p in procs:
@@ -136,28 +138,45 @@ def _run_world(tmp_path, world, **extra_env):
     return procs, outs
 
 
+_ASYNC = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'}
+
+
+@pytest.fixture(scope='module')
+def worlds(tmp_path_factory):
+    """The five worlds of rccl_world_rank.py the tests below look at -- three with a fault switch of the stand-in, the healthy ones
+    of 2 and 4 ranks -- started TOGETHER (sixteen processes on the one GPU; each world has its own shared-memory file): run one
+    after the other they spent a minute of the GPU suite's time box mostly asleep in the stand-in's bounded waits."""
+    tmp = tmp_path_factory.mktemp('worlds')
+    lib = _build_fake_rccl(tmp)
+    started = {}
+    for fault in ('reduce', 'recv', 'early'):
+        extra = dict(_ASYNC) if fault == 'early' else {}
+        started['fault-' + fault] = _start_world(lib, str(tmp / ('id_' + fault)), 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='20', **extra)
+    for world in (2, 4):
+        started['async-%d' % world] = _start_world(lib, str(tmp / ('id_w%d' % world)), world, **_ASYNC)
+    return {name: _finish_world(procs) for name, procs in started.items()}
+
+
 @pytest.mark.parametrize('fault', ['reduce', 'recv', 'early'])
-def test_fake_rccl_world_test_has_teeth(tmp_path, fault):
+def test_fake_rccl_world_test_has_teeth(worlds, fault):
     """The test below must notice a transport that loses a rank's contribution to a reduce, delivers the wrong block of the
     mirrored-range exchange, or (asynchronous mode) lets the stream go on before the collective's data has arrived -- what a missing
     dependency between streams amounts to: with the stand-in told to do so, some rank has to fail an assertion (and none may hang)."""
-    extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if fault == 'early' else {}
-    procs, outs = _run_world(tmp_path, 2, KPAL_FAKE_RCCL_FAULT=fault, KPAL_FAKE_RCCL_TIMEOUT_S='8', **extra)
+    procs, outs = worlds['fault-' + fault]
     assert any(p.returncode != 0 for p in procs), outs
     assert any('AssertionError' in out for out in outs), outs
 
 
 @pytest.mark.parametrize('mode', ['async'])       # ('sync' -- every collective completed inside the call -- passes too and is the schedule with fewer ways to go wrong: tools/multi_rank_one_gpu.sh runs both)
 @pytest.mark.parametrize('world', [2, 4])
-def test_library_comm_world_over_fake_rccl(tmp_path, world, mode):
+def test_library_comm_world_over_fake_rccl(worlds, world, mode):
     """The library's kpal_comm_* protocol between W real processes on the one GPU of this box: RCCL refuses two ranks on one device,
     so KPAL_RCCL_LIBRARY points at a stand-in for the dozen entry points the library binds (tests/native/fake_rccl.cpp: shared
     memory between the processes, bounded waits).  Contexts, streams, events, kernels, offsets, the order of the collectives:
     all real (tests/rccl_world_rank.py says what is compared with the oracle).  async: the stand-in's calls return at once, as
     RCCL's do -- the stream is held by a host function until the communicator's worker thread has moved the data, (rank + 1) x 15 ms
     late, so every collective is in flight while the caller goes on queueing work (the pipelined reduce: the next count)."""
-    extra = {'KPAL_FAKE_RCCL_ASYNC': '1', 'KPAL_FAKE_RCCL_DELAY_MS': '15'} if mode == 'async' else {}
-    procs, outs = _run_world(tmp_path, world, **extra)
+    procs, outs = worlds['async-%d' % world]
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and 'RCCL_WORLD_OK rank %d of %d' % (r, world) in out, 'rank %d:\n%s' % (r, out[-3000:])
 

@@ -10,7 +10,7 @@
 #   bench_k15_*                        BASELINE config 4 as its own command, + kernel stats
 #   matrix_k12_P64_*                   BASELINE config 5 (multiset prod, euclidean) as its own command, + kernel stats
 set -u
-ROUND=${1:-r5}
+ROUND=${1:-r6}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT" "$ROOT/profiles/$ROUND"
@@ -67,7 +67,10 @@ cd /tmp
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_fetch_matrix.err"
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_write_matrix.err"
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_matrix" "$OUT/pmc_write_matrix" 0 \
-  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around python3 bench.py $M5 (64 profiles, k = 12, multiset prod); gfx950 correction: FETCH_SIZE x2" matrix_rdiff > "$OUT/pmc_hbm_traffic_matrix.json"
+  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around python3 bench.py $M5 (64 profiles, k = 12, multiset prod); gfx950 correction: FETCH_SIZE x2" matrix_rdiff_all > "$OUT/pmc_hbm_traffic_matrix.json"
+rocprofv3 --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_VALU -d "$OUT/pmc_sq_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_sq_matrix.err"
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d "$OUT/pmc_wave_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_wave_matrix.err"
+python3 "$ROOT/tools/pmc_counters.py" "rocprofv3 --pmc (two passes) -- python3 bench.py $M5 (64 profiles, k = 12, multiset prod: matrix_rdiff_all)" "$OUT/pmc_sq_matrix" "$OUT/pmc_wave_matrix" > "$OUT/pmc_sq_matrix.json"
 rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum -d "$OUT/pmc_l2_matrix" -o p -- python3 "$B" $M5 > /dev/null 2> "$OUT/pmc_l2_matrix.err"
 python3 - "$OUT/pmc_l2_matrix" > "$OUT/pmc_l2_matrix.json" <<'PY'
 import collections, csv, json, os, sys
@@ -96,13 +99,15 @@ python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_fetch_vec" "$OUT/pmc_write_vec" 0
 cd "$ROOT"
 python3 tools/clibench.py --gb 8 > "$OUT/clibench.json" 2> "$OUT/clibench.err"
 python3 tools/hostbench.py --reads 20000000 2>&1 | head -8 > "$OUT/hostbench.log"
-for g in join gather; do KPAL_GATHERER=$g python3 tools/seqbench.py 2>&1 | grep -v amdgpu; done > "$OUT/seqbench.log"
+for t in 1 16; do KPAL_GATHER_THREADS=$t python3 tools/seqbench.py 2>&1 | grep -v amdgpu; done > "$OUT/seqbench.log"
 python3 tools/clibench.py --by-record > "$OUT/clibench_by_record.json" 2> "$OUT/clibench_by_record.err"
 # ---- skewed inputs
 python3 tools/skewbench.py > "$OUT/skewbench_k12.log" 2>&1
 python3 tools/skewbench.py --k 15 > "$OUT/skewbench_k15.log" 2>&1
 python3 tools/skewdiag.py > "$OUT/skewdiag_k12.log" 2> /dev/null
 python3 tools/skewdiag.py --k 15 > "$OUT/skewdiag_k15.log" 2> /dev/null
+# ---- what a vector instruction costs to issue (round 6: the scatter's opcode mix priced with measured costs)
+hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_bench tools/valu_bench.hip 2> /dev/null && timeout 300 /tmp/valu_bench > "$OUT/valu_bench.log" 2>&1
 # ---- LDS primitives (what an LDS atomic costs with and without bank conflicts)
 hipcc -O3 --offload-arch=gfx950 -o /tmp/lds_bench tools/lds_bench.hip 2> /dev/null && timeout 300 /tmp/lds_bench > "$OUT/lds_bench.log" 2>&1
 # ---- the N > 1 path of bench.py with 2, 3, 4 and 8 real ranks on this one GPU over the test stand-in for RCCL, synchronous and
