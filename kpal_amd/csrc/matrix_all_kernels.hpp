@@ -217,6 +217,14 @@ __global__ __launch_bounds__((MatrixAllGeometry<S, B, U>::kThreads), S == 16 ? 4
         }
 #endif
     };
+#if defined(KPAL_MALL_PRIO)   // A/B: a fixed priority per wave of a SIMD (waves w, w + 4, w + 8, w + 12 share one)
+    switch ((threadIdx.x >> 8) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+#endif
 #if defined(KPAL_MALL_CLOCK)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), wall0 = __builtin_amdgcn_s_memrealtime();
 #endif

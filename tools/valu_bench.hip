@@ -24,7 +24,7 @@
 enum Op {
     FMA_F32 = 0, ADD_F64, FMA_F64, PERM, DOT4, LSHL_OR, AND_OR, BFE, LSHRREV_B64, MOV_DPP_SHR, READLANE, ADD_U32, LSHLREV, XOR, CNDMASK,
     BCNT, MBCNT, CMP_EQ, ADD3, MUL_LO, MUL_U24, MAD_U24, SAD, CVT_F64_U32, ALIGNBIT, PK_ADD_F32, ADD_LSHL, MOV, LSHL_ADD, OR3, MIX_SCATTER, NOPS,
-    BITOP3, LSHRREV, AND, OR, SUB, NOT, CNDMASK_SGPR, CNDMASK_ALT, LSHL_ADD_U64, CMP_GT_U64, WRITELANE, CMP_CNDMASK
+    BITOP3, LSHRREV, AND, OR, SUB, NOT, CNDMASK_SGPR, CNDMASK_ALT, LSHL_ADD_U64, CMP_GT_U64, WRITELANE, CMP_CNDMASK, ABSDIFF_F64, ABSDIFF_F64_FAR
 };
 
 #define ONE8(INS)                                                                                                                 \
@@ -90,6 +90,9 @@ __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t seed, u
         r[u] = seed * (threadIdx.x + 1u) + u;
         d[u] = 1.0 + (double)(threadIdx.x + u) * 1e-9;
     }
+    double e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = 1.0 / (double)(threadIdx.x * 4 + u + seed + 1);   // (operands with full mantissas: the power they draw)
     const uint32_t c0 = seed ^ 0x01020304u, c1 = seed | 0x03020100u;
     const uint32_t sc = seed;
     const double dc = 1.0000001;
@@ -157,6 +160,22 @@ __global__ __launch_bounds__(1024) void bench_kernel(int iters, uint32_t seed, u
                              : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
                              :
                              : "s44");
+            } else if constexpr (OP == ABSDIFF_F64 || OP == ABSDIFF_F64_FAR) {
+                // the matrix kernels' term: t = x - y; acc += |t| -- three different register pairs per instruction, the second
+                // instruction reads the first one's result (ABSDIFF_F64: back to back; _FAR: four instructions later)
+                if constexpr (OP == ABSDIFF_F64) {
+                    asm volatile("v_add_f64 %0, %8, -%9\n v_add_f64 %4, |%0|, %4\n v_add_f64 %1, %9, -%10\n v_add_f64 %5, |%1|, %5\n"
+                                 "v_add_f64 %2, %10, -%11\n v_add_f64 %6, |%2|, %6\n v_add_f64 %3, %11, -%8\n v_add_f64 %7, |%3|, %7\n"
+                                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+                                 : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3])
+                                 :);
+                } else {
+                    asm volatile("v_add_f64 %0, %8, -%9\n v_add_f64 %1, %9, -%10\n v_add_f64 %2, %10, -%11\n v_add_f64 %3, %11, -%8\n"
+                                 "v_add_f64 %4, |%0|, %4\n v_add_f64 %5, |%1|, %5\n v_add_f64 %6, |%2|, %6\n v_add_f64 %7, |%3|, %7\n"
+                                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+                                 : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3])
+                                 :);
+                }
             } else if constexpr (OP == LSHL_ADD_U64) ONE8D(I_LSHL_ADD_U64);
             else if constexpr (OP == CMP_GT_U64) {
                 asm volatile(I_CMP_GT_U64(0) I_CMP_GT_U64(1) I_CMP_GT_U64(2) I_CMP_GT_U64(3) I_CMP_GT_U64(4) I_CMP_GT_U64(5) I_CMP_GT_U64(6) I_CMP_GT_U64(7)
@@ -286,5 +305,7 @@ int main()
     run<WRITELANE>("v_writelane_b32", dout);
     run<LSHL_ADD_U64>("v_lshl_add_u64", dout);
     run<CMP_GT_U64>("v_cmp_gt_u64 -> vcc", dout);
+    run<ABSDIFF_F64>("t=x-y; acc+=|t| (f64)", dout);
+    run<ABSDIFF_F64_FAR>("... 4 apart", dout);
     return 0;
 }
