@@ -219,6 +219,10 @@ def cpu_baseline(k, read_len, budget_reads, big=None):
         'sample': '%d synthetic %d bp reads, k=%d, oracle/kpal_oracle.c (1 thread: %.2f s)' % (budget_reads, read_len, k, t1),
         # the same figures as scalars (the driver's record keeps scalars only): all host cores, and the reference's own speed class
         'all_cores_value': best_rate / 1e9, 'all_cores_threads': best_threads, 'all_cores_tables': best_mode, 'all_cores_sample_reads': best_reads, 'host_cores': cores,
+        # (why not more threads: every plan's seconds are in all_cores.seconds_by_threads -- on the MI355X hosts 64 and 128 threads with a
+        # private 128 MiB table each count 40 M reads in 7.1 and 10.2 s, 0.85 and 0.59 Gbases/s: random increments into T x 128 MiB miss the
+        # TLB and the caches on every k-mer, and one shared table with atomic adds stops scaling at ~16 threads)
+        'all_cores_plans_tried': ', '.join('%s %.2f s' % kv for kv in sorted(tried.items())),
         'python_loop_value': 1.5e6 / tp / 1e9, 'python_loop_sample': 'BASELINE config 1 (10000 reads, k=9), pure-Python restatement of klib.py:149-170, 1 core',
         'all_cores': {'value': best_rate / 1e9, 'cores': best_threads, 'host_cores': cores, 'seconds': tn, 'sample_reads': best_reads,
                       'per_thread_efficiency': best_rate / (bases / t1) / best_threads,
