@@ -1266,10 +1266,23 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         if constexpr (C::kStaged) {
             if (i == 0) return local ^ (((local >> 8) & 7u) << 3);                                   // hipart[3:1] -> bits 5:3 (t's low bits); a
                                                                                                       // staging lane reads hipart 2j and 2j+1
-            if (i == 1) return local ^ (((local >> 9) & 1u) << 5) ^ (((local >> 10) & 3u) << 3);   // hipart[0] -> bit 5, hipart[2:1] -> bits 4:3
+            if (i == 1) return local ^ (((local >> 9) & 7u) << 3);                                     // hipart[2:0] -> bits 5:3 (two lanes share a
+                                                                                                      // hipart: bits 4:3 also tell the lane's half and h)
         }
         return local;
     };
+    // One LDS add per k-mer -- and the histogram is bound by VALU issue as much as by the adds (75 % against 69 % busy,
+    // profiles/r6/pmc_lds_quad.json; a three-operand or bit-field instruction costs 4.25 cycles of a SIMD, a plain shift right /
+    // and / or / v_bitop3 2.5: tools/valu_bench.hip), so the fast path is spelled in the cheap ones (!PACKED: 32-bit bins):
+    //   * the BYTE offset of bin `local` is (item >> (8 - 2i)) & ((2^L - 1) << 2) -- no v_bfe_u32, no shift left by two;
+    //   * the staging swizzle of forms 0 and 1 works on that byte offset (the same bits, two places up);
+    //   * a k-mer adds item & (8 >> i) -- its mask bit where it stands: 8, 4, 2 or 1 (or 0) -- instead of the extracted bit:
+    //     plane i counts in UNITS of 8 >> i, and whoever reads a plane (staging, merge) shifts right by 3 - i.  (A bin holds at
+    //     most 20 items per tile and scatter workgroup -- a row's capacity --, 2.6 M for a 16 GiB piece: x 8 stays far below 2^32.)
+    uint32_t plane_base[2] = {2u * (uint32_t)(BINS * 4), 3u * (uint32_t)(BINS * 4)};   // byte offsets of planes 2 and 3, kept in registers
+    asm volatile("" : "+v"(plane_base[0]), "+v"(plane_base[1]));
+    constexpr bool kUnits = !PACKED;                    // plane i holds counts << unit_shift(i)
+    auto unit_shift = [](int i) -> int { return kUnits ? 3 - i : 0; };
     auto add_item = [&](uint32_t it, auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
         // bin of k-mer i in its form: the low 6-2i bits of hi6 above the top L-6+2i bits of low -- with the item laid out
@@ -1283,8 +1296,51 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                     const uint32_t local = __builtin_amdgcn_ubfe(it, 8 - 2 * i, L + 2);                  // 15 bits at k = 12
                     atomicAdd(&hist[(uint32_t)(i / 2) * (uint32_t)(2 * BINS) + (local >> 1)], counted << (16u * (local & 1u)));
                 } else {
-                    atomicAdd(&hist[plane_of(i) + stage_swizzle(i, __builtin_amdgcn_ubfe(it, 10 - 2 * i, L))], counted);
+                    atomicAdd(&hist[plane_of(i) + stage_swizzle(i, __builtin_amdgcn_ubfe(it, 10 - 2 * i, L))], counted << unit_shift(i));
                 }
+            }
+            return;
+        }
+#endif
+#if !defined(KPAL_AB_HIST_OLD_SPELLING)   // (A/B: the bit-field spelling of rounds 2-5 below)
+        if constexpr (!GUARD && !PACKED) {
+            char *base = reinterpret_cast<char *>(hist);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t off = (it >> (8 - 2 * i)) & (((1u << L) - 1u) << 2);          // 4 * local
+#if !defined(KPAL_AB_NO_STAGE_SWIZZLE)
+                if constexpr (C::kStaged) {                                             // (stage_swizzle, two places up)
+                    if (i == 0) off ^= (off >> 5) & 0xE0u;
+                    if (i == 1) off ^= (off >> 6) & 0xE0u;
+                }
+#endif
+                if (i >= 2 && BINS * 4 * 2 > 65535) {
+                    // (planes 2 and 3 lie beyond the 16-bit offset field of a DS instruction: their base is OR-ed in -- by the same
+                    // v_bitop3_b32 that masks, (x & mask) | plane, where the compiler writes a v_and_b32 and a v_or_b32)
+                    const uint32_t shifted = it >> (8 - 2 * i);
+                    uint32_t addr;
+                    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(addr) : "v"(shifted), "s"(((1u << L) - 1u) << 2), "v"(plane_base[i - 2]));
+                    atomicAdd(reinterpret_cast<uint32_t *>(base + addr), it & (8u >> i));
+                } else {
+                    atomicAdd(reinterpret_cast<uint32_t *>(base + ((uint32_t)i * (uint32_t)(BINS * 4) | off)), it & (8u >> i));
+                }
+            }
+            return;
+        }
+#endif
+#if !defined(KPAL_AB_HIST_OLD_SPELLING)
+        if constexpr (!GUARD && PACKED) {                  // (16-bit halves: no room for units; the byte offsets as above)
+            char *base = reinterpret_cast<char *>(hist);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t off = (it >> (8 - 2 * i)) & (((1u << L) - 1u) << 2);
+#if !defined(KPAL_AB_NO_STAGE_SWIZZLE)
+                if (i == 0) off ^= (off >> 5) & 0xE0u;
+                if (i == 1) off ^= (off >> 6) & 0xE0u;
+#endif
+                // forms 0, 1: the mask bit as 0 / 1 in the low half; forms 2, 3: moved to bit 16 (the high half of the word of forms 0, 1)
+                const uint32_t value = i < 2 ? __builtin_amdgcn_ubfe(it, 3 - i, 1) : ((it << (13 + i)) & 0x10000u);
+                atomicAdd(reinterpret_cast<uint32_t *>(base + ((uint32_t)(i & 1) * (uint32_t)(BINS * 4) | off)), value);
             }
             return;
         }
@@ -1297,10 +1353,10 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                 const uint32_t hot = __builtin_amdgcn_readfirstlane(local);
                 const bool eq = counted && local == hot;
                 const uint32_t same = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(eq));
-                atomicAdd(&hist[eq ? (uint32_t)(PLANES * BINS + lane) : plane_of(i) + local], counted << shift_of(i));
-                if (same && lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[plane_of(i) + hot], same << shift_of(i));
+                atomicAdd(&hist[eq ? (uint32_t)(PLANES * BINS + lane) : plane_of(i) + local], counted << (shift_of(i) + unit_shift(i)));
+                if (same && lane == (__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1)) atomicAdd(&hist[plane_of(i) + hot], same << (shift_of(i) + unit_shift(i)));
             } else {
-                atomicAdd(&hist[plane_of(i) + local], counted << shift_of(i));
+                atomicAdd(&hist[plane_of(i) + local], counted << (shift_of(i) + unit_shift(i)));
             }
         }
     };
@@ -1459,6 +1515,10 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
                     const int sh = shift_of(i);                        // (wave-uniform: a plane is 512 vectors)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) c[e] = (c[e] >> sh) & 0xFFFFu;
+                } else {
+                    const int sh = unit_shift(i);                      // (the plane's unit; wave-uniform)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) c[e] >>= sh;
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) any |= c[e];
@@ -1483,7 +1543,7 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             for (int local = threadIdx.x; local < BINS; local += blockDim.x) {
-                const uint32_t c = hist[i * BINS + stage_swizzle(i, (uint32_t)local)];   // (k = 12 keeps forms 0 and 1 swizzled for the staging read)
+                const uint32_t c = hist[i * BINS + stage_swizzle(i, (uint32_t)local)] >> unit_shift(i);   // (k = 12 keeps forms 0 and 1 swizzled for the staging read)
                 if (c) atomicAdd(&table.table[quad_bin_index<K>(row, coarse, i, (uint32_t)local)], (unsigned long long)c);
             }
         }
