@@ -306,6 +306,14 @@ class Profile(object):
     def counts(self, value):
         self._counts, self._device = value, None
 
+    # (pickling / copy.deepcopy of a profile whose table is still in HBM: the counts travel, the device handle does not)
+    def __getstate__(self):
+        return {'counts': self.counts, 'name': self._name, 'length': self.length}
+
+    def __setstate__(self, state):
+        self._counts, self._device = state['counts'], None
+        self.length, self._name = state['length'], state['name']
+
     def _device_counts(self):
         """(context, device address) of the int64 table while it lives in HBM only, else None."""
         if self._counts is None and self._device is not None:

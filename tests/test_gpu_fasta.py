@@ -281,6 +281,12 @@ def test_by_record_profiles_stay_in_hbm(ctx, tmp_path, monkeypatch):
     assert same(dists[0].distance(c, profiles[5]), dists[0].distance(host[4], host[5]))      # the copy still has the counted table
     profiles[6].counts = want[6] * 2                                           # the setter drops the device copy as well
     assert profiles[6]._device_counts() is None and int(profiles[6].total) == 2 * int(want[6].sum())
+    import copy as _copy
+    import pickle
+    for clone in (_copy.deepcopy(profiles[12]), pickle.loads(pickle.dumps(profiles[13]))):      # the counts travel, not the device handle
+        assert clone._device_counts() is None
+    np.testing.assert_array_equal(_copy.deepcopy(profiles[12]).counts, want[12])
+    np.testing.assert_array_equal(pickle.loads(pickle.dumps(profiles[13])).counts, want[13])
     profiles[9].balance()
     np.testing.assert_array_equal(profiles[9].counts, oracle.balance(want[9], k))
     # mixed: some on the device, some on the host -> the host path, same text
