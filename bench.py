@@ -192,8 +192,8 @@ def cpu_baseline(k, read_len, budget_reads, big=None):
     # ~2 s of fixed cost), every plan is compared by its RATE on its own sample, and the line says which sample the best one had.
     bases = budget_reads * read_len
     plans = [('private', min(most_private, 64), big if big is not None else buf)]
-    if big is not None and most_private >= 128 and big.size >= 20_000_000 * (read_len + 1):   # (a second private plan only where its fixed cost amortises)
-        plans.append(('private', 128, big))
+    # (128 threads with a private table each were timed in round 6 as well: 10.2 s for the 40 M reads against 7.1 s with 64 -- slower, so
+    # the default line does not spend ten seconds on it again; profiles/r6/bench_k12_n1.json holds both)
     plans += [('shared', t, buf) for t in sorted(set([min(cores, 64), min(cores, 16)]), reverse=True)]
     best_rate, best_reads = 0.0, budget_reads
     for mode, threads, sample in plans:
