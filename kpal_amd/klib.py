@@ -354,7 +354,7 @@ class Profile(object):
             # counting pipelined chunk by chunk; no byte of the text passes through Python
             ctx.count_feed_fasta_file(plain[0], plain[1], 0)
             handle.seek(0, os.SEEK_END)      # the handle has been consumed, as by the reference's SeqIO.parse loop
-            return cls(ctx.count_finish(), name=name)
+            return cls._finish_count(ctx, length, name)
         reader = handle
         if isinstance(handle, io.TextIOWrapper):
             try:                              # a pipe or a decompressing wrapper in an ASCII-compatible text encoding: its bytes, undecoded
@@ -389,7 +389,7 @@ class Profile(object):
                 carry = text[begin:]
         if carry:
             ctx.count_feed_fasta(carry)
-        return cls(ctx.count_finish(), name=name)
+        return cls._finish_count(ctx, length, name)
 
     @classmethod
     def from_fasta_by_record(cls, handle, length, prefix=None):
@@ -480,6 +480,22 @@ class Profile(object):
                     yield profile
 
     @classmethod
+    def _finish_count(cls, ctx, length, name):
+        """The finished count of ``ctx`` as a profile.  The table stays in HBM -- copied device-to-device out of the context's
+        count table, which the next count reuses, into an allocation of its own -- until something asks for ``counts``
+        (`kpal count` saving it: the one download it always was; a distance between two freshly counted profiles: none at all);
+        past the budget of live device tables it is downloaded at once."""
+        nbytes = 8 * 4 ** length
+        if _DEVICE_PROFILE_BYTES and _DeviceBatch.live_bytes + nbytes <= _DEVICE_PROFILE_BYTES:
+            ctx.count_finish(to_host=False)
+            table, _ = ctx.count_table()
+            batch = _DeviceBatch(ctx, nbytes, 1)
+            ctx.d2d(batch.ptr, table, nbytes)
+            ctx.sync()
+            return cls._from_device(batch, 0, length, name)
+        return cls(ctx.count_finish(), name=name)
+
+    @classmethod
     def _record_batch(cls, ctx, length, first, n, names):
         """The profiles of records [first, first + n) of the text the context has indexed.  Their tables stay in HBM (one
         allocation per batch) while the budget of live device tables allows; else they are downloaded at once."""
@@ -504,7 +520,7 @@ class Profile(object):
         ctx.count_begin(length)
         if _kpal_gather is not None:
             _gather_feed(ctx, sequences)
-            return cls(ctx.count_finish(), name=name)
+            return cls._finish_count(ctx, length, name)
         it = iter(sequences)
         pending = []
         size = 0
@@ -521,7 +537,7 @@ class Profile(object):
                 pending, size = [], 0
         if pending:
             ctx.count_feed(pending[0] if len(pending) == 1 else b'\n'.join(pending))
-        return cls(ctx.count_finish(), name=name)
+        return cls._finish_count(ctx, length, name)
 
     # ---- properties ------------------------------------------------------------------------
     @property

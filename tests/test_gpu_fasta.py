@@ -319,6 +319,47 @@ def test_by_record_profiles_stay_in_hbm(ctx, tmp_path, monkeypatch):
     assert klib._DeviceBatch.live_bytes == live0
 
 
+def test_counted_profiles_stay_in_hbm(monkeypatch):
+    """Profile.from_sequences / from_fasta leave the finished table in HBM as well (a device-to-device copy out of the context's
+    count table): a distance between two freshly counted profiles moves no table, `total` / `non_zero` come from the device, the
+    first look at ``counts`` downloads; with the budget at zero the table comes to the host at once, as before round 6."""
+    import gc
+    from kpal_amd import kdistlib, klib
+    reads_a = oracle.synth_reads(41, 0, 3000, 150, noisy=True)
+    reads_b = oracle.synth_reads(42, 0, 2500, 150, noisy=True)
+    seqs_a = [bytes(r) for r in reads_a.reshape(-1, 151)[:, :150]]
+    text_b = ''.join('>r%d\n%s\n' % (i, bytes(r).decode('latin-1')) for i, r in enumerate(reads_b.reshape(-1, 151)[:, :150]))
+    gc.collect()
+    live0 = klib._DeviceBatch.live_bytes
+    for k in (5, 9, 13):
+        want_a, want_b = oracle.count_flat(reads_a, k), oracle.from_sequences([s for _, s in seqio_records(text_b)], k)
+        pa = klib.Profile.from_sequences(seqs_a, k, name='a')
+        pb = klib.Profile.from_fasta(io.StringIO(text_b), k, name='b')
+        assert pa._device_counts() is not None and pb._device_counts() is not None
+        assert klib._DeviceBatch.live_bytes - live0 == 2 * 8 * 4 ** k
+        assert int(pa.total) == int(want_a.sum()) and int(pb.non_zero) == int(np.count_nonzero(want_b)) and pa.number == 4 ** k
+        for d, kw in ((kdistlib.ProfileDistance(), {}), (kdistlib.ProfileDistance(do_balance=True), {'do_balance': True})):
+            got = d.distance(pa, pb)
+            want = oracle.distance(want_a, want_b, k, **kw)
+            assert abs(got - want) <= 1e-9 * abs(want), (k, kw)
+        assert pa._device_counts() is not None and pb._device_counts() is not None
+        # a second count on the same context does not disturb the first profile's table
+        pc = klib.Profile.from_sequences(seqs_a[:100], k)
+        np.testing.assert_array_equal(pa.counts, want_a)
+        np.testing.assert_array_equal(pb.counts, want_b)
+        assert pa._device_counts() is None
+        np.testing.assert_array_equal(pc.counts, oracle.from_sequences([s.decode('latin-1') for s in seqs_a[:100]], k))
+        pa.balance()
+        np.testing.assert_array_equal(pa.counts, oracle.balance(want_a, k))
+        del pa, pb, pc
+        gc.collect()
+        assert klib._DeviceBatch.live_bytes == live0
+    monkeypatch.setattr(klib, '_DEVICE_PROFILE_BYTES', 0)
+    ph = klib.Profile.from_sequences(seqs_a, 9)
+    assert ph._device_counts() is None
+    np.testing.assert_array_equal(ph.counts, oracle.count_flat(reads_a, 9))
+
+
 def test_fasta_records_c_abi(ctx, tmp_path):
     """kpal_fasta_records_* through the binding: the index (header offsets into the text, record starts in the flattened stream),
     batches of any size at any record (also starting in the middle of a 16-byte chunk of the flattened text), errors, and
