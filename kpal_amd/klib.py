@@ -52,9 +52,17 @@ class _DeviceBatch(object):
     one is dropped or materialised."""
     live_bytes = 0
 
+    _POOL_BYTES = 1 << 30      # freed allocations a context keeps for the next batch of the same size (hipMalloc + hipFree of a
+                               # 128 MiB table cost a from_sequences call of a million reads 5 of its 23 ms)
+
     def __init__(self, ctx, nbytes, n_tables):
         self.ctx, self.nbytes, self.n_tables = ctx, int(nbytes), int(n_tables)
-        self.ptr = ctx.alloc(self.nbytes)
+        pool = getattr(ctx, '_table_pool', None)
+        if pool and pool.get(self.nbytes):
+            self.ptr = pool[self.nbytes].pop()
+            ctx._table_pool_bytes -= self.nbytes
+        else:
+            self.ptr = ctx.alloc(self.nbytes)
         self.host = None
         _DeviceBatch.live_bytes += self.nbytes
 
@@ -71,8 +79,15 @@ class _DeviceBatch(object):
     def __del__(self):
         try:
             _DeviceBatch.live_bytes -= self.nbytes
-            if getattr(self.ctx, '_h', None):      # (a context that has been closed took its allocations with it)
-                self.ctx.free(self.ptr)
+            ctx = self.ctx
+            if getattr(ctx, '_h', None):           # (a context that has been closed took its allocations with it)
+                if getattr(ctx, '_table_pool', None) is None:
+                    ctx._table_pool, ctx._table_pool_bytes = {}, 0
+                if ctx._table_pool_bytes + self.nbytes <= _DeviceBatch._POOL_BYTES:
+                    ctx._table_pool.setdefault(self.nbytes, []).append(self.ptr)
+                    ctx._table_pool_bytes += self.nbytes
+                else:
+                    ctx.free(self.ptr)
         except Exception:       # pragma: no cover  (interpreter shutdown)
             pass
 
