@@ -1461,25 +1461,6 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
         };
         uint32_t v = part * 256u + lane;
         uint4 q0 = fetch(v), q1 = fetch(v + 64u), q2 = fetch(v + 128u), q3 = fetch(v + 192u);
-#if defined(KPAL_HIST_DEPTH2)   // A/B: TWO batches of four vectors requested ahead of the one being counted
-        const uint32_t hop = parts * 256u;
-        uint4 n0 = fetch(v + hop), n1 = fetch(v + hop + 64u), n2 = fetch(v + hop + 128u), n3 = fetch(v + hop + 192u);
-        while (v < nvec) {
-            v += hop;
-            const uint4 m0 = fetch(v + hop), m1 = fetch(v + hop + 64u), m2 = fetch(v + hop + 128u), m3 = fetch(v + hop + 192u);
-#if defined(KPAL_AB_HIST_NO_ADD)
-            asm volatile("" ::"v"(q0.x ^ q0.y ^ q0.z ^ q0.w ^ q1.x ^ q1.y ^ q1.z ^ q1.w ^ q2.x ^ q2.y ^ q2.z ^ q2.w ^ q3.x ^ q3.y ^ q3.z ^ q3.w));
-#else
-            const bool skew = repeats(q0);
-            add4(q0, skew);
-            add4(q1, skew);
-            add4(q2, skew);
-            add4(q3, skew);
-#endif
-            q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            n0 = m0, n1 = m1, n2 = m2, n3 = m3;
-        }
-#else
         while (v < nvec) {
             v += parts * 256u;
             const uint4 n0 = fetch(v), n1 = fetch(v + 64u), n2 = fetch(v + 128u), n3 = fetch(v + 192u);
@@ -1497,7 +1478,6 @@ __global__ __launch_bounds__(1024) void quad_hist_kernel(const uint32_t *__restr
             q2 = n2;
             q3 = n3;
         }
-#endif
     }
 #if !defined(KPAL_QUAD_NO_PRIO)
     __builtin_amdgcn_s_setprio(3);               // (staging / merging: every wave is needed)

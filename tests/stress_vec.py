@@ -88,5 +88,21 @@ while time.time() < t_end:
             got = ctx.distance_matrix(profs, k, metric[m], do_balance=bal)
             want = oracle.distance_matrix_values(profs, k, do_balance=bal, metric=m)
             assert all(close(x, y) for x, y in zip(got, want)), ('matrix', k, m, bal)
+    if 6 <= k <= 8 and rs.rand() < 0.25:
+        # 9 .. 70 profiles: the super-tile kernels (9..16, > 64) and the kernels that stage every profile once (17..64; 256 and 1024
+        # threads), on count-like vectors -- Poisson of a random mean with zero bins, a few counts past the reciprocal tables, an
+        # empty profile now and then
+        P = int(rs.randint(9, 71))
+        mean = float(rs.choice([0.3, 4.0, 60.0, 700.0]))
+        profs = [rs.poisson(mean, n).astype(np.int64) for _ in range(P)]
+        for pr in profs[::5]:
+            pr[rs.randint(0, n, 20)] = rs.randint(0, 3000, 20)
+        if rs.rand() < 0.3:
+            profs[int(rs.randint(P))][:] = 0
+        for m in ('prod', 'sum'):
+            bal = bool(rs.rand() < 0.3)
+            got = ctx.distance_matrix(profs, k, metric[m], do_balance=bal)
+            want = oracle.distance_matrix_values(profs, k, do_balance=bal, metric=m)
+            assert all(close(x, y) for x, y in zip(got, want)), ('matrix', k, P, m, bal)
     cases += 1
 print('vector stress ok: %d cases, seed %d' % (cases, a.seed))
